@@ -1,0 +1,325 @@
+// oracle/dtc_oracle.cpp -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+//
+// CPU restatement of the reference's `deltapq -task query` hot path
+// (RunhuiWang/DeltaPQ).  Only tests/, __graft_entry__.smoke() and the
+// cpu_baseline leg of bench.py may load this library; the product path
+// (deltapq_amd/csrc) never links, calls or falls back to anything in oracle/.
+//
+// PARITY UNPINNED.  The reference ships no tests, golden vectors or fixtures
+// for this path, and the reference itself cannot be
+// built in this image: deltapq_create_approx_tree.h:2 includes pq.h, whose
+// line 8 includes <opencv2/opencv.hpp>, and OpenCV is not installed.  This
+// file is therefore a line-by-line restatement of the reference's algorithm
+// written from reading its source, cross-checked only against a second,
+// independent restatement (oracle/dtc_oracle.py).  Every function cites the
+// reference lines it follows ("h:" = deltapq_create_approx_tree.h,
+// "main:" = deltapq_approx_tree_main.cpp).
+//
+// Things restated bit-for-bit on purpose:
+//   * LUT arithmetic: fp32 subtract, fp64 square, `float += double` (h:2841-2849)
+//   * incremental fp64 distance stack, per changed position "-from" then "+to",
+//     positions ascending (h:2896-2905)
+//   * heap admission `double dist < float top` and libstdc++ priority_queue
+//     op sequence, so tie order in the output is the reference's (h:2909-2914)
+//   * even-N quirk: the trailing node is reported with id N, not N-1 (h:2949,2970)
+//   * 3-bit depth fields in the pair byte, full byte for the trailing node
+//
+// Build: see oracle/Makefile (g++ -O2 -ffp-contract=off).
+
+#include <algorithm>
+#include <cerrno>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fcntl.h>
+#include <fstream>
+#include <queue>
+#include <string>
+#include <unistd.h>
+#include <utility>
+#include <vector>
+
+typedef unsigned char uchar;
+typedef unsigned int uint;
+
+namespace {
+
+// h:2054-2056  cmp_max: max-heap on the float distance only.
+struct CmpMax {
+    bool operator()(const std::pair<float, uint>& l, const std::pair<float, uint>& r) const {
+        return l.first < r.first;
+    }
+};
+typedef std::priority_queue<std::pair<float, uint>, std::vector<std::pair<float, uint>>, CmpMax> MaxHeap;
+
+// main:312-325  decoder[b] = {popcount(b), ascending set-bit indices}.
+struct Decoder {
+    uchar tab[256][9];
+    Decoder() {
+        for (int b = 0; b < 256; b++) {
+            int n = 0;
+            for (int j = 0; j < 8; j++)
+                if (b & (1 << j)) tab[b][++n] = (uchar)j;
+            tab[b][0] = (uchar)n;
+        }
+    }
+};
+const Decoder g_decoder;
+
+// h:2841-2849 / h:3750-3758.  m_sub_distances[i][j] is a float; the inner
+// statement is `float += pow(float - float, 2)`: the subtraction is fp32,
+// pow() promotes to double (the square of an fp32 value is exact in fp64),
+// and the compound assignment computes (double)acc + sq and rounds to float.
+void build_lut(const float* codebook, const float* query, int M, int K, int Ds, float* lut) {
+    for (int i = 0; i < M; i++) {
+        for (int j = 0; j < K; j++) {
+            float acc = .0f;
+            for (int k = 0; k < Ds; k++) {
+                volatile float diff = codebook[((size_t)i * K + j) * Ds + k] - query[i * Ds + k];
+                double d = (double)diff;
+                double sq = d * d;                   // == pow(diff, 2), exact
+                acc = (float)((double)acc + sq);
+            }
+            lut[(size_t)i * K + j] = acc;
+        }
+    }
+}
+
+// Byte source abstraction: in-memory (h:3726-3729) or 4 KB block reads from an
+// fd (h:2783-2804).
+struct MemSource {
+    const uchar* p;
+    long long off;
+    inline int next() { return p[off++]; }
+};
+
+struct FdSource {
+    uchar* buffer;          // 4096-aligned, 4096 bytes
+    int fd;
+    long long byte_offset;  // absolute offset in the file (header included)
+    long long max_n_bytes;
+    inline int next() {     // h:2783-2804
+        long long boffset = byte_offset % 4096;
+        int cid = buffer[boffset];
+        byte_offset += 1;
+        if (boffset + 1 == 4096) {
+            if (byte_offset < max_n_bytes) {
+                ssize_t r = read(fd, buffer, 4096);
+                (void)r;
+            }
+        }
+        return cid;
+    }
+};
+
+// The scan proper: h:2851-2982 and its in-memory twin h:3760-3890.
+// `lut` is M x K.  results: ids/dists of length top_k, ascending distance.
+// Optional all_dists (length num_codes): the float-rounded distance of every
+// DFS position (used by tests for the tie-aware comparison), optional
+// all_codes (num_codes x M): every decoded code.
+template <class Source>
+void scan(Source& src, const float* lut, int top_k, int M, int K, long long num_codes_ll,
+          int* out_ids, float* out_dists, float* all_dists, uchar* all_codes) {
+    uint num_codes = (uint)num_codes_ll;
+    MaxHeap max_heap;
+    double qdist = 0;
+    std::vector<uchar> stacks((size_t)M * M + 8, 0);
+    std::vector<uchar*> vecs_stack(M);
+    for (int i = 0; i < M; i++) vecs_stack[i] = stacks.data() + (size_t)i * M;
+    std::vector<double> dists_stack(M, 0);
+
+    for (int m = 0; m < M; m++) {                       // h:2866-2871
+        uchar cid = (uchar)src.next();
+        qdist += lut[(size_t)m * K + cid];
+        vecs_stack[0][m] = cid;
+    }
+    dists_stack[0] = qdist;
+    max_heap.push(std::make_pair((float)qdist, 0u));    // h:2873
+    if (all_dists) all_dists[0] = (float)qdist;
+    if (all_codes) memcpy(all_codes, vecs_stack[0], M);
+
+    auto process = [&](int depth, long id_to_report, long pos, bool store_dist) {
+        // h:2888: parent copy (one 8-byte word for M == 8; bytewise otherwise,
+        // as the trailing-node branch h:2954-2955 does)
+        memcpy(vecs_stack[depth], vecs_stack[depth - 1], M);
+        double dist = dists_stack[depth - 1];           // h:2889
+        uchar bitmap = (uchar)src.next();               // h:2891
+        int n_diff = g_decoder.tab[bitmap][0];
+        for (int j = 0; j < n_diff; j++) {              // h:2896-2905
+            int m = g_decoder.tab[bitmap][j + 1];
+            uchar cid = (uchar)src.next();
+            vecs_stack[depth][m] = cid;
+            uchar from = vecs_stack[depth - 1][m];
+            dist -= lut[(size_t)m * K + from];
+            dist += lut[(size_t)m * K + cid];
+        }
+        if (store_dist) dists_stack[depth] = dist;      // h:2907 (not in the trailing branch)
+        if ((int)max_heap.size() < top_k) {             // h:2909-2914
+            max_heap.emplace((float)dist, (uint)id_to_report);
+        } else if (dist < max_heap.top().first) {       // double < float
+            max_heap.pop();
+            max_heap.emplace((float)dist, (uint)id_to_report);
+        }
+        if (all_dists) all_dists[pos] = (float)dist;
+        if (all_codes) memcpy(all_codes + (size_t)pos * M, vecs_stack[depth], M);
+    };
+
+    long i = 1;
+    for (; i + 1 < (long)num_codes; i = i + 2) {        // h:2876
+        int depths = src.next();
+        process(depths & 7, i, i, true);                // h:2883
+        process((depths >> 4) & 7, i + 1, i + 1, true); // h:2916
+    }
+    if (i == (long)num_codes - 1) {                     // h:2949: trailing node
+        int depth = src.next();                         // whole byte
+        process(depth, i + 1, i, false);                // reported as i+1 (h:2970)
+    }
+    for (int r = top_k - 1; r >= 0; r--) {              // h:2977-2982
+        const std::pair<float, uint>& top = max_heap.top();
+        out_ids[r] = (int)top.second;
+        out_dists[r] = top.first;
+        max_heap.pop();
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+// h:2841-2849
+void oracle_build_lut(const float* codebook, const float* query, int M, int K, int Ds, float* lut) {
+    build_lut(codebook, query, M, K, Ds, lut);
+}
+
+// h:3731-3892: query_processing_scan_compressed_codes_opt_in_memory.
+// payload = the n_bytes that follow the 16-byte file header.
+int oracle_query_in_memory(const uchar* payload, long long n_bytes, const float* query, int top_k,
+                           int M, int K, int Ds, long long num_codes, const float* codebook,
+                           int* out_ids, float* out_dists) {
+    (void)n_bytes;
+    if (num_codes < top_k || top_k < 1) return -1;  // reference would pop an empty heap (h:2977-2981)
+    std::vector<float> lut((size_t)M * K);
+    build_lut(codebook, query, M, K, Ds, lut.data());
+    MemSource src{payload, 0};
+    scan(src, lut.data(), top_k, M, K, num_codes, out_ids, out_dists, nullptr, nullptr);
+    return 0;
+}
+
+// Same scan with a precomputed LUT (lets tests separate a3 from a5/a6) and the
+// optional per-node outputs.
+int oracle_scan_lut(const uchar* payload, long long n_bytes, const float* lut, int top_k, int M,
+                    int K, long long num_codes, int* out_ids, float* out_dists, float* all_dists,
+                    uchar* all_codes) {
+    (void)n_bytes;
+    if (num_codes < top_k || top_k < 1) return -1;
+    MemSource src{payload, 0};
+    scan(src, lut, top_k, M, K, num_codes, out_ids, out_dists, all_dists, all_codes);
+    return 0;
+}
+
+// h:2805-2984: query_processing_scan_compressed_codes_opt_o_direct, reading the
+// file `path` in 4 KB blocks.  O_DIRECT is requested as the reference does and
+// dropped if the filesystem refuses it (tmpfs); the byte arithmetic is the same.
+int oracle_query_o_direct(const char* path, const float* query, int top_k, int M, int K, int Ds,
+                          long long num_codes, const float* codebook, int* out_ids,
+                          float* out_dists) {
+    uchar* buffer = (uchar*)aligned_alloc(4096, 4096);
+    int fd = open(path, O_DIRECT | O_RDONLY);
+    if (fd < 0) fd = open(path, O_RDONLY);
+    if (fd < 0) { free(buffer); return -2; }
+    memset(buffer, 0, 4096);
+    ssize_t r = read(fd, buffer, 4096);                  // h:2822
+    (void)r;
+    long long n_codes = ((long long*)buffer)[0];         // h:2823
+    long long n_bytes = ((long long*)buffer)[1];         // h:2824
+    if (num_codes == -1) num_codes = n_codes;            // h:2825
+    int rc = 0;
+    if (num_codes < top_k || top_k < 1) rc = -1;
+    if (rc == 0) {
+        std::vector<float> lut((size_t)M * K);
+        build_lut(codebook, query, M, K, Ds, lut.data());
+        FdSource src{buffer, fd, 16, n_bytes + 16};      // h:2855-2856
+        scan(src, lut.data(), top_k, M, K, num_codes, out_ids, out_dists, nullptr, nullptr);
+    }
+    close(fd);
+    free(buffer);
+    return rc;
+}
+
+// Plain PQ scan comparator, h:2590-2678 (`-task pqscan`): full ADC over raw
+// N x M codes with **fp32** accumulation (h:2658-2662), same heap rule.
+int oracle_pqscan_plain(const uchar* codes, long long num_codes, const float* lut, int top_k, int M,
+                        int K, int* out_ids, float* out_dists) {
+    if (num_codes < top_k || top_k < 1) return -1;
+    MaxHeap max_heap;
+    for (long long i = 0; i < num_codes; i++) {
+        float dist = 0;
+        for (int m = 0; m < M; m++) dist += lut[(size_t)m * K + codes[i * M + m]];
+        if ((int)max_heap.size() < top_k) {
+            max_heap.emplace(dist, (uint)i);
+        } else if (dist < max_heap.top().first) {
+            max_heap.pop();
+            max_heap.emplace(dist, (uint)i);
+        }
+    }
+    for (int r = top_k - 1; r >= 0; r--) {
+        out_ids[r] = (int)max_heap.top().second;
+        out_dists[r] = max_heap.top().first;
+        max_heap.pop();
+    }
+    return 0;
+}
+
+// pq.cpp:288-312  PQ::ReadCodewords: text "M,Ks,Ds\n" then per m "m:\n" and
+// Ks lines of "v,v,...,\n", parsed with `ifs >> float >> char`.
+// Call once with out == NULL to get the shape, then with a buffer.
+int oracle_read_codewords(const char* path, int* M, int* Ks, int* Ds, float* out) {
+    std::ifstream ifs(path);
+    if (!ifs.is_open()) return -2;
+    char c1, c2;
+    int v;
+    ifs >> *M >> c1 >> *Ks >> c2 >> *Ds;
+    if (!ifs || *M <= 0 || *Ks <= 0 || *Ds <= 0) return -3;
+    if (!out) return 0;
+    for (int m = 0; m < *M; ++m) {
+        ifs >> v >> c1;
+        if (v != m) return -3;
+        for (int ks = 0; ks < *Ks; ++ks)
+            for (int ds = 0; ds < *Ds; ++ds)
+                ifs >> out[((size_t)m * *Ks + ks) * *Ds + ds] >> c1;
+    }
+    return ifs ? 0 : -3;
+}
+
+// utils.cpp:14-32 / 46-71 / 96-110: .fvecs / .bvecs readers behind ReadTopN.
+// Returns the number of vectors; fills out (n x D floats) when non-NULL.
+long long oracle_read_vecs(const char* path, int is_bvecs, int* D_out, float* out, long long cap) {
+    FILE* f = fopen(path, "rb");
+    if (!f) return -2;
+    long long n = 0;
+    int D;
+    std::vector<uchar> buff;
+    while (fread(&D, sizeof(int), 1, f) == 1) {
+        if (D <= 0) { fclose(f); return -3; }
+        *D_out = D;
+        if (is_bvecs) {
+            buff.resize(D);
+            if (fread(buff.data(), 1, D, f) != (size_t)D) break;
+            if (out && n < cap)
+                for (int d = 0; d < D; d++) out[n * D + d] = (float)buff[d];
+        } else {
+            if (out && n < cap) {
+                if (fread(out + n * D, sizeof(float), D, f) != (size_t)D) break;
+            } else {
+                if (fseek(f, (long)sizeof(float) * D, SEEK_CUR) != 0) break;
+            }
+        }
+        n++;
+    }
+    fclose(f);
+    return n;
+}
+
+}  // extern "C"
