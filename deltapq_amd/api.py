@@ -1,0 +1,251 @@
+"""Python face of the C-ABI (include/deltapq_amd.h) for tests, bench.py and the
+multi-GPU driver.  Everything here is plumbing: numpy/torch buffers in, the HIP
+library does the work.  Names of the two convenience functions at the bottom
+mirror the reference's entry points (deltapq_create_approx_tree.h:2805, 3731).
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from ._lib import DpqError, Info, OpenOpts, Profile, check  # noqa: F401
+
+
+def _np_ptr(a):
+    return ctypes.c_void_p(a.ctypes.data)
+
+
+def device_count():
+    return _lib.load().dpq_device_count()
+
+
+def read_codewords(path):
+    """PQ::ReadCodewords (pq.cpp:288-312) -> float32 [M][K][Ds]."""
+    lib = _lib.load()
+    M, K, Ds = _lib.c_i32(), _lib.c_i32(), _lib.c_i32()
+    check(lib.dpq_read_codewords(path.encode(), M, K, Ds, None), "dpq_read_codewords")
+    out = np.empty((M.value, K.value, Ds.value), dtype=np.float32)
+    check(lib.dpq_read_codewords(path.encode(), M, K, Ds, _np_ptr(out)), "dpq_read_codewords")
+    return out
+
+
+def read_vecs(path, ext="fvecs", top_n=-1):
+    """ReadTopN (utils.cpp:96-110) over .fvecs/.bvecs -> float32 [n][D]."""
+    lib = _lib.load()
+    n, D = _lib.c_i64(), _lib.c_i32()
+    check(lib.dpq_read_vecs(path.encode(), int(ext == "bvecs"), n, D, None, 0), "dpq_read_vecs")
+    keep = n.value if top_n < 0 else min(n.value, top_n)
+    out = np.empty((keep, D.value), dtype=np.float32)
+    check(lib.dpq_read_vecs(path.encode(), int(ext == "bvecs"), n, D, _np_ptr(out), keep), "dpq_read_vecs")
+    return out
+
+
+def read_dtc_file(path):
+    """(n_codes, payload u8[n_bytes]) of a reference DTC index file (h:1839-1842)."""
+    lib = _lib.load()
+    n_codes, n_bytes = _lib.c_i64(), _lib.c_i64()
+    check(lib.dpq_read_dtc_header(path.encode(), n_codes, n_bytes), "dpq_read_dtc_header")
+    payload = np.fromfile(path, dtype=np.uint8, offset=16, count=n_bytes.value)
+    return n_codes.value, payload
+
+
+def dtc_validate(payload, n_codes, M=8):
+    lib = _lib.load()
+    pl = np.ascontiguousarray(payload, dtype=np.uint8)
+    st = _lib.DtcStats()
+    check(lib.dpq_dtc_validate(_np_ptr(pl), pl.size, n_codes, M, st), "dpq_dtc_validate")
+    return dict(n_codes=st.n_codes, n_bytes=st.n_bytes, n_diffs=st.n_diffs, max_depth=st.max_depth,
+                depth_hist=list(st.depth_hist))
+
+
+def dtc_encode(root, depths, masks, deltas, M=8):
+    """qnodes_to_compressed_codes_opt (h:1765-1826) through the C-ABI."""
+    lib = _lib.load()
+    root = np.ascontiguousarray(root, dtype=np.uint8)
+    depths = np.ascontiguousarray(depths, dtype=np.uint8)
+    masks = np.ascontiguousarray(masks, dtype=np.uint16)
+    deltas = np.ascontiguousarray(deltas, dtype=np.uint8)
+    nb = _lib.c_i64()
+    check(lib.dpq_dtc_encode(_np_ptr(root), _np_ptr(depths), _np_ptr(masks), _np_ptr(deltas), len(depths), M, None,
+                             nb), "dpq_dtc_encode")
+    out = np.empty(nb.value, dtype=np.uint8)
+    check(lib.dpq_dtc_encode(_np_ptr(root), _np_ptr(depths), _np_ptr(masks), _np_ptr(deltas), len(depths), M,
+                             _np_ptr(out), nb), "dpq_dtc_encode")
+    return out
+
+
+class HostSoA:
+    """The transcoded structure-of-arrays image, built on the host (no GPU)."""
+
+    def __init__(self, payload, n_codes, M=8, shard_rank=0, shard_count=1, chunks_per_segment=0):
+        lib = _lib.load()
+        pl = np.ascontiguousarray(payload, dtype=np.uint8)
+        opts = OpenOpts(0, shard_rank, shard_count, chunks_per_segment, 0)
+        h = ctypes.c_void_p()
+        check(lib.dpq_soa_build(_np_ptr(pl), pl.size, n_codes, M, opts, h), "dpq_soa_build")
+        self._h = h
+        info = Info()
+        check(lib.dpq_soa_info(h, info), "dpq_soa_info")
+        self.info = info.as_dict()
+        names = ["nib", "mask", "delta", "seg_delta_off", "seg_ckpt"]
+        for which, name in enumerate(names):
+            ptr, nb = ctypes.c_void_p(), _lib.c_i64()
+            check(lib.dpq_soa_array(h, which, ptr, nb), "dpq_soa_array")
+            buf = (ctypes.c_ubyte * nb.value).from_address(ptr.value) if nb.value else b""
+            arr = np.frombuffer(buf, dtype=np.uint8).copy()
+            if name == "seg_delta_off":
+                arr = arr.view(np.uint64)
+            setattr(self, name, arr)
+        lib.dpq_soa_free(h)
+        self._h = None
+
+
+class DeltaPQIndex:
+    """One DTC index (or one shard) resident on one MI355X."""
+
+    def __init__(self, handle):
+        self._h = handle
+        self._lib = _lib.load()
+
+    @classmethod
+    def open_file(cls, path, M=8, K=256, device=0, shard_rank=0, shard_count=1, chunks_per_segment=0,
+                  cand_capacity=0):
+        lib = _lib.load()
+        opts = OpenOpts(device, shard_rank, shard_count, chunks_per_segment, cand_capacity)
+        h = ctypes.c_void_p()
+        check(lib.dpq_open_file(path.encode(), M, K, opts, h), "dpq_open_file")
+        return cls(h)
+
+    @classmethod
+    def open_memory(cls, payload, n_codes, M=8, K=256, device=0, shard_rank=0, shard_count=1, chunks_per_segment=0,
+                    cand_capacity=0):
+        lib = _lib.load()
+        pl = np.ascontiguousarray(payload, dtype=np.uint8)
+        opts = OpenOpts(device, shard_rank, shard_count, chunks_per_segment, cand_capacity)
+        h = ctypes.c_void_p()
+        check(lib.dpq_open_memory(_np_ptr(pl), pl.size, n_codes, M, K, opts, h), "dpq_open_memory")
+        return cls(h)
+
+    def set_codebook(self, codebook):
+        cb = np.ascontiguousarray(codebook, dtype=np.float32)
+        assert cb.ndim == 3
+        check(self._lib.dpq_set_codebook(self._h, _np_ptr(cb), cb.shape[2]), "dpq_set_codebook")
+        return self
+
+    def info(self):
+        i = Info()
+        check(self._lib.dpq_get_info(self._h, i), "dpq_get_info")
+        return i.as_dict()
+
+    def query_batch(self, queries, top_k):
+        """Host buffers in/out.  Returns (ids int32 [nq][k], dists float32 [nq][k])."""
+        q = np.ascontiguousarray(queries, dtype=np.float32)
+        if q.ndim == 1:
+            q = q[None, :]
+        nq = q.shape[0]
+        ids = np.empty((nq, top_k), dtype=np.int32)
+        dists = np.empty((nq, top_k), dtype=np.float32)
+        check(self._lib.dpq_query_batch(self._h, _np_ptr(q), nq, top_k, _np_ptr(ids), _np_ptr(dists)),
+              "dpq_query_batch")
+        return ids, dists
+
+    def query_batch_torch(self, queries, top_k, out_ids=None, out_dists=None):
+        """Device tensors in/out on torch's current stream (no host copies)."""
+        import torch
+        assert queries.is_cuda and queries.dtype == torch.float32 and queries.is_contiguous()
+        nq = queries.shape[0]
+        if out_ids is None:
+            out_ids = torch.empty((nq, top_k), dtype=torch.int32, device=queries.device)
+        if out_dists is None:
+            out_dists = torch.empty((nq, top_k), dtype=torch.float32, device=queries.device)
+        stream = torch.cuda.current_stream(queries.device).cuda_stream
+        check(self._lib.dpq_query_batch_device(self._h, ctypes.c_void_p(queries.data_ptr()), nq, top_k,
+                                               ctypes.c_void_p(out_ids.data_ptr()),
+                                               ctypes.c_void_p(out_dists.data_ptr()), ctypes.c_void_p(stream)),
+              "dpq_query_batch_device")
+        return out_ids, out_dists
+
+    def profile_enable(self, on=True):
+        check(self._lib.dpq_profile_enable(self._h, int(on)), "dpq_profile_enable")
+
+    def profile_reset(self):
+        check(self._lib.dpq_profile_reset(self._h), "dpq_profile_reset")
+
+    def profile_read(self):
+        p = Profile()
+        check(self._lib.dpq_profile_read(self._h, p), "dpq_profile_read")
+        return p.as_dict()
+
+    def close(self):
+        if self._h is not None:
+            self._lib.dpq_close(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+
+def merge_topk_host(ids, dists):
+    """ids/dists [n_lists][nq][k] -> merged [nq][k] by (distance, id)."""
+    lib = _lib.load()
+    ids = np.ascontiguousarray(ids, dtype=np.int32)
+    dists = np.ascontiguousarray(dists, dtype=np.float32)
+    n_lists, nq, k = ids.shape
+    oi = np.empty((nq, k), dtype=np.int32)
+    od = np.empty((nq, k), dtype=np.float32)
+    check(lib.dpq_merge_topk_host(_np_ptr(ids), _np_ptr(dists), n_lists, nq, k, _np_ptr(oi), _np_ptr(od)),
+          "dpq_merge_topk_host")
+    return oi, od
+
+
+def merge_topk_torch(ids, dists):
+    """Device merge after an all-gather: ids/dists [n_lists][nq][k] cuda tensors."""
+    import torch
+    lib = _lib.load()
+    assert ids.is_cuda and ids.is_contiguous() and dists.is_contiguous()
+    n_lists, nq, k = ids.shape
+    oi = torch.empty((nq, k), dtype=torch.int32, device=ids.device)
+    od = torch.empty((nq, k), dtype=torch.float32, device=ids.device)
+    stream = torch.cuda.current_stream(ids.device).cuda_stream
+    check(lib.dpq_merge_topk_device(ctypes.c_void_p(ids.data_ptr()), ctypes.c_void_p(dists.data_ptr()), n_lists, nq,
+                                    k, ctypes.c_void_p(oi.data_ptr()), ctypes.c_void_p(od.data_ptr()),
+                                    ids.device.index or 0, ctypes.c_void_p(stream)), "dpq_merge_topk_device")
+    return oi, od
+
+
+# ---------------------------------------------------------------------------
+# Reference-named conveniences (one call per query, like main:328-339).
+# ---------------------------------------------------------------------------
+
+def query_processing_scan_compressed_codes_opt_in_memory(codes, n_bytes, query, top_k, M, K, m_Ds, num_codes,
+                                                         m_codewords, device=0):
+    """Signature of deltapq_create_approx_tree.h:3731-3736 (decoder argument dropped).
+    Returns results as a list of (id, dist) ascending, like `results` there."""
+    payload = np.asarray(codes, dtype=np.uint8)[:n_bytes]
+    cb = np.asarray(m_codewords, dtype=np.float32).reshape(M, K, m_Ds)
+    with DeltaPQIndex.open_memory(payload, num_codes, M, K, device=device) as idx:
+        idx.set_codebook(cb)
+        ids, dists = idx.query_batch(np.asarray(query, dtype=np.float32)[None, :], top_k)
+    return list(zip(ids[0].tolist(), dists[0].tolist()))
+
+
+def query_processing_scan_compressed_codes_opt_o_direct(dataset_path, query, top_k, M, K, m_Ds, num_codes,
+                                                        m_codewords, device=0):
+    """Signature of deltapq_create_approx_tree.h:2805-2810 (decoder argument dropped)."""
+    lib = _lib.load()
+    buf = ctypes.create_string_buffer(4096)
+    check(lib.dpq_dtc_file_name(dataset_path.encode(), M, K, num_codes, buf, 4096), "dpq_dtc_file_name")
+    cb = np.asarray(m_codewords, dtype=np.float32).reshape(M, K, m_Ds)
+    with DeltaPQIndex.open_file(buf.value.decode(), M, K, device=device) as idx:
+        idx.set_codebook(cb)
+        ids, dists = idx.query_batch(np.asarray(query, dtype=np.float32)[None, :], top_k)
+    return list(zip(ids[0].tolist(), dists[0].tolist()))

@@ -1,0 +1,820 @@
+// dpq_capi.cpp -- the C-ABI of include/deltapq_amd.h: index lifetime, the
+// threshold-cascade driver around the scan/select kernels, profiling.
+// Compiled with hipcc (HIP runtime calls only; kernels live in dpq_kernels.hip).
+//
+// There is no CPU implementation of the query in this library: every
+// dpq_query_* call runs the HIP kernels or fails with an error code.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <type_traits>
+#include <vector>
+
+#include "../../include/deltapq_amd.h"
+#include "dpq_format.h"
+#include "dpq_kernels.h"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const std::string& msg) {
+    g_last_error = msg;
+    return code;
+}
+
+#define DPQ_HIP(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t _e = (expr);                                                                    \
+        if (_e != hipSuccess) {                                                                    \
+            return fail(DPQ_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));           \
+        }                                                                                          \
+    } while (0)
+
+template <class T>
+int dev_alloc(T** p, size_t count) {
+    *p = nullptr;
+    if (count == 0) count = 1;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(p), count * sizeof(T));
+    if (e != hipSuccess) return fail(DPQ_ERR_NOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
+    return DPQ_OK;
+}
+
+struct EventPair {
+    int kind;  // 0 lut, 1 scan, 2 select
+    hipEvent_t a, b;
+};
+
+constexpr int kMaxBatchQueries = 2048;
+
+}  // namespace
+
+struct dpq_soa {
+    dpq::SoA soa;
+};
+
+struct dpq_index {
+    int device = 0;
+    int M = 8, K = 256, Ds = 0;
+    int cap = 0;
+    bool cap_auto = true;
+    dpq_info info{};
+    dpq::DeviceImage img;
+    // owned device memory of the image
+    uint8_t *d_nib = nullptr, *d_mask = nullptr, *d_delta = nullptr, *d_ckpt = nullptr;
+    uint64_t* d_seg_off = nullptr;
+    float* d_codebook = nullptr;
+    // workspace, sized for ws_slots padded queries and ws_cap candidates each
+    int ws_slots = 0, ws_cap = 0;
+    float* d_lut = nullptr;
+    uint32_t *d_cand_count = nullptr, *d_cand_id = nullptr, *d_cand_code = nullptr, *d_overflow = nullptr;
+    uint64_t *d_keys = nullptr, *d_thr_key = nullptr;
+    float *d_thr_hi = nullptr, *d_thr_lo = nullptr;
+    uint32_t* h_overflow = nullptr;  // pinned
+    // staging for the host-pointer entry point
+    float* d_q_stage = nullptr;
+    int32_t* d_ids_stage = nullptr;
+    float* d_dists_stage = nullptr;
+    size_t q_stage_floats = 0, out_stage_elems = 0;
+    // cascade plan cache
+    int plan_top_k = -1, plan_cap = -1;
+    std::vector<int> level_off, level_cnt;
+    uint32_t* d_seg_lists = nullptr;
+    size_t seg_lists_cap = 0;
+    // profiling
+    bool prof = false;
+    std::vector<EventPair> events;
+    dpq_profile prof_acc{};
+};
+
+namespace {
+
+void free_workspace(dpq_index* x) {
+    hipFree(x->d_lut);
+    hipFree(x->d_cand_count);
+    hipFree(x->d_cand_id);
+    hipFree(x->d_cand_code);
+    hipFree(x->d_overflow);
+    hipFree(x->d_keys);
+    hipFree(x->d_thr_key);
+    hipFree(x->d_thr_hi);
+    hipFree(x->d_thr_lo);
+    x->d_lut = nullptr;
+    x->d_cand_count = x->d_cand_id = x->d_cand_code = x->d_overflow = nullptr;
+    x->d_keys = x->d_thr_key = nullptr;
+    x->d_thr_hi = x->d_thr_lo = nullptr;
+    x->ws_slots = x->ws_cap = 0;
+}
+
+int ensure_workspace(dpq_index* x, int slots, int cap) {
+    if (slots <= x->ws_slots && cap <= x->ws_cap) return DPQ_OK;
+    slots = std::max(slots, x->ws_slots);
+    cap = std::max(cap, x->ws_cap);
+    free_workspace(x);
+    const size_t W = (size_t)x->M / 4;
+    int rc;
+    if ((rc = dev_alloc(&x->d_lut, (size_t)slots * x->M * 256))) return rc;
+    if ((rc = dev_alloc(&x->d_cand_count, (size_t)slots))) return rc;
+    if ((rc = dev_alloc(&x->d_cand_id, (size_t)slots * cap))) return rc;
+    if ((rc = dev_alloc(&x->d_cand_code, (size_t)slots * cap * W))) return rc;
+    if ((rc = dev_alloc(&x->d_overflow, (size_t)slots))) return rc;
+    if ((rc = dev_alloc(&x->d_keys, (size_t)slots * cap))) return rc;
+    if ((rc = dev_alloc(&x->d_thr_key, (size_t)slots))) return rc;
+    if ((rc = dev_alloc(&x->d_thr_hi, (size_t)slots))) return rc;
+    if ((rc = dev_alloc(&x->d_thr_lo, (size_t)slots))) return rc;
+    if (!x->h_overflow) DPQ_HIP(hipHostMalloc(reinterpret_cast<void**>(&x->h_overflow), sizeof(uint32_t) * 4096));
+    x->ws_slots = slots;
+    x->ws_cap = cap;
+    return DPQ_OK;
+}
+
+int auto_cap(int top_k) { return std::max(4096, 32 * top_k); }
+
+// Cascade plan: sample sizes (in segments) nseg, nseg/rho, ... down to the
+// level-0 sample that fits the candidate buffer; expected survivors per level
+// = top_k * rho = cap / 3.
+int ensure_plan(dpq_index* x, int top_k, int cap) {
+    if (x->plan_top_k == top_k && x->plan_cap == cap) return DPQ_OK;
+    const int64_t S = (int64_t)dpq::kChunk * x->img.chunks_per_segment;
+    const int64_t nseg = x->img.n_segments;
+    std::vector<int64_t> sizes;
+    const int64_t s0 = std::max<int64_t>(1, cap / S);
+    if (s0 >= nseg) {
+        sizes.push_back(nseg);
+    } else {
+        const double rho = std::max(2.0, (double)cap / (3.0 * top_k));
+        int64_t cur = nseg;
+        sizes.push_back(cur);
+        while (true) {
+            const int64_t nxt = (int64_t)std::floor((double)cur / rho);
+            if (nxt <= s0) break;
+            sizes.push_back(nxt);
+            cur = nxt;
+        }
+        sizes.push_back(s0);
+        std::reverse(sizes.begin(), sizes.end());
+    }
+    std::vector<uint32_t> lists;
+    x->level_off.clear();
+    x->level_cnt.clear();
+    for (size_t l = 0; l < sizes.size(); ++l) {
+        const int64_t n = sizes[l];
+        if (n == nseg) {  // the full level needs no list
+            x->level_off.push_back(-1);
+            x->level_cnt.push_back((int)nseg);
+            continue;
+        }
+        x->level_off.push_back((int)lists.size());
+        x->level_cnt.push_back((int)n);
+        for (int64_t j = 0; j < n; ++j) lists.push_back((uint32_t)((j * nseg) / n));
+    }
+    if (lists.size() > x->seg_lists_cap) {
+        hipFree(x->d_seg_lists);
+        x->d_seg_lists = nullptr;
+        int rc = dev_alloc(&x->d_seg_lists, lists.size());
+        if (rc) return rc;
+        x->seg_lists_cap = lists.size();
+    }
+    if (!lists.empty())
+        DPQ_HIP(hipMemcpy(x->d_seg_lists, lists.data(), lists.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    x->plan_top_k = top_k;
+    x->plan_cap = cap;
+    return DPQ_OK;
+}
+
+struct Timer {
+    dpq_index* x;
+    hipStream_t s;
+    int kind;
+    bool on;
+    EventPair ep{};
+    Timer(dpq_index* x_, hipStream_t s_, int kind_) : x(x_), s(s_), kind(kind_), on(x_->prof) {
+        if (on) {
+            ep.kind = kind;
+            hipEventCreate(&ep.a);
+            hipEventCreate(&ep.b);
+            hipEventRecord(ep.a, s);
+        }
+    }
+    ~Timer() {
+        if (on) {
+            hipEventRecord(ep.b, s);
+            x->events.push_back(ep);
+        }
+    }
+};
+
+int splits_for(int n_seg_pass, int n_groups) {
+    // enough workgroups to fill 256 CUs about twice, but no more waves than segments
+    int by_work = (n_seg_pass + dpq::kScanWaves - 1) / dpq::kScanWaves;
+    int want = std::max(1, (512 + n_groups - 1) / n_groups);
+    return std::max(1, std::min(by_work, want));
+}
+
+// One sub-batch (nq <= kMaxBatchQueries) end to end on `stream`.
+int run_batch(dpq_index* x, const float* d_queries, int nq, int top_k, int32_t* d_ids, float* d_dists,
+              hipStream_t stream) {
+    const int QG = dpq::queries_per_group(x->M);
+    const int nqp = (nq + QG - 1) / QG * QG;
+    const int ngroups = nqp / QG;
+    const int cap = x->cap_auto ? auto_cap(top_k) : std::max(x->cap, top_k);
+    int rc;
+    if ((rc = ensure_workspace(x, nqp, cap))) return rc;
+    if ((rc = ensure_plan(x, top_k, cap))) return rc;
+
+    {
+        Timer t(x, stream, 0);
+        DPQ_HIP(dpq::launch_lut_build(x->d_codebook, d_queries, nq, nqp, x->M, x->K, x->Ds, x->d_lut, stream));
+    }
+    if (x->prof) x->prof_acc.lut_launches++;
+    DPQ_HIP(dpq::launch_init_thresholds(x->d_thr_key, x->d_thr_hi, x->d_thr_lo, nqp, nq, stream));
+
+    dpq::ScanArgs sa{};
+    sa.img = x->img;
+    sa.lut = x->d_lut;
+    sa.group_list = nullptr;
+    sa.thr_hi = x->d_thr_hi;
+    sa.thr_lo = x->d_thr_lo;
+    sa.thr_key = x->d_thr_key;
+    sa.cand_count = x->d_cand_count;
+    sa.cand_id = x->d_cand_id;
+    sa.cand_code = x->d_cand_code;
+    sa.cap = cap;
+
+    dpq::SelectArgs se{};
+    se.cand_count = x->d_cand_count;
+    se.cand_id = x->d_cand_id;
+    se.cand_code = x->d_cand_code;
+    se.cap = cap;
+    se.lut = x->d_lut;
+    se.slot_query = nullptr;
+    se.keys = x->d_keys;
+    se.M = x->M;
+    se.top_k = top_k;
+    se.thr_key = x->d_thr_key;
+    se.thr_hi = x->d_thr_hi;
+    se.thr_lo = x->d_thr_lo;
+    se.overflow = x->d_overflow;
+    se.out_ids = d_ids;
+    se.out_dists = d_dists;
+    se.n_codes_total = x->img.n_codes_total;
+    se.n_local = x->img.n_local;
+
+    const int64_t S = (int64_t)dpq::kChunk * x->img.chunks_per_segment;
+    const size_t n_levels = x->img.n_segments > 0 ? x->level_cnt.size() : 0;
+    if (n_levels == 0) {  // empty shard: every row is padding
+        DPQ_HIP(hipMemsetAsync(x->d_cand_count, 0, sizeof(uint32_t) * nqp, stream));
+        se.final_pass = 1;
+        DPQ_HIP(dpq::launch_select(se, nq, stream));
+        return DPQ_OK;
+    }
+    for (size_t l = 0; l < n_levels; ++l) {
+        const bool final_pass = l + 1 == n_levels;
+        DPQ_HIP(hipMemsetAsync(x->d_cand_count, 0, sizeof(uint32_t) * nqp, stream));
+        sa.seg_list = x->level_off[l] < 0 ? nullptr : x->d_seg_lists + x->level_off[l];
+        sa.n_seg_pass = x->level_cnt[l];
+        {
+            Timer t(x, stream, 1);
+            DPQ_HIP(dpq::launch_scan(sa, ngroups, splits_for(sa.n_seg_pass, ngroups), stream));
+        }
+        if (x->prof) {
+            x->prof_acc.scan_launches++;
+            x->prof_acc.scan_node_query_pairs += (int64_t)sa.n_seg_pass * S * nq;
+            x->prof_acc.scan_stream_bytes +=
+                (int64_t)((double)x->info.device_bytes * sa.n_seg_pass / std::max(1, x->img.n_segments));
+        }
+        se.final_pass = final_pass ? 1 : 0;
+        {
+            Timer t(x, stream, 2);
+            DPQ_HIP(dpq::launch_select(se, nq, stream));
+        }
+        if (x->prof) x->prof_acc.select_launches++;
+    }
+
+    // The only host synchronisation of the batch: did any query overflow its
+    // candidate buffer in the final level?  (Then its list may miss candidates.)
+    std::vector<int> over;
+    uint32_t max_cnt = 0;
+    for (int base = 0; base < nq; base += 4096) {
+        const int n = std::min(4096, nq - base);
+        DPQ_HIP(hipMemcpyAsync(x->h_overflow, x->d_overflow + base, sizeof(uint32_t) * n, hipMemcpyDeviceToHost,
+                               stream));
+        DPQ_HIP(hipStreamSynchronize(stream));
+        for (int i = 0; i < n; ++i)
+            if (x->h_overflow[i]) {
+                over.push_back(base + i);
+                max_cnt = std::max(max_cnt, x->h_overflow[i]);
+            }
+    }
+    if (over.empty()) return DPQ_OK;
+
+    // Rerun the final level for the affected LUT groups with buffers sized from
+    // the now-known candidate counts (the thresholds are unchanged, so the count
+    // is exact and one rerun always suffices).
+    std::vector<int> groups;
+    for (int q : over) {
+        int g = q / QG;
+        if (groups.empty() || groups.back() != g) groups.push_back(g);
+    }
+    const int ng2 = (int)groups.size();
+    const int slots2 = ng2 * QG;
+    const int cap2 = (int)std::min<uint64_t>((uint64_t)max_cnt + 64, (uint64_t)INT32_MAX / 2);
+    std::vector<int32_t> slot_query((size_t)slots2, -1);
+    std::vector<uint64_t> h_key((size_t)nqp), k2((size_t)slots2, 0);
+    std::vector<float> h_hi((size_t)nqp), h_lo((size_t)nqp), hi2((size_t)slots2, -1.0f), lo2((size_t)slots2, -1.0f);
+    DPQ_HIP(hipMemcpy(h_key.data(), x->d_thr_key, sizeof(uint64_t) * nqp, hipMemcpyDeviceToHost));
+    DPQ_HIP(hipMemcpy(h_hi.data(), x->d_thr_hi, sizeof(float) * nqp, hipMemcpyDeviceToHost));
+    DPQ_HIP(hipMemcpy(h_lo.data(), x->d_thr_lo, sizeof(float) * nqp, hipMemcpyDeviceToHost));
+    for (int g = 0; g < ng2; ++g)
+        for (int i = 0; i < QG; ++i) {
+            const int q = groups[g] * QG + i;
+            const size_t s = (size_t)g * QG + i;
+            if (q < nq && std::binary_search(over.begin(), over.end(), q)) {
+                slot_query[s] = q;
+                k2[s] = h_key[q];
+                hi2[s] = h_hi[q];
+                lo2[s] = h_lo[q];
+            }
+        }
+    const size_t W = (size_t)x->M / 4;
+    int32_t *d_groups = nullptr, *d_slot_query = nullptr;
+    uint32_t *c_count = nullptr, *c_id = nullptr, *c_code = nullptr, *c_over = nullptr;
+    uint64_t *c_keys = nullptr, *c_tk = nullptr;
+    float *c_hi = nullptr, *c_lo = nullptr;
+    auto cleanup = [&]() {
+        hipFree(d_groups); hipFree(d_slot_query); hipFree(c_count); hipFree(c_id); hipFree(c_code);
+        hipFree(c_over); hipFree(c_keys); hipFree(c_tk); hipFree(c_hi); hipFree(c_lo);
+    };
+    rc = dev_alloc(&d_groups, (size_t)ng2);
+    if (!rc) rc = dev_alloc(&d_slot_query, (size_t)slots2);
+    if (!rc) rc = dev_alloc(&c_count, (size_t)slots2);
+    if (!rc) rc = dev_alloc(&c_id, (size_t)slots2 * cap2);
+    if (!rc) rc = dev_alloc(&c_code, (size_t)slots2 * cap2 * W);
+    if (!rc) rc = dev_alloc(&c_over, (size_t)slots2);
+    if (!rc) rc = dev_alloc(&c_keys, (size_t)slots2 * cap2);
+    if (!rc) rc = dev_alloc(&c_tk, (size_t)slots2);
+    if (!rc) rc = dev_alloc(&c_hi, (size_t)slots2);
+    if (!rc) rc = dev_alloc(&c_lo, (size_t)slots2);
+    if (rc) {
+        cleanup();
+        return rc;
+    }
+    hipError_t e = hipSuccess;
+    auto chk = [&](hipError_t r) { if (e == hipSuccess) e = r; };
+    chk(hipMemcpy(d_groups, groups.data(), sizeof(int32_t) * ng2, hipMemcpyHostToDevice));
+    chk(hipMemcpy(d_slot_query, slot_query.data(), sizeof(int32_t) * slots2, hipMemcpyHostToDevice));
+    chk(hipMemcpy(c_tk, k2.data(), sizeof(uint64_t) * slots2, hipMemcpyHostToDevice));
+    chk(hipMemcpy(c_hi, hi2.data(), sizeof(float) * slots2, hipMemcpyHostToDevice));
+    chk(hipMemcpy(c_lo, lo2.data(), sizeof(float) * slots2, hipMemcpyHostToDevice));
+    chk(hipMemsetAsync(c_count, 0, sizeof(uint32_t) * slots2, stream));
+    sa.seg_list = nullptr;
+    sa.n_seg_pass = x->img.n_segments;
+    sa.group_list = d_groups;
+    sa.thr_hi = c_hi;
+    sa.thr_lo = c_lo;
+    sa.thr_key = c_tk;
+    sa.cand_count = c_count;
+    sa.cand_id = c_id;
+    sa.cand_code = c_code;
+    sa.cap = cap2;
+    chk(dpq::launch_scan(sa, ng2, splits_for(sa.n_seg_pass, ng2), stream));
+    se.cand_count = c_count;
+    se.cand_id = c_id;
+    se.cand_code = c_code;
+    se.cap = cap2;
+    se.slot_query = d_slot_query;
+    se.keys = c_keys;
+    se.thr_key = c_tk;
+    se.thr_hi = c_hi;
+    se.thr_lo = c_lo;
+    se.overflow = c_over;
+    se.final_pass = 1;
+    chk(dpq::launch_select(se, slots2, stream));
+    chk(hipStreamSynchronize(stream));
+    cleanup();
+    if (x->prof) x->prof_acc.overflow_reruns += (int64_t)over.size();
+    if (e != hipSuccess) return fail(DPQ_ERR_HIP, std::string("overflow rerun: ") + hipGetErrorString(e));
+    return DPQ_OK;
+}
+
+int open_from_payload(const uint8_t* payload, int64_t n_bytes, int64_t n_codes, int M, int K,
+                      const dpq_open_opts* opts, dpq_index** out) {
+    if (!out) return fail(DPQ_ERR_ARG, "out is NULL");
+    *out = nullptr;
+    dpq_open_opts o{};
+    if (opts) o = *opts;
+    if (M != 8) return fail(DPQ_ERR_ARG, "this build has scan kernels for M = 8 only");
+    if (K < 1 || K > 256) return fail(DPQ_ERR_ARG, "K must be in 1..256 (one byte per sub-code)");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(DPQ_ERR_NO_DEVICE, "no HIP device visible; this library has no CPU fallback");
+    if (o.device < 0 || o.device >= ndev) return fail(DPQ_ERR_NO_DEVICE, "device ordinal out of range");
+
+    dpq::SoA soa;
+    std::string err;
+    int rc = dpq::transcode(payload, n_bytes, n_codes, M, o.shard_rank, o.shard_count, o.chunks_per_segment, &soa,
+                            &err);
+    if (rc) return fail(rc, err);
+
+    DPQ_HIP(hipSetDevice(o.device));
+    dpq_index* x = new dpq_index();
+    x->device = o.device;
+    x->M = M;
+    x->K = K;
+    x->cap_auto = o.cand_capacity <= 0;
+    x->cap = o.cand_capacity;
+    auto up = [&](auto** dptr, const void* src, size_t bytes) -> int {
+        using T = std::remove_pointer_t<std::remove_pointer_t<decltype(dptr)>>;
+        int r = dev_alloc(dptr, (bytes + sizeof(T) - 1) / sizeof(T) + 64 / sizeof(T));
+        if (r) return r;
+        if (bytes) {
+            hipError_t e = hipMemcpy(*dptr, src, bytes, hipMemcpyHostToDevice);
+            if (e != hipSuccess) return fail(DPQ_ERR_HIP, std::string("upload: ") + hipGetErrorString(e));
+        }
+        return DPQ_OK;
+    };
+    rc = up(&x->d_nib, soa.nib.data(), soa.nib.size());
+    if (!rc) rc = up(&x->d_mask, soa.mask.data(), soa.mask.size());
+    if (!rc) rc = up(&x->d_delta, soa.delta.data(), soa.delta.size());
+    if (!rc) rc = up(&x->d_seg_off, soa.seg_delta_off.data(), soa.seg_delta_off.size() * 8);
+    if (!rc) rc = up(&x->d_ckpt, soa.seg_ckpt.data(), soa.seg_ckpt.size());
+    if (rc) {
+        dpq_close(x);
+        return rc;
+    }
+    x->img.nib = x->d_nib;
+    x->img.mask = x->d_mask;
+    x->img.delta = x->d_delta;
+    x->img.seg_delta_off = x->d_seg_off;
+    x->img.seg_ckpt = x->d_ckpt;
+    x->img.n_local = soa.node_hi - soa.node_lo;
+    x->img.n_codes_total = soa.n_codes_total;
+    x->img.id_base = (uint32_t)soa.node_lo;
+    x->img.n_segments = (int32_t)soa.n_segments;
+    x->img.chunks_per_segment = soa.chunks_per_segment;
+    x->img.M = M;
+    x->img.K = K;
+
+    dpq_info& inf = x->info;
+    inf.n_codes_total = soa.n_codes_total;
+    inf.n_bytes_total = soa.n_bytes_total;
+    inf.node_lo = soa.node_lo;
+    inf.node_hi = soa.node_hi;
+    inf.algorithmic_bytes = soa.algorithmic_bytes;
+    inf.device_bytes = soa.device_bytes();
+    inf.n_diffs = soa.n_diffs;
+    inf.M = M;
+    inf.K = K;
+    inf.Ds = 0;
+    inf.n_segments = (int32_t)soa.n_segments;
+    inf.chunks_per_segment = soa.chunks_per_segment;
+    inf.max_depth = soa.max_depth;
+    inf.device = o.device;
+    inf.cand_capacity = x->cap;
+    *out = x;
+    return DPQ_OK;
+}
+
+void fill_info_from_soa(const dpq::SoA& s, dpq_info* inf) {
+    memset(inf, 0, sizeof *inf);
+    inf->n_codes_total = s.n_codes_total;
+    inf->n_bytes_total = s.n_bytes_total;
+    inf->node_lo = s.node_lo;
+    inf->node_hi = s.node_hi;
+    inf->algorithmic_bytes = s.algorithmic_bytes;
+    inf->device_bytes = s.device_bytes();
+    inf->n_diffs = s.n_diffs;
+    inf->M = s.M;
+    inf->n_segments = (int32_t)s.n_segments;
+    inf->chunks_per_segment = s.chunks_per_segment;
+    inf->max_depth = s.max_depth;
+    inf->device = -1;
+}
+
+}  // namespace
+
+extern "C" {
+
+int dpq_version(void) { return DPQ_VERSION; }
+
+const char* dpq_strerror(int status) {
+    switch (status) {
+        case DPQ_OK: return "ok";
+        case DPQ_ERR_ARG: return "bad argument";
+        case DPQ_ERR_IO: return "i/o error";
+        case DPQ_ERR_FORMAT: return "malformed DTC stream";
+        case DPQ_ERR_NO_DEVICE: return "no usable GPU";
+        case DPQ_ERR_HIP: return "HIP runtime error";
+        case DPQ_ERR_NOMEM: return "out of memory";
+        case DPQ_ERR_STATE: return "call out of order";
+        case DPQ_ERR_TOPK: return "top_k exceeds the number of codes";
+        default: return "unknown status";
+    }
+}
+
+const char* dpq_last_error(void) { return g_last_error.c_str(); }
+
+int dpq_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n < 0 ? 0 : n;
+}
+
+int dpq_read_dtc_header(const char* path, int64_t* n_codes, int64_t* n_bytes) {
+    if (!path || !n_codes || !n_bytes) return fail(DPQ_ERR_ARG, "NULL argument");
+    std::string err;
+    int rc = dpq::read_dtc_header(path, n_codes, n_bytes, &err);
+    return rc ? fail(rc, err) : DPQ_OK;
+}
+
+int dpq_read_codewords(const char* path, int32_t* M, int32_t* K, int32_t* Ds, float* out) {
+    if (!path || !M || !K || !Ds) return fail(DPQ_ERR_ARG, "NULL argument");
+    std::string err;
+    std::vector<float> v;
+    int m, k, ds;
+    int rc = dpq::read_codewords(path, &m, &k, &ds, out ? &v : nullptr, &err);
+    if (rc) return fail(rc, err);
+    *M = m;
+    *K = k;
+    *Ds = ds;
+    if (out) memcpy(out, v.data(), v.size() * sizeof(float));
+    return DPQ_OK;
+}
+
+int dpq_read_vecs(const char* path, int is_bvecs, int64_t* n, int32_t* D, float* out, int64_t cap) {
+    if (!path || !n || !D) return fail(DPQ_ERR_ARG, "NULL argument");
+    std::string err;
+    std::vector<float> v;
+    int d = 0;
+    int rc = dpq::read_vecs(path, is_bvecs != 0, n, &d, out ? &v : nullptr, cap, &err);
+    if (rc) return fail(rc, err);
+    *D = d;
+    if (out) memcpy(out, v.data(), v.size() * sizeof(float));
+    return DPQ_OK;
+}
+
+int dpq_dtc_file_name(const char* dataset_dir, int M, int K, int64_t N, char* out, int64_t out_len) {
+    if (!dataset_dir || !out) return fail(DPQ_ERR_ARG, "NULL argument");
+    std::string s = dpq::dtc_file_name(dataset_dir, M, K, N);
+    if ((int64_t)s.size() + 1 > out_len) return fail(DPQ_ERR_ARG, "output buffer too small");
+    memcpy(out, s.c_str(), s.size() + 1);
+    return DPQ_OK;
+}
+
+int dpq_dtc_validate(const uint8_t* payload, int64_t n_bytes, int64_t n_codes, int M, dpq_dtc_stats* stats) {
+    std::string err;
+    int rc = dpq::validate(payload, n_bytes, n_codes, M, stats, &err);
+    return rc ? fail(rc, err) : DPQ_OK;
+}
+
+int dpq_soa_build(const uint8_t* payload, int64_t n_bytes, int64_t n_codes, int M, const dpq_open_opts* opts,
+                  dpq_soa** out) {
+    if (!out) return fail(DPQ_ERR_ARG, "out is NULL");
+    dpq_open_opts o{};
+    if (opts) o = *opts;
+    dpq_soa* s = new dpq_soa();
+    std::string err;
+    int rc = dpq::transcode(payload, n_bytes, n_codes, M, o.shard_rank, o.shard_count, o.chunks_per_segment, &s->soa,
+                            &err);
+    if (rc) {
+        delete s;
+        *out = nullptr;
+        return fail(rc, err);
+    }
+    *out = s;
+    return DPQ_OK;
+}
+
+int dpq_soa_info(const dpq_soa* soa, dpq_info* info) {
+    if (!soa || !info) return fail(DPQ_ERR_ARG, "NULL argument");
+    fill_info_from_soa(soa->soa, info);
+    return DPQ_OK;
+}
+
+int dpq_soa_array(const dpq_soa* soa, int which, const void** ptr, int64_t* n_bytes) {
+    if (!soa || !ptr || !n_bytes) return fail(DPQ_ERR_ARG, "NULL argument");
+    const dpq::SoA& s = soa->soa;
+    switch (which) {
+        case 0: *ptr = s.nib.data(); *n_bytes = (int64_t)s.nib.size(); break;
+        case 1: *ptr = s.mask.data(); *n_bytes = (int64_t)s.mask.size(); break;
+        case 2: *ptr = s.delta.data(); *n_bytes = (int64_t)s.delta.size(); break;
+        case 3: *ptr = s.seg_delta_off.data(); *n_bytes = (int64_t)s.seg_delta_off.size() * 8; break;
+        case 4: *ptr = s.seg_ckpt.data(); *n_bytes = (int64_t)s.seg_ckpt.size(); break;
+        default: return fail(DPQ_ERR_ARG, "which must be 0..4");
+    }
+    return DPQ_OK;
+}
+
+void dpq_soa_free(dpq_soa* soa) { delete soa; }
+
+int dpq_dtc_encode(const uint8_t* root_code, const uint8_t* depths, const uint16_t* masks, const uint8_t* deltas,
+                   int64_t n_codes, int M, uint8_t* out, int64_t* n_bytes) {
+    std::string err;
+    int rc = dpq::encode(root_code, depths, masks, deltas, n_codes, M, out, n_bytes, &err);
+    return rc ? fail(rc, err) : DPQ_OK;
+}
+
+int dpq_open_file(const char* path, int M, int K, const dpq_open_opts* opts, dpq_index** out) {
+    if (!path || !out) return fail(DPQ_ERR_ARG, "NULL argument");
+    std::vector<uint8_t> buf;
+    std::string err;
+    int rc = dpq::read_file(path, &buf, &err);
+    if (rc) return fail(rc, err);
+    if (buf.size() < 16) return fail(DPQ_ERR_FORMAT, std::string("file shorter than its header: ") + path);
+    int64_t h[2];
+    memcpy(h, buf.data(), 16);  // h:2823-2824
+    if (h[1] < 0 || (uint64_t)h[1] > buf.size() - 16)
+        return fail(DPQ_ERR_FORMAT, "n_bytes in the header exceeds the file size");
+    return open_from_payload(buf.data() + 16, h[1], h[0], M, K, opts, out);
+}
+
+int dpq_open_memory(const uint8_t* payload, int64_t n_bytes, int64_t n_codes, int M, int K,
+                    const dpq_open_opts* opts, dpq_index** out) {
+    return open_from_payload(payload, n_bytes, n_codes, M, K, opts, out);
+}
+
+int dpq_set_codebook(dpq_index* x, const float* codewords, int Ds) {
+    if (!x || !codewords || Ds < 1 || Ds > 4096) return fail(DPQ_ERR_ARG, "bad codebook argument");
+    DPQ_HIP(hipSetDevice(x->device));
+    hipFree(x->d_codebook);
+    x->d_codebook = nullptr;
+    const size_t n = (size_t)x->M * x->K * Ds;
+    int rc = dev_alloc(&x->d_codebook, n);
+    if (rc) return rc;
+    DPQ_HIP(hipMemcpy(x->d_codebook, codewords, n * sizeof(float), hipMemcpyHostToDevice));
+    x->Ds = Ds;
+    x->info.Ds = Ds;
+    return DPQ_OK;
+}
+
+int dpq_get_info(const dpq_index* x, dpq_info* info) {
+    if (!x || !info) return fail(DPQ_ERR_ARG, "NULL argument");
+    *info = x->info;
+    info->cand_capacity = x->cap_auto ? 0 : x->cap;
+    return DPQ_OK;
+}
+
+int dpq_close(dpq_index* x) {
+    if (!x) return DPQ_OK;
+    hipSetDevice(x->device);
+    for (auto& ep : x->events) {
+        hipEventDestroy(ep.a);
+        hipEventDestroy(ep.b);
+    }
+    free_workspace(x);
+    hipFree(x->d_nib);
+    hipFree(x->d_mask);
+    hipFree(x->d_delta);
+    hipFree(x->d_ckpt);
+    hipFree(x->d_seg_off);
+    hipFree(x->d_codebook);
+    hipFree(x->d_seg_lists);
+    hipFree(x->d_q_stage);
+    hipFree(x->d_ids_stage);
+    hipFree(x->d_dists_stage);
+    if (x->h_overflow) hipHostFree(x->h_overflow);
+    delete x;
+    return DPQ_OK;
+}
+
+int dpq_query_batch_device(dpq_index* x, const float* d_queries, int nq, int top_k, int32_t* d_ids, float* d_dists,
+                           void* hip_stream) {
+    if (!x || !d_queries || !d_ids || !d_dists || nq < 0) return fail(DPQ_ERR_ARG, "NULL argument or nq < 0");
+    if (!x->d_codebook) return fail(DPQ_ERR_STATE, "dpq_set_codebook has not been called");
+    if (top_k < 1 || top_k > dpq::kMaxTopK) return fail(DPQ_ERR_ARG, "top_k must be in 1..2048");
+    if ((int64_t)top_k > x->img.n_codes_total)
+        return fail(DPQ_ERR_TOPK, "top_k exceeds the number of codes in the index");
+    if (nq == 0) return DPQ_OK;
+    DPQ_HIP(hipSetDevice(x->device));
+    hipStream_t stream = reinterpret_cast<hipStream_t>(hip_stream);
+    const int D = x->M * x->Ds;
+    for (int base = 0; base < nq; base += kMaxBatchQueries) {
+        const int n = std::min(kMaxBatchQueries, nq - base);
+        int rc = run_batch(x, d_queries + (size_t)base * D, n, top_k, d_ids + (size_t)base * top_k,
+                           d_dists + (size_t)base * top_k, stream);
+        if (rc) return rc;
+    }
+    if (x->prof) {
+        x->prof_acc.query_batches++;
+        x->prof_acc.queries += nq;
+    }
+    return DPQ_OK;
+}
+
+int dpq_query_batch(dpq_index* x, const float* queries, int nq, int top_k, int32_t* ids, float* dists) {
+    if (!x || !queries || !ids || !dists || nq < 0) return fail(DPQ_ERR_ARG, "NULL argument or nq < 0");
+    if (!x->d_codebook) return fail(DPQ_ERR_STATE, "dpq_set_codebook has not been called");
+    if (nq == 0) return DPQ_OK;
+    if (top_k < 1 || top_k > dpq::kMaxTopK) return fail(DPQ_ERR_ARG, "top_k must be in 1..2048");
+    DPQ_HIP(hipSetDevice(x->device));
+    const size_t qf = (size_t)nq * x->M * x->Ds, oe = (size_t)nq * top_k;
+    if (qf > x->q_stage_floats) {
+        hipFree(x->d_q_stage);
+        x->d_q_stage = nullptr;
+        int rc = dev_alloc(&x->d_q_stage, qf);
+        if (rc) return rc;
+        x->q_stage_floats = qf;
+    }
+    if (oe > x->out_stage_elems) {
+        hipFree(x->d_ids_stage);
+        hipFree(x->d_dists_stage);
+        x->d_ids_stage = nullptr;
+        x->d_dists_stage = nullptr;
+        int rc = dev_alloc(&x->d_ids_stage, oe);
+        if (!rc) rc = dev_alloc(&x->d_dists_stage, oe);
+        if (rc) return rc;
+        x->out_stage_elems = oe;
+    }
+    DPQ_HIP(hipMemcpy(x->d_q_stage, queries, qf * sizeof(float), hipMemcpyHostToDevice));
+    int rc = dpq_query_batch_device(x, x->d_q_stage, nq, top_k, x->d_ids_stage, x->d_dists_stage, nullptr);
+    if (rc) return rc;
+    DPQ_HIP(hipDeviceSynchronize());
+    DPQ_HIP(hipMemcpy(ids, x->d_ids_stage, oe * sizeof(int32_t), hipMemcpyDeviceToHost));
+    DPQ_HIP(hipMemcpy(dists, x->d_dists_stage, oe * sizeof(float), hipMemcpyDeviceToHost));
+    return DPQ_OK;
+}
+
+int dpq_merge_topk_host(const int32_t* ids, const float* dists, int n_lists, int nq, int top_k, int32_t* out_ids,
+                        float* out_dists) {
+    if (!ids || !dists || !out_ids || !out_dists || n_lists < 1 || nq < 0 || top_k < 1)
+        return fail(DPQ_ERR_ARG, "bad merge argument");
+    std::vector<uint64_t> keys;
+    for (int q = 0; q < nq; ++q) {
+        keys.clear();
+        for (int l = 0; l < n_lists; ++l)
+            for (int r = 0; r < top_k; ++r) {
+                const size_t o = ((size_t)l * nq + q) * top_k + r;
+                if (ids[o] < 0) continue;
+                uint32_t bits;
+                memcpy(&bits, &dists[o], 4);
+                keys.push_back(((uint64_t)bits << 32) | (uint32_t)ids[o]);
+            }
+        const size_t kk = std::min((size_t)top_k, keys.size());
+        std::partial_sort(keys.begin(), keys.begin() + kk, keys.end());
+        for (int r = 0; r < top_k; ++r) {
+            const size_t o = (size_t)q * top_k + r;
+            if ((size_t)r < kk) {
+                out_ids[o] = (int32_t)(keys[r] & 0xffffffffu);
+                uint32_t bits = (uint32_t)(keys[r] >> 32);
+                memcpy(&out_dists[o], &bits, 4);
+            } else {
+                out_ids[o] = -1;
+                out_dists[o] = INFINITY;
+            }
+        }
+    }
+    return DPQ_OK;
+}
+
+int dpq_merge_topk_device(const int32_t* d_ids, const float* d_dists, int n_lists, int nq, int top_k,
+                          int32_t* d_out_ids, float* d_out_dists, int device, void* hip_stream) {
+    if (!d_ids || !d_dists || !d_out_ids || !d_out_dists || n_lists < 1 || nq < 0 || top_k < 1)
+        return fail(DPQ_ERR_ARG, "bad merge argument");
+    if ((int64_t)n_lists * top_k > 16384) return fail(DPQ_ERR_ARG, "n_lists * top_k exceeds 16384");
+    DPQ_HIP(hipSetDevice(device));
+    DPQ_HIP(dpq::launch_merge(d_ids, d_dists, n_lists, nq, top_k, d_out_ids, d_out_dists,
+                              reinterpret_cast<hipStream_t>(hip_stream)));
+    return DPQ_OK;
+}
+
+int dpq_profile_enable(dpq_index* x, int on) {
+    if (!x) return fail(DPQ_ERR_ARG, "NULL index");
+    x->prof = on != 0;
+    return DPQ_OK;
+}
+
+int dpq_profile_reset(dpq_index* x) {
+    if (!x) return fail(DPQ_ERR_ARG, "NULL index");
+    hipSetDevice(x->device);
+    for (auto& ep : x->events) {
+        hipEventDestroy(ep.a);
+        hipEventDestroy(ep.b);
+    }
+    x->events.clear();
+    memset(&x->prof_acc, 0, sizeof x->prof_acc);
+    return DPQ_OK;
+}
+
+int dpq_profile_read(dpq_index* x, dpq_profile* out) {
+    if (!x || !out) return fail(DPQ_ERR_ARG, "NULL argument");
+    DPQ_HIP(hipSetDevice(x->device));
+    for (auto& ep : x->events) {
+        DPQ_HIP(hipEventSynchronize(ep.b));
+        float ms = 0.f;
+        DPQ_HIP(hipEventElapsedTime(&ms, ep.a, ep.b));
+        if (ep.kind == 0) x->prof_acc.lut_ms += ms;
+        if (ep.kind == 1) x->prof_acc.scan_ms += ms;
+        if (ep.kind == 2) x->prof_acc.select_ms += ms;
+        hipEventDestroy(ep.a);
+        hipEventDestroy(ep.b);
+    }
+    x->events.clear();
+    *out = x->prof_acc;
+    return DPQ_OK;
+}
+
+}  // extern "C"

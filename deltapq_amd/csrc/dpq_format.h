@@ -1,0 +1,89 @@
+// dpq_format.h -- host side of the DTC format: parse, validate, transcode to the
+// structure-of-arrays image the GPU scans, and serialise.  No HIP here.
+//
+// DTC ("delta tree compressed") is the byte stream written by the reference's
+// qnodes_to_compressed_codes_opt (deltapq_create_approx_tree.h:1730-1845) and
+// consumed by its scan (h:2866-2975).  See DESIGN.md "Data layout" for the SoA.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/deltapq_amd.h"
+
+namespace dpq {
+
+constexpr int kChunk = 64;  // nodes per wavefront step
+
+inline int mask_bytes_for(int M) { return M > 8 ? 2 : 1; }
+inline int depth_field_mask(int M) { return M > 8 ? 15 : 7; }  // h:2883 uses & 7 for M <= 8
+inline int levels_for(int M) { return M > 8 ? 16 : 8; }        // ancestor stack entries (h:2858-2864: M of them)
+
+// One (depth, mask, changed bytes) record while walking the payload.
+struct NodeRec {
+    int depth;
+    unsigned mask;
+    const uint8_t* deltas;  // popcount(mask) bytes
+    int n_diff;
+    int64_t payload_begin;  // first payload byte attributed to this node (its depth byte if it owns one)
+    int64_t payload_end;
+};
+
+// Sequential reader of a DTC payload; mirrors the control flow of h:2866-2975.
+class DtcWalker {
+public:
+    DtcWalker(const uint8_t* payload, int64_t n_bytes, int64_t n_codes, int M);
+    // Returns DPQ_OK and fills rec for node `pos()`; DPQ_ERR_FORMAT with a message on violation.
+    int next(NodeRec* rec);
+    int64_t pos() const { return i_; }
+    bool done() const { return i_ >= n_; }
+    int64_t offset() const { return off_; }
+    const std::string& error() const { return err_; }
+
+private:
+    const uint8_t* p_;
+    int64_t nb_, n_;
+    int M_, mb_, dmask_;
+    int64_t i_ = 0, off_ = 0;
+    int pending_depth_ = -1;  // depth of node i+1 taken from the pair byte
+    int max_depth_seen_ = 0;
+    std::string err_;
+};
+
+struct SoA {
+    int M = 8;
+    int levels = 8;
+    int mask_bytes = 1;
+    int chunks_per_segment = 4;
+    int64_t n_codes_total = 0, n_bytes_total = 0;
+    int64_t node_lo = 0, node_hi = 0;  // global DFS positions in this image
+    int64_t n_segments = 0;            // local segments
+    int64_t algorithmic_bytes = 0;
+    int64_t n_diffs = 0;
+    int max_depth = 0;
+    std::vector<uint8_t> nib;             // 4-bit depth per local node, node 2j in the low nibble of byte j
+    std::vector<uint8_t> mask;            // mask_bytes per local node (little endian)
+    std::vector<uint8_t> delta;           // changed bytes, node order, ascending position; 16 bytes of tail padding
+    std::vector<uint64_t> seg_delta_off;  // [n_segments + 1]
+    std::vector<uint8_t> seg_ckpt;        // [n_segments][levels][M]: ancestor stack at the segment's first node
+    int64_t nodes_per_segment() const { return (int64_t)kChunk * chunks_per_segment; }
+    int64_t device_bytes() const {
+        return (int64_t)(nib.size() + mask.size() + delta.size() + seg_delta_off.size() * 8 + seg_ckpt.size());
+    }
+};
+
+int validate(const uint8_t* payload, int64_t n_bytes, int64_t n_codes, int M, dpq_dtc_stats* stats, std::string* err);
+int transcode(const uint8_t* payload, int64_t n_bytes, int64_t n_codes, int M, int shard_rank, int shard_count,
+              int chunks_per_segment, SoA* out, std::string* err);
+int encode(const uint8_t* root_code, const uint8_t* depths, const uint16_t* masks, const uint8_t* deltas,
+           int64_t n_codes, int M, uint8_t* out, int64_t* n_bytes, std::string* err);
+
+// loaders (a10)
+int read_file(const std::string& path, std::vector<uint8_t>* out, std::string* err);
+int read_dtc_header(const std::string& path, int64_t* n_codes, int64_t* n_bytes, std::string* err);
+int read_codewords(const std::string& path, int* M, int* K, int* Ds, std::vector<float>* out, std::string* err);
+int read_vecs(const std::string& path, bool is_bvecs, int64_t* n, int* D, std::vector<float>* out, int64_t cap,
+              std::string* err);
+std::string dtc_file_name(const std::string& dir, int M, int K, int64_t N);
+
+}  // namespace dpq

@@ -1,0 +1,199 @@
+/* deltapq_amd.h -- C-ABI of the MI355X-native DeltaPQ query engine.
+ *
+ * This is the drop-in boundary for ONE path of RunhuiWang/DeltaPQ: the
+ * delta-tree scan behind `deltapq -task query` / `-task query_im`.  The
+ * reference has no FFI layer; its boundary is a C++ free function called once
+ * per query (citations are file:line into the reference repository):
+ *
+ *   void query_processing_scan_compressed_codes_opt_o_direct(
+ *       const string& dataset_path, const vector<float>& query, int top_k,
+ *       int M, int K, int m_Ds, uint num_codes,
+ *       const vector<PQ::Array>& m_codewords,
+ *       vector<pair<int,float>>& results, uchar** decoder);
+ *                                   deltapq_create_approx_tree.h:2805-2810
+ *   void query_processing_scan_compressed_codes_opt_in_memory(
+ *       uchar* codes, long long n_bytes, ...same...);
+ *                                   deltapq_create_approx_tree.h:3731-3736
+ *
+ * A C-ABI replacement splits that call into load-once / query-many:
+ *
+ *   reference                                   this library
+ *   ------------------------------------------  ---------------------------------
+ *   open()+read() of the DTC file per query     dpq_open_file / dpq_open_memory
+ *     (h:2812-2824; main:624-634 for query_im)    (parse, validate, transcode to
+ *                                                 SoA, upload to HBM -- once)
+ *   m_codewords argument (h:2809)               dpq_set_codebook
+ *   one call per query (main:328-339)           dpq_query_batch[_device]
+ *   results[top_k] of (int id, float dist),     ids[nq][top_k] int32,
+ *     ascending (h:2977-2982)                     dists[nq][top_k] float, ascending
+ *   decoder[256] argument (main:312-325)        gone (popcount / byte permute on GPU)
+ *   PQ::ReadCodewords (pq.cpp:288-312)          dpq_read_codewords
+ *   ReadTopN(query.{fvecs,bvecs})               dpq_read_vecs
+ *     (utils.cpp:14-110)
+ *
+ * Conventions: plain pointers and sizes only; the caller owns every host
+ * buffer it passes, the library owns device memory.  Every function returns a
+ * dpq_status (0 = OK, negative = error) instead of the reference's
+ * print-and-continue (h:2819-2821); dpq_last_error() gives a thread-local
+ * detail string.  A handle is bound to one GPU and is safe to use from one
+ * thread at a time.  Nothing here falls back to a CPU implementation: without
+ * a usable GPU dpq_open_* fails with DPQ_ERR_NO_DEVICE.
+ *
+ * Result semantics (identical to the reference, see DESIGN.md "Parity"):
+ *   - ids are DFS positions in the index (h:2910, 2979), NOT original vector ids;
+ *   - distance = fp64 sum of the M fp32 table entries, rounded to fp32, which is
+ *     bit-identical to the reference's incremental fp64 stack (h:2889-2907);
+ *   - for even N the last DFS node is reported with id N, not N-1 (h:2949, 2970);
+ *   - equal-distance results are ordered by ascending id (the reference emits
+ *     them in libstdc++ heap order); at the k-th boundary the lowest ids win.
+ */
+#ifndef DELTAPQ_AMD_H
+#define DELTAPQ_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DPQ_VERSION 100 /* 0.1.0 */
+
+typedef enum dpq_status {
+    DPQ_OK = 0,
+    DPQ_ERR_ARG = -1,       /* bad argument (NULL, M/K unsupported, top_k < 1, ...) */
+    DPQ_ERR_IO = -2,        /* cannot open / short read */
+    DPQ_ERR_FORMAT = -3,    /* DTC stream violates the format invariants */
+    DPQ_ERR_NO_DEVICE = -4, /* no usable gfx950 GPU / bad device ordinal */
+    DPQ_ERR_HIP = -5,       /* HIP runtime error (message in dpq_last_error) */
+    DPQ_ERR_NOMEM = -6,
+    DPQ_ERR_STATE = -7,     /* e.g. query before dpq_set_codebook */
+    DPQ_ERR_TOPK = -8       /* top_k > number of codes (reference: pops an empty heap, h:2977-2981) */
+} dpq_status;
+
+typedef struct dpq_index dpq_index; /* opaque: one DTC index (or one shard of it) resident on one GPU */
+typedef struct dpq_soa dpq_soa;     /* opaque: host-side transcoded image (no GPU needed) */
+
+/* Options for dpq_open_*.  Zero-initialise, then set what you need. */
+typedef struct dpq_open_opts {
+    int32_t device;             /* HIP device ordinal */
+    int32_t shard_rank;         /* this handle holds shard `shard_rank` of `shard_count` */
+    int32_t shard_count;        /* 0 or 1 = whole index; shards are contiguous DFS-position ranges
+                                   cut at segment boundaries and balanced by payload bytes */
+    int32_t chunks_per_segment; /* 64-node chunks per independently decodable segment; 0 = default (4) */
+    int32_t cand_capacity;      /* per-query candidate slots for the threshold cascade; 0 = auto */
+    int32_t reserved[3];
+} dpq_open_opts;
+
+typedef struct dpq_info {
+    int64_t n_codes_total;     /* N of the whole index (header field 0, h:1839-1840) */
+    int64_t n_bytes_total;     /* payload bytes of the whole index (header field 1, h:1841) */
+    int64_t node_lo, node_hi;  /* DFS positions [lo, hi) held by this handle */
+    int64_t algorithmic_bytes; /* DTC payload bytes that encode [lo, hi): the per-query roofline numerator */
+    int64_t device_bytes;      /* HBM bytes of the SoA image (nibbles + masks + deltas + tables) */
+    int64_t n_diffs;           /* changed bytes in [lo, hi) */
+    int32_t M, K, Ds;
+    int32_t n_segments;
+    int32_t chunks_per_segment;
+    int32_t max_depth;
+    int32_t device;
+    int32_t cand_capacity;
+} dpq_info;
+
+/* Per-kernel device time accumulated since the last dpq_profile_reset, measured
+ * with hipEvents recorded on the launch stream (profiling must be enabled). */
+typedef struct dpq_profile {
+    double lut_ms, scan_ms, select_ms; /* summed over launches */
+    int64_t lut_launches, scan_launches, select_launches;
+    int64_t scan_node_query_pairs;     /* (code, query) distance evaluations issued by scan launches */
+    int64_t scan_stream_bytes;         /* SoA bytes the scan launches had to read at least once */
+    int64_t query_batches, queries;
+    int64_t overflow_reruns;           /* queries that needed a second final pass (candidate overflow) */
+} dpq_profile;
+
+typedef struct dpq_dtc_stats {
+    int64_t n_codes, n_bytes, n_diffs;
+    int64_t depth_hist[16];
+    int32_t max_depth;
+    int32_t M;
+} dpq_dtc_stats;
+
+/* ---- library ---------------------------------------------------------- */
+int dpq_version(void);
+const char* dpq_strerror(int status);
+const char* dpq_last_error(void);
+/* Number of usable GPUs (0 if none / no driver).  Never fails. */
+int dpq_device_count(void);
+
+/* ---- loaders around the path (host only; a10 in SURVEY.md section 8) ---- */
+/* DTC file header: int64 n_codes, int64 n_bytes (h:1839-1841, read at h:2823-2824). */
+int dpq_read_dtc_header(const char* path, int64_t* n_codes, int64_t* n_bytes);
+/* PQ::ReadCodewords (pq.cpp:288-312).  Call with out == NULL to get the shape. */
+int dpq_read_codewords(const char* path, int32_t* M, int32_t* K, int32_t* Ds, float* out);
+/* ReadTopN over .fvecs / .bvecs (utils.cpp:14-110).  Call with out == NULL to
+ * get the count and dimension; at most `cap` vectors are stored. */
+int dpq_read_vecs(const char* path, int is_bvecs, int64_t* n, int32_t* D, float* out, int64_t cap);
+/* Reference file name of the index: <dir>/M{M}K{K}_Approx_compressed_codes_opt_N{N} (h:2812-2814). */
+int dpq_dtc_file_name(const char* dataset_dir, int M, int K, int64_t N, char* out, int64_t out_len);
+
+/* ---- format (host only) ------------------------------------------------ */
+/* Walk a DTC payload, checking every invariant the scan relies on
+ * (depth >= 1, depth <= deepest-seen + 1, depth < M, byte count == n_bytes). */
+int dpq_dtc_validate(const uint8_t* payload, int64_t n_bytes, int64_t n_codes, int M, dpq_dtc_stats* stats);
+/* Transcode (a shard of) a DTC payload into the structure-of-arrays image the
+ * GPU scans, on the host.  Used by dpq_open_* and exposed for CPU-only tests. */
+int dpq_soa_build(const uint8_t* payload, int64_t n_bytes, int64_t n_codes, int M, const dpq_open_opts* opts,
+                  dpq_soa** out);
+int dpq_soa_info(const dpq_soa* soa, dpq_info* info);
+/* Borrowed pointers into the image (valid until dpq_soa_free):
+ * which = 0 depth nibbles, 1 masks, 2 deltas, 3 segment delta offsets (u64[n_seg+1]),
+ * 4 segment ancestor checkpoints (u8[n_seg][levels][M]). */
+int dpq_soa_array(const dpq_soa* soa, int which, const void** ptr, int64_t* n_bytes);
+void dpq_soa_free(dpq_soa* soa);
+/* Serialise a tree given as per-node arrays into the reference DTC payload
+ * (qnodes_to_compressed_codes_opt, h:1765-1826).  depths[0] must be 0;
+ * masks[i] bit m set <=> position m changes; deltas = changed bytes in node
+ * order, ascending position.  Call with out == NULL to get n_bytes. */
+int dpq_dtc_encode(const uint8_t* root_code, const uint8_t* depths, const uint16_t* masks, const uint8_t* deltas,
+                   int64_t n_codes, int M, uint8_t* out, int64_t* n_bytes);
+
+/* ---- index lifetime (GPU) ---------------------------------------------- */
+/* Replaces the per-query open()/read() of h:2812-2824: loads
+ * <path> = int64 n_codes, int64 n_bytes, payload. */
+int dpq_open_file(const char* path, int M, int K, const dpq_open_opts* opts, dpq_index** out);
+/* In-memory twin (h:3731-3733: `uchar* codes, long long n_bytes`). */
+int dpq_open_memory(const uint8_t* payload, int64_t n_bytes, int64_t n_codes, int M, int K,
+                    const dpq_open_opts* opts, dpq_index** out);
+/* m_codewords[M][K][Ds] (h:2809), row-major fp32, copied to the GPU. */
+int dpq_set_codebook(dpq_index* idx, const float* codewords, int Ds);
+int dpq_get_info(const dpq_index* idx, dpq_info* info);
+int dpq_close(dpq_index* idx);
+
+/* ---- the hot path ------------------------------------------------------- */
+/* Answer nq queries (host buffers; synchronous).  queries[nq][M*Ds];
+ * ids[nq][top_k], dists[nq][top_k] ascending by (distance, id).  With
+ * shard_count > 1 the lists are this shard's partial top-k with GLOBAL DFS
+ * positions; rows are padded with id -1 / +inf when the shard holds fewer than
+ * top_k codes. */
+int dpq_query_batch(dpq_index* idx, const float* queries, int nq, int top_k, int32_t* ids, float* dists);
+/* Same with device pointers, enqueued on `hip_stream` (a hipStream_t, NULL =
+ * default stream), asynchronous with respect to the host except for one
+ * overflow check at the end of the batch. */
+int dpq_query_batch_device(dpq_index* idx, const float* d_queries, int nq, int top_k, int32_t* d_ids,
+                           float* d_dists, void* hip_stream);
+/* Merge n_lists partial top-k lists per query (lists[l][nq][top_k]) into the
+ * final top_k by (distance, id).  Host version for the single-process
+ * multi-GPU CLI, device version for use after an RCCL all-gather. */
+int dpq_merge_topk_host(const int32_t* ids, const float* dists, int n_lists, int nq, int top_k, int32_t* out_ids,
+                        float* out_dists);
+int dpq_merge_topk_device(const int32_t* d_ids, const float* d_dists, int n_lists, int nq, int top_k,
+                          int32_t* d_out_ids, float* d_out_dists, int device, void* hip_stream);
+
+/* ---- measurement -------------------------------------------------------- */
+int dpq_profile_enable(dpq_index* idx, int on);
+int dpq_profile_reset(dpq_index* idx);
+int dpq_profile_read(dpq_index* idx, dpq_profile* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DELTAPQ_AMD_H */
