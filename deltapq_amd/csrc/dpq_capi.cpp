@@ -88,7 +88,18 @@ struct dpq_index {
     // profiling
     bool prof = false;
     std::vector<EventPair> events;
+    std::vector<hipEvent_t> ev_pool;
     dpq_profile prof_acc{};
+    hipEvent_t get_event() {
+        if (!ev_pool.empty()) {
+            hipEvent_t e = ev_pool.back();
+            ev_pool.pop_back();
+            return e;
+        }
+        hipEvent_t e;
+        hipEventCreate(&e);
+        return e;
+    }
 };
 
 namespace {
@@ -134,53 +145,53 @@ int ensure_workspace(dpq_index* x, int slots, int cap) {
 
 int auto_cap(int top_k) { return std::max(4096, 32 * top_k); }
 
-// Cascade plan: sample sizes (in segments) nseg, nseg/rho, ... down to the
-// level-0 sample that fits the candidate buffer; expected survivors per level
-// = top_k * rho = cap / 3.
+// Progressive cascade plan.  Segments are visited in a low-discrepancy order
+// (so every prefix is a spread-out sample of the DFS stream); level l scans
+// order[bound[l-1] : bound[l]] -- every segment exactly once over the whole
+// cascade -- with the threshold set to the k-th best key of everything seen
+// before.  Expected survivors of a level = top_k * (bound[l]/bound[l-1] - 1).
 int ensure_plan(dpq_index* x, int top_k, int cap) {
     if (x->plan_top_k == top_k && x->plan_cap == cap) return DPQ_OK;
     const int64_t S = (int64_t)dpq::kChunk * x->img.chunks_per_segment;
     const int64_t nseg = x->img.n_segments;
-    std::vector<int64_t> sizes;
-    const int64_t s0 = std::max<int64_t>(1, cap / S);
+    // level 0 keeps every node it sees: at least 2*top_k nodes, at most `cap`
+    int64_t s0 = (std::max<int64_t>(1024, 2 * (int64_t)top_k) + S - 1) / S;
+    s0 = std::max<int64_t>(1, std::min<int64_t>(s0, std::max<int64_t>(1, cap / S)));
+    std::vector<int64_t> bounds;
     if (s0 >= nseg) {
-        sizes.push_back(nseg);
+        bounds.push_back(nseg);
     } else {
-        const double rho = std::max(2.0, (double)cap / (3.0 * top_k));
-        int64_t cur = nseg;
-        sizes.push_back(cur);
-        while (true) {
-            const int64_t nxt = (int64_t)std::floor((double)cur / rho);
-            if (nxt <= s0) break;
-            sizes.push_back(nxt);
-            cur = nxt;
+        bounds.push_back(nseg);
+        const int ratios[] = {2, 4, 8};
+        int64_t b = nseg;
+        for (int i = 0;; ++i) {
+            const int64_t nb = b / ratios[std::min(i, 2)];
+            if (nb < 2 * s0) break;
+            bounds.push_back(nb);
+            b = nb;
         }
-        sizes.push_back(s0);
-        std::reverse(sizes.begin(), sizes.end());
+        bounds.push_back(s0);
+        std::reverse(bounds.begin(), bounds.end());
     }
-    std::vector<uint32_t> lists;
     x->level_off.clear();
     x->level_cnt.clear();
-    for (size_t l = 0; l < sizes.size(); ++l) {
-        const int64_t n = sizes[l];
-        if (n == nseg) {  // the full level needs no list
-            x->level_off.push_back(-1);
-            x->level_cnt.push_back((int)nseg);
-            continue;
-        }
-        x->level_off.push_back((int)lists.size());
-        x->level_cnt.push_back((int)n);
-        for (int64_t j = 0; j < n; ++j) lists.push_back((uint32_t)((j * nseg) / n));
+    int64_t prev = 0;
+    for (int64_t bnd : bounds) {
+        x->level_off.push_back((int)prev);
+        x->level_cnt.push_back((int)(bnd - prev));
+        prev = bnd;
     }
-    if (lists.size() > x->seg_lists_cap) {
-        hipFree(x->d_seg_lists);
-        x->d_seg_lists = nullptr;
-        int rc = dev_alloc(&x->d_seg_lists, lists.size());
+    if (!x->d_seg_lists && nseg > 0) {
+        // order[j] = j * P mod nseg, P ~ nseg / golden ratio, gcd(P, nseg) = 1
+        std::vector<uint32_t> order((size_t)nseg);
+        int64_t P = std::max<int64_t>(1, (int64_t)((double)nseg * 0.6180339887498949));
+        auto gcd = [](int64_t a, int64_t b) { while (b) { int64_t t = a % b; a = b; b = t; } return a; };
+        while (gcd(P, nseg) != 1) ++P;
+        for (int64_t j = 0; j < nseg; ++j) order[(size_t)j] = (uint32_t)((j * P) % nseg);
+        int rc = dev_alloc(&x->d_seg_lists, (size_t)nseg);
         if (rc) return rc;
-        x->seg_lists_cap = lists.size();
+        DPQ_HIP(hipMemcpy(x->d_seg_lists, order.data(), (size_t)nseg * sizeof(uint32_t), hipMemcpyHostToDevice));
     }
-    if (!lists.empty())
-        DPQ_HIP(hipMemcpy(x->d_seg_lists, lists.data(), lists.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     x->plan_top_k = top_k;
     x->plan_cap = cap;
     return DPQ_OK;
@@ -195,8 +206,8 @@ struct Timer {
     Timer(dpq_index* x_, hipStream_t s_, int kind_) : x(x_), s(s_), kind(kind_), on(x_->prof) {
         if (on) {
             ep.kind = kind;
-            hipEventCreate(&ep.a);
-            hipEventCreate(&ep.b);
+            ep.a = x->get_event();
+            ep.b = x->get_event();
             hipEventRecord(ep.a, s);
         }
     }
@@ -209,9 +220,10 @@ struct Timer {
 };
 
 int splits_for(int n_seg_pass, int n_groups) {
-    // enough workgroups to fill 256 CUs about twice, but no more waves than segments
-    int by_work = (n_seg_pass + dpq::kScanWaves - 1) / dpq::kScanWaves;
-    int want = std::max(1, (512 + n_groups - 1) / n_groups);
+    // One workgroup per CU is resident (LDS), so aim at a whole number of
+    // chip-waves: <= 2 x 256 workgroups, and no more waves than segments.
+    const int by_work = (n_seg_pass + dpq::kScanWaves - 1) / dpq::kScanWaves;
+    const int want = std::max(1, 512 / std::max(1, n_groups));
     return std::max(1, std::min(by_work, want));
 }
 
@@ -266,16 +278,17 @@ int run_batch(dpq_index* x, const float* d_queries, int nq, int top_k, int32_t* 
 
     const int64_t S = (int64_t)dpq::kChunk * x->img.chunks_per_segment;
     const size_t n_levels = x->img.n_segments > 0 ? x->level_cnt.size() : 0;
+    DPQ_HIP(hipMemsetAsync(x->d_cand_count, 0, sizeof(uint32_t) * nqp, stream));
+    DPQ_HIP(hipMemsetAsync(x->d_overflow, 0, sizeof(uint32_t) * nqp, stream));
     if (n_levels == 0) {  // empty shard: every row is padding
-        DPQ_HIP(hipMemsetAsync(x->d_cand_count, 0, sizeof(uint32_t) * nqp, stream));
         se.final_pass = 1;
         DPQ_HIP(dpq::launch_select(se, nq, stream));
         return DPQ_OK;
     }
     for (size_t l = 0; l < n_levels; ++l) {
         const bool final_pass = l + 1 == n_levels;
-        DPQ_HIP(hipMemsetAsync(x->d_cand_count, 0, sizeof(uint32_t) * nqp, stream));
-        sa.seg_list = x->level_off[l] < 0 ? nullptr : x->d_seg_lists + x->level_off[l];
+        // level l appends behind the winners the previous select carried over
+        sa.seg_list = n_levels == 1 ? nullptr : x->d_seg_lists + x->level_off[l];
         sa.n_seg_pass = x->level_cnt[l];
         {
             Timer t(x, stream, 1);
@@ -295,26 +308,23 @@ int run_batch(dpq_index* x, const float* d_queries, int nq, int top_k, int32_t* 
         if (x->prof) x->prof_acc.select_launches++;
     }
 
-    // The only host synchronisation of the batch: did any query overflow its
-    // candidate buffer in the final level?  (Then its list may miss candidates.)
+    // The only host synchronisation of the batch: did any query drop candidates
+    // at some level (buffer overflow)?  Then its list may miss entries.
     std::vector<int> over;
-    uint32_t max_cnt = 0;
     for (int base = 0; base < nq; base += 4096) {
         const int n = std::min(4096, nq - base);
         DPQ_HIP(hipMemcpyAsync(x->h_overflow, x->d_overflow + base, sizeof(uint32_t) * n, hipMemcpyDeviceToHost,
                                stream));
         DPQ_HIP(hipStreamSynchronize(stream));
         for (int i = 0; i < n; ++i)
-            if (x->h_overflow[i]) {
-                over.push_back(base + i);
-                max_cnt = std::max(max_cnt, x->h_overflow[i]);
-            }
+            if (x->h_overflow[i]) over.push_back(base + i);
     }
     if (over.empty()) return DPQ_OK;
 
-    // Rerun the final level for the affected LUT groups with buffers sized from
-    // the now-known candidate counts (the thresholds are unchanged, so the count
-    // is exact and one rerun always suffices).
+    // Rerun the affected LUT groups over the whole shard in ONE level.  The k-th
+    // key of the incomplete list is still a valid upper bound (its entries are
+    // real nodes), and it is tight, so the number of nodes under it is about
+    // top_k; grow the buffer and repeat in the (pathological) case it is not.
     std::vector<int> groups;
     for (int q : over) {
         int g = q / QG;
@@ -322,7 +332,6 @@ int run_batch(dpq_index* x, const float* d_queries, int nq, int top_k, int32_t* 
     }
     const int ng2 = (int)groups.size();
     const int slots2 = ng2 * QG;
-    const int cap2 = (int)std::min<uint64_t>((uint64_t)max_cnt + 64, (uint64_t)INT32_MAX / 2);
     std::vector<int32_t> slot_query((size_t)slots2, -1);
     std::vector<uint64_t> h_key((size_t)nqp), k2((size_t)slots2, 0);
     std::vector<float> h_hi((size_t)nqp), h_lo((size_t)nqp), hi2((size_t)slots2, -1.0f), lo2((size_t)slots2, -1.0f);
@@ -341,63 +350,80 @@ int run_batch(dpq_index* x, const float* d_queries, int nq, int top_k, int32_t* 
             }
         }
     const size_t W = (size_t)x->M / 4;
-    int32_t *d_groups = nullptr, *d_slot_query = nullptr;
-    uint32_t *c_count = nullptr, *c_id = nullptr, *c_code = nullptr, *c_over = nullptr;
-    uint64_t *c_keys = nullptr, *c_tk = nullptr;
-    float *c_hi = nullptr, *c_lo = nullptr;
-    auto cleanup = [&]() {
-        hipFree(d_groups); hipFree(d_slot_query); hipFree(c_count); hipFree(c_id); hipFree(c_code);
-        hipFree(c_over); hipFree(c_keys); hipFree(c_tk); hipFree(c_hi); hipFree(c_lo);
-    };
-    rc = dev_alloc(&d_groups, (size_t)ng2);
-    if (!rc) rc = dev_alloc(&d_slot_query, (size_t)slots2);
-    if (!rc) rc = dev_alloc(&c_count, (size_t)slots2);
-    if (!rc) rc = dev_alloc(&c_id, (size_t)slots2 * cap2);
-    if (!rc) rc = dev_alloc(&c_code, (size_t)slots2 * cap2 * W);
-    if (!rc) rc = dev_alloc(&c_over, (size_t)slots2);
-    if (!rc) rc = dev_alloc(&c_keys, (size_t)slots2 * cap2);
-    if (!rc) rc = dev_alloc(&c_tk, (size_t)slots2);
-    if (!rc) rc = dev_alloc(&c_hi, (size_t)slots2);
-    if (!rc) rc = dev_alloc(&c_lo, (size_t)slots2);
-    if (rc) {
+    int64_t cap2 = std::max(cap, 8 * top_k);
+    for (int attempt = 0;; ++attempt) {
+        int32_t *d_groups = nullptr, *d_slot_query = nullptr;
+        uint32_t *c_count = nullptr, *c_id = nullptr, *c_code = nullptr, *c_over = nullptr;
+        uint64_t *c_keys = nullptr, *c_tk = nullptr;
+        float *c_hi = nullptr, *c_lo = nullptr;
+        auto cleanup = [&]() {
+            hipFree(d_groups); hipFree(d_slot_query); hipFree(c_count); hipFree(c_id); hipFree(c_code);
+            hipFree(c_over); hipFree(c_keys); hipFree(c_tk); hipFree(c_hi); hipFree(c_lo);
+        };
+        rc = dev_alloc(&d_groups, (size_t)ng2);
+        if (!rc) rc = dev_alloc(&d_slot_query, (size_t)slots2);
+        if (!rc) rc = dev_alloc(&c_count, (size_t)slots2);
+        if (!rc) rc = dev_alloc(&c_id, (size_t)slots2 * cap2);
+        if (!rc) rc = dev_alloc(&c_code, (size_t)slots2 * cap2 * W);
+        if (!rc) rc = dev_alloc(&c_over, (size_t)slots2);
+        if (!rc) rc = dev_alloc(&c_keys, (size_t)slots2 * cap2);
+        if (!rc) rc = dev_alloc(&c_tk, (size_t)slots2);
+        if (!rc) rc = dev_alloc(&c_hi, (size_t)slots2);
+        if (!rc) rc = dev_alloc(&c_lo, (size_t)slots2);
+        if (rc) {
+            cleanup();
+            return rc;
+        }
+        hipError_t e = hipSuccess;
+        auto chk = [&](hipError_t r) { if (e == hipSuccess) e = r; };
+        chk(hipMemcpy(d_groups, groups.data(), sizeof(int32_t) * ng2, hipMemcpyHostToDevice));
+        chk(hipMemcpy(d_slot_query, slot_query.data(), sizeof(int32_t) * slots2, hipMemcpyHostToDevice));
+        chk(hipMemcpy(c_tk, k2.data(), sizeof(uint64_t) * slots2, hipMemcpyHostToDevice));
+        chk(hipMemcpy(c_hi, hi2.data(), sizeof(float) * slots2, hipMemcpyHostToDevice));
+        chk(hipMemcpy(c_lo, lo2.data(), sizeof(float) * slots2, hipMemcpyHostToDevice));
+        chk(hipMemsetAsync(c_count, 0, sizeof(uint32_t) * slots2, stream));
+        chk(hipMemsetAsync(c_over, 0, sizeof(uint32_t) * slots2, stream));
+        sa.seg_list = nullptr;
+        sa.n_seg_pass = x->img.n_segments;
+        sa.group_list = d_groups;
+        sa.thr_hi = c_hi;
+        sa.thr_lo = c_lo;
+        sa.thr_key = c_tk;
+        sa.cand_count = c_count;
+        sa.cand_id = c_id;
+        sa.cand_code = c_code;
+        sa.cap = (int32_t)cap2;
+        chk(dpq::launch_scan(sa, ng2, splits_for(sa.n_seg_pass, ng2), stream));
+        // the scan's counts are exact (rank of the threshold key), read them before select resets anything
+        std::vector<uint32_t> h_cnt((size_t)slots2, 0);
+        chk(hipMemcpyAsync(h_cnt.data(), c_count, sizeof(uint32_t) * slots2, hipMemcpyDeviceToHost, stream));
+        chk(hipStreamSynchronize(stream));
+        uint32_t max_cnt = 0;
+        for (uint32_t c : h_cnt) max_cnt = std::max(max_cnt, c);
+        if (e == hipSuccess && (int64_t)max_cnt > cap2 && attempt < 4) {
+            cleanup();
+            cap2 = (int64_t)max_cnt + 64;
+            continue;
+        }
+        se.cand_count = c_count;
+        se.cand_id = c_id;
+        se.cand_code = c_code;
+        se.cap = (int32_t)cap2;
+        se.slot_query = d_slot_query;
+        se.keys = c_keys;
+        se.thr_key = c_tk;
+        se.thr_hi = c_hi;
+        se.thr_lo = c_lo;
+        se.overflow = c_over;
+        se.final_pass = 1;
+        chk(dpq::launch_select(se, slots2, stream));
+        chk(hipStreamSynchronize(stream));
         cleanup();
-        return rc;
+        if (e != hipSuccess) return fail(DPQ_ERR_HIP, std::string("overflow rerun: ") + hipGetErrorString(e));
+        if ((int64_t)max_cnt > cap2) return fail(DPQ_ERR_NOMEM, "candidate overflow persisted after reruns");
+        break;
     }
-    hipError_t e = hipSuccess;
-    auto chk = [&](hipError_t r) { if (e == hipSuccess) e = r; };
-    chk(hipMemcpy(d_groups, groups.data(), sizeof(int32_t) * ng2, hipMemcpyHostToDevice));
-    chk(hipMemcpy(d_slot_query, slot_query.data(), sizeof(int32_t) * slots2, hipMemcpyHostToDevice));
-    chk(hipMemcpy(c_tk, k2.data(), sizeof(uint64_t) * slots2, hipMemcpyHostToDevice));
-    chk(hipMemcpy(c_hi, hi2.data(), sizeof(float) * slots2, hipMemcpyHostToDevice));
-    chk(hipMemcpy(c_lo, lo2.data(), sizeof(float) * slots2, hipMemcpyHostToDevice));
-    chk(hipMemsetAsync(c_count, 0, sizeof(uint32_t) * slots2, stream));
-    sa.seg_list = nullptr;
-    sa.n_seg_pass = x->img.n_segments;
-    sa.group_list = d_groups;
-    sa.thr_hi = c_hi;
-    sa.thr_lo = c_lo;
-    sa.thr_key = c_tk;
-    sa.cand_count = c_count;
-    sa.cand_id = c_id;
-    sa.cand_code = c_code;
-    sa.cap = cap2;
-    chk(dpq::launch_scan(sa, ng2, splits_for(sa.n_seg_pass, ng2), stream));
-    se.cand_count = c_count;
-    se.cand_id = c_id;
-    se.cand_code = c_code;
-    se.cap = cap2;
-    se.slot_query = d_slot_query;
-    se.keys = c_keys;
-    se.thr_key = c_tk;
-    se.thr_hi = c_hi;
-    se.thr_lo = c_lo;
-    se.overflow = c_over;
-    se.final_pass = 1;
-    chk(dpq::launch_select(se, slots2, stream));
-    chk(hipStreamSynchronize(stream));
-    cleanup();
     if (x->prof) x->prof_acc.overflow_reruns += (int64_t)over.size();
-    if (e != hipSuccess) return fail(DPQ_ERR_HIP, std::string("overflow rerun: ") + hipGetErrorString(e));
     return DPQ_OK;
 }
 
@@ -665,6 +691,7 @@ int dpq_close(dpq_index* x) {
         hipEventDestroy(ep.a);
         hipEventDestroy(ep.b);
     }
+    for (auto e : x->ev_pool) hipEventDestroy(e);
     free_workspace(x);
     hipFree(x->d_nib);
     hipFree(x->d_mask);
@@ -781,6 +808,55 @@ int dpq_merge_topk_device(const int32_t* d_ids, const float* d_dists, int n_list
     return DPQ_OK;
 }
 
+// Developer hook (not in the public header): time `reps` full-index scan launches
+// for nq queries with thresholds fixed at `thr` (-1: nothing survives, +inf:
+// everything survives), to separate decode/ADC cost from candidate handling.
+// Needs a prior dpq_query_batch* call with >= nq queries so that the workspace
+// (LUT images) exists.
+int dpq_debug_scan_time(dpq_index* x, int nq, float thr, int reps, int splits, float* ms_out) {
+    if (!x || !ms_out || !x->d_lut) return fail(DPQ_ERR_STATE, "run a query batch first");
+    DPQ_HIP(hipSetDevice(x->device));
+    const int QG = dpq::queries_per_group(x->M);
+    const int nqp = (nq + QG - 1) / QG * QG;
+    if (nqp > x->ws_slots) return fail(DPQ_ERR_ARG, "nq exceeds the workspace");
+    std::vector<float> h((size_t)nqp, thr);
+    std::vector<uint64_t> hk((size_t)nqp, thr < 0 ? 0ull : ~0ull);
+    DPQ_HIP(hipMemcpy(x->d_thr_hi, h.data(), sizeof(float) * nqp, hipMemcpyHostToDevice));
+    DPQ_HIP(hipMemcpy(x->d_thr_lo, h.data(), sizeof(float) * nqp, hipMemcpyHostToDevice));
+    DPQ_HIP(hipMemcpy(x->d_thr_key, hk.data(), sizeof(uint64_t) * nqp, hipMemcpyHostToDevice));
+    dpq::ScanArgs sa{};
+    sa.img = x->img;
+    sa.lut = x->d_lut;
+    sa.seg_list = nullptr;
+    sa.n_seg_pass = x->img.n_segments;
+    sa.thr_hi = x->d_thr_hi;
+    sa.thr_lo = x->d_thr_lo;
+    sa.thr_key = x->d_thr_key;
+    sa.cand_count = x->d_cand_count;
+    sa.cand_id = x->d_cand_id;
+    sa.cand_code = x->d_cand_code;
+    sa.cap = x->ws_cap;
+    if (splits <= 0) splits = splits_for(sa.n_seg_pass, nqp / QG);
+    hipEvent_t a, b;
+    DPQ_HIP(hipEventCreate(&a));
+    DPQ_HIP(hipEventCreate(&b));
+    DPQ_HIP(hipMemset(x->d_cand_count, 0, sizeof(uint32_t) * nqp));
+    DPQ_HIP(dpq::launch_scan(sa, nqp / QG, splits, nullptr));
+    DPQ_HIP(hipEventRecord(a, nullptr));
+    for (int r = 0; r < reps; ++r) {
+        DPQ_HIP(hipMemsetAsync(x->d_cand_count, 0, sizeof(uint32_t) * nqp, nullptr));
+        DPQ_HIP(dpq::launch_scan(sa, nqp / QG, splits, nullptr));
+    }
+    DPQ_HIP(hipEventRecord(b, nullptr));
+    DPQ_HIP(hipEventSynchronize(b));
+    float ms = 0;
+    DPQ_HIP(hipEventElapsedTime(&ms, a, b));
+    *ms_out = ms / reps;
+    hipEventDestroy(a);
+    hipEventDestroy(b);
+    return DPQ_OK;
+}
+
 int dpq_profile_enable(dpq_index* x, int on) {
     if (!x) return fail(DPQ_ERR_ARG, "NULL index");
     x->prof = on != 0;
@@ -791,8 +867,8 @@ int dpq_profile_reset(dpq_index* x) {
     if (!x) return fail(DPQ_ERR_ARG, "NULL index");
     hipSetDevice(x->device);
     for (auto& ep : x->events) {
-        hipEventDestroy(ep.a);
-        hipEventDestroy(ep.b);
+        x->ev_pool.push_back(ep.a);
+        x->ev_pool.push_back(ep.b);
     }
     x->events.clear();
     memset(&x->prof_acc, 0, sizeof x->prof_acc);
@@ -809,8 +885,8 @@ int dpq_profile_read(dpq_index* x, dpq_profile* out) {
         if (ep.kind == 0) x->prof_acc.lut_ms += ms;
         if (ep.kind == 1) x->prof_acc.scan_ms += ms;
         if (ep.kind == 2) x->prof_acc.select_ms += ms;
-        hipEventDestroy(ep.a);
-        hipEventDestroy(ep.b);
+        x->ev_pool.push_back(ep.a);
+        x->ev_pool.push_back(ep.b);
     }
     x->events.clear();
     *out = x->prof_acc;

@@ -1,0 +1,222 @@
+// dpq_cli.cpp -- `deltapq`, the reference-compatible command line driver for the
+// query path, on top of the C-ABI (include/deltapq_amd.h).
+//
+// Mirrors the flag surface and output of the reference driver
+// (/root/reference/deltapq_approx_tree_main.cpp:14-70 flags, :265-349 `-task
+// query`, :617-710 `-task query_im`):
+//
+//   deltapq -dataset DIR -task query -m 8 -k 256 -h 1 -diff 8 -N 1000000
+//           -query_size 1000 -topk 100 [-ext fvecs|bvecs] [-debug]
+//           [-gpus G] [-out FILE]
+//
+// Files read from DIR, same names as the reference: M{m}K{k}codewords.txt
+// (main:274), query.{ext} (main:303), M{m}K{k}_Approx_compressed_codes_opt_N{N}
+// (h:2812-2814).  -h, -diff and -method are parsed and ignored by the query, as
+// in the reference.  Both `query` and `query_im` load the
+// index once into HBM (the reference re-opens the file per query for `query`).
+// Extensions: -gpus G shards the index over G GPUs of this node and merges the
+// partial top-k lists on the host; -out writes all results (the reference
+// only prints top-1 under -debug).
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <iostream>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/deltapq_amd.h"
+
+static double Elapsed() {  // utils.cpp:112-116
+    using namespace std::chrono;
+    return duration<double>(system_clock::now().time_since_epoch()).count();
+}
+
+static int die(const char* where, int rc) {
+    std::cout << where << ": " << dpq_strerror(rc) << ": " << dpq_last_error() << std::endl;
+    return 1;
+}
+
+int main(int argc, char* argv[]) {
+    std::string dataset, queryset, task = "approx_tree", ext = "fvecs", out_path;
+    int query_size = -1, top_k = 1, diff_argument = 1, debug = 0, max_height_folds = 1, method = 1;
+    int PQ_M = 0, PQ_K = 0, gpus = 1;
+    long long N = -1;
+    for (int i = 0; i < argc; i++) {  // main:26-70: hand-rolled scan, no validation
+        std::string arg = argv[i];
+        const char* nx = i + 1 < argc ? argv[i + 1] : "";
+        if (arg == "-dataset") dataset = nx;
+        if (arg == "-queryset") queryset = nx;
+        if (arg == "-task") task = nx;
+        if (arg == "-topk") top_k = atoi(nx);
+        if (arg == "-N") N = atoll(nx);
+        if (arg == "-diff") diff_argument = atoi(nx);
+        if (arg == "-query_size") query_size = atoi(nx);
+        if (arg == "-m") PQ_M = atoi(nx);
+        if (arg == "-k") PQ_K = atoi(nx);
+        if (arg == "-ext") ext = nx;
+        if (arg == "-debug") debug = 1;
+        if (arg == "-h") max_height_folds = atoi(nx);  // max height folds, not help (main:61-63)
+        if (arg == "-method") method = atoi(nx);
+        if (arg == "-gpus") gpus = atoi(nx);
+        if (arg == "-out") out_path = nx;
+    }
+    (void)diff_argument; (void)max_height_folds; (void)method; (void)queryset;
+
+    if (task != "query" && task != "query_im") {
+        std::cout << "deltapq (MI355X build): only -task query and -task query_im are implemented; got '" << task
+                  << "'" << std::endl;
+        return 2;
+    }
+    if (PQ_M <= 0 || PQ_K <= 0 || dataset.empty()) {
+        std::cout << "usage: deltapq -dataset DIR -task query -m M -k K -N N -query_size Q -topk K [-ext fvecs|bvecs]"
+                     " [-debug] [-gpus G] [-out FILE]" << std::endl;
+        return 2;
+    }
+
+    // main:274-275
+    const std::string cw_path = dataset + "/M" + std::to_string(PQ_M) + "K" + std::to_string(PQ_K) + "codewords.txt";
+    std::cout << cw_path << std::endl;
+    int32_t cM = 0, cK = 0, cDs = 0;
+    int rc = dpq_read_codewords(cw_path.c_str(), &cM, &cK, &cDs, nullptr);
+    if (rc) return die("ReadCodewords", rc);
+    std::vector<float> codewords((size_t)cM * cK * cDs);
+    rc = dpq_read_codewords(cw_path.c_str(), &cM, &cK, &cDs, codewords.data());
+    if (rc) return die("ReadCodewords", rc);
+    std::cout << "++++++ codewords read from +++++" << cw_path << std::endl;
+    std::cout << "++++++ " << cM << "Ks " << cK << "Ds " << cDs << std::endl;
+    if (cM != PQ_M || cK != PQ_K) {
+        std::cout << "codewords file is M=" << cM << " K=" << cK << " but -m " << PQ_M << " -k " << PQ_K << std::endl;
+        return 1;
+    }
+
+    // index file (h:2812-2814); N == -1: take it from the only header we can find is not
+    // possible without the name, so like the reference the caller must pass -N.
+    char fname[4096];
+    rc = dpq_dtc_file_name(dataset.c_str(), PQ_M, PQ_K, N, fname, sizeof fname);
+    if (rc) return die("file name", rc);
+    std::cout << fname << std::endl;
+    int64_t n_codes = 0, n_bytes = 0;
+    rc = dpq_read_dtc_header(fname, &n_codes, &n_bytes);
+    if (rc) return die("open index", rc);
+    if (N != n_codes) {  // h:2826-2829 / main:629-632
+        std::cout << "scan only part of the codes " << N << " / " << n_codes
+                  << " is not supported by this build: pass -N " << n_codes << std::endl;
+        return 1;
+    }
+    std::cout << "M = " << PQ_M << std::endl;
+    std::cout << "K = " << PQ_K << std::endl;
+    std::cout << "N = " << N << std::endl;
+    std::cout << dataset << std::endl;
+
+    // main:303-308
+    const std::string q_path = dataset + "/query." + ext;
+    std::cout << "In ReadTopN " << q_path << std::endl;
+    int64_t nq_file = 0;
+    int32_t D = 0;
+    rc = dpq_read_vecs(q_path.c_str(), ext == "bvecs", &nq_file, &D, nullptr, 0);
+    if (rc) return die("ReadTopN", rc);
+    std::cout << nq_file << " query vectors read from " << q_path << std::endl;
+    int64_t nq = nq_file;
+    if (nq > 10000) nq = 10000;
+    if (query_size != -1) {
+        if (query_size > nq) {
+            std::cout << "-query_size " << query_size << " exceeds the " << nq << " available queries" << std::endl;
+            return 1;
+        }
+        nq = query_size;
+    }
+    std::vector<float> queries((size_t)nq * D);
+    rc = dpq_read_vecs(q_path.c_str(), ext == "bvecs", &nq_file, &D, queries.data(), nq);
+    if (rc) return die("ReadTopN", rc);
+    if (D != PQ_M * cDs) {
+        std::cout << "query dimension " << D << " != M*Ds = " << PQ_M * cDs << std::endl;
+        return 1;
+    }
+
+    const int ndev = dpq_device_count();
+    if (ndev < 1) {
+        std::cout << "no GPU visible: this build has no CPU query path" << std::endl;
+        return 1;
+    }
+    if (gpus < 1) gpus = 1;
+    if (gpus > ndev) {
+        std::cout << "-gpus " << gpus << " but only " << ndev << " device(s) visible" << std::endl;
+        return 1;
+    }
+
+    // load once: parse + transcode + upload, one shard per GPU
+    std::vector<dpq_index*> shards((size_t)gpus, nullptr);
+    const double tl0 = Elapsed();
+    for (int g = 0; g < gpus; ++g) {
+        dpq_open_opts o;
+        memset(&o, 0, sizeof o);
+        o.device = g;
+        o.shard_rank = g;
+        o.shard_count = gpus;
+        rc = dpq_open_file(fname, PQ_M, PQ_K, &o, &shards[(size_t)g]);
+        if (rc) return die("dpq_open_file", rc);
+        rc = dpq_set_codebook(shards[(size_t)g], codewords.data(), cDs);
+        if (rc) return die("dpq_set_codebook", rc);
+    }
+    std::cout << "index resident on " << gpus << " GPU(s) in " << (Elapsed() - tl0) << " [sec]" << std::endl;
+
+    // ranked_scores[q] = vector<pair<int,float>>(top_k)  (main:310-311), flattened
+    std::vector<int32_t> ids((size_t)nq * top_k);
+    std::vector<float> dists((size_t)nq * top_k);
+    std::vector<int32_t> part_ids;
+    std::vector<float> part_dists;
+    if (gpus > 1) {
+        part_ids.resize((size_t)gpus * nq * top_k);
+        part_dists.resize((size_t)gpus * nq * top_k);
+    }
+
+    const double t0 = Elapsed();  // main:327
+    if (gpus == 1) {
+        rc = dpq_query_batch(shards[0], queries.data(), (int)nq, top_k, ids.data(), dists.data());
+        if (rc) return die("dpq_query_batch", rc);
+    } else {
+        std::vector<int> rcs((size_t)gpus, 0);
+        std::vector<std::string> msgs((size_t)gpus);
+        std::vector<std::thread> th;
+        for (int g = 0; g < gpus; ++g)
+            th.emplace_back([&, g]() {
+                rcs[(size_t)g] = dpq_query_batch(shards[(size_t)g], queries.data(), (int)nq, top_k,
+                                                 part_ids.data() + (size_t)g * nq * top_k,
+                                                 part_dists.data() + (size_t)g * nq * top_k);
+                if (rcs[(size_t)g]) msgs[(size_t)g] = dpq_last_error();
+            });
+        for (auto& t : th) t.join();
+        for (int g = 0; g < gpus; ++g)
+            if (rcs[(size_t)g]) {
+                std::cout << "shard " << g << ": " << dpq_strerror(rcs[(size_t)g]) << ": " << msgs[(size_t)g]
+                          << std::endl;
+                return 1;
+            }
+        rc = dpq_merge_topk_host(part_ids.data(), part_dists.data(), gpus, (int)nq, top_k, ids.data(), dists.data());
+        if (rc) return die("dpq_merge_topk_host", rc);
+    }
+    const double elapsed = Elapsed() - t0;
+    if (debug)  // main:340-343: top-1 per query
+        for (int64_t q = 0; q < nq; ++q)
+            std::cout << ids[(size_t)q * top_k] << " " << dists[(size_t)q * top_k] << std::endl;
+    std::cout << elapsed / (double)nq * 1000 << " [msec/query] " << std::endl;  // main:345
+    std::cout << nq << " queries run" << std::endl;                              // main:347
+
+    if (!out_path.empty()) {
+        FILE* f = fopen(out_path.c_str(), "wb");
+        if (!f) {
+            std::cout << "cannot open " << out_path << std::endl;
+            return 1;
+        }
+        int64_t hdr[2] = {nq, top_k};
+        fwrite(hdr, sizeof(int64_t), 2, f);
+        fwrite(ids.data(), sizeof(int32_t), ids.size(), f);
+        fwrite(dists.data(), sizeof(float), dists.size(), f);
+        fclose(f);
+    }
+    for (auto* s : shards) dpq_close(s);
+    std::cout << "===========================" << std::endl << std::endl;  // main:711
+    return 0;
+}

@@ -10,6 +10,7 @@ constexpr int kScanThreads = 1024;  // 16 wavefronts, one workgroup per CU (LDS-
 constexpr int kScanWaves = kScanThreads / 64;
 constexpr int kMaxTopK = 2048;
 constexpr int kSelectThreads = 512;
+constexpr int kStage = 128;  // LDS-staged candidates per query per scan workgroup
 
 // queries per LUT group: one scan workgroup keeps QG per-query M x 256 fp32
 // tables in LDS (128 KB) and decodes each chunk once for all of them.
@@ -47,9 +48,9 @@ struct ScanArgs {
 };
 
 struct SelectArgs {
-    const uint32_t* cand_count;
-    const uint32_t* cand_id;
-    const uint32_t* cand_code;
+    uint32_t* cand_count;        // in: candidates per slot; out (non-final): winners carried to the next level
+    uint32_t* cand_id;
+    uint32_t* cand_code;
     int32_t cap;
     const float* lut;            // grouped images
     const int32_t* slot_query;   // slot -> query index in the batch (LUT lookup + output row), NULL = identity
@@ -60,7 +61,7 @@ struct SelectArgs {
     uint64_t* thr_key;           // out [slots]
     float* thr_hi;               // out [slots]
     float* thr_lo;               // out [slots]
-    uint32_t* overflow;          // out [slots]: candidate count when it exceeded cap, else 0 (final pass only)
+    uint32_t* overflow;          // out [slots]: set to 1 when a level dropped candidates (sticky)
     int32_t* out_ids;            // [nq][top_k]
     float* out_dists;            // [nq][top_k]
     int64_t n_codes_total;

@@ -107,6 +107,11 @@ __global__ __launch_bounds__(kScanThreads) void scan_m8_kernel(const ScanArgs a)
     float4* lut4 = reinterpret_cast<float4*>(smem);                         // [NG][M][256]
     const float* lutf = reinterpret_cast<const float*>(smem);
     uint4* dtab = reinterpret_cast<uint4*>(smem + (size_t)QG * M * 256 * 4);  // [256]
+    // candidate staging: survivors are appended with LDS atomics and flushed to
+    // HBM once per workgroup (one global atomic per query), see the epilogue
+    uint32_t* stg_count = reinterpret_cast<uint32_t*>(smem + (size_t)QG * M * 256 * 4 + 4096);  // [QG] (+pad)
+    uint32_t* stg_id = stg_count + 16;                                                          // [QG][kStage]
+    uint32_t* stg_code = stg_id + QG * kStage;                                                  // [QG][kStage][2]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -118,6 +123,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_m8_kernel(const ScanArgs a)
         const float4* src = reinterpret_cast<const float4*>(a.lut) + (size_t)group * (QG * M * 256 / 4);
         for (int i = tid; i < QG * M * 256 / 4; i += kScanThreads) lut4[i] = src[i];
         if (tid < 256) dtab[tid] = make_decode_entry((uint32_t)tid);
+        if (tid < 16) stg_count[tid] = 0;
     }
     __syncthreads();
 
@@ -250,16 +256,42 @@ __global__ __launch_bounds__(kScanThreads) void scan_m8_kernel(const ScanArgs a)
                             take = make_key((float)dsum, id) <= a.thr_key[slot0 + q];
                         }
                         if (take) {
-                            const uint32_t idx = atomicAdd(&a.cand_count[slot0 + q], 1u);
-                            if (idx < (uint32_t)a.cap) {
-                                const size_t o = (size_t)(slot0 + q) * a.cap + idx;
-                                a.cand_id[o] = id;
-                                a.cand_code[2 * o] = code_lo;
-                                a.cand_code[2 * o + 1] = code_hi;
+                            const uint32_t li = atomicAdd(&stg_count[q], 1u);
+                            if (li < (uint32_t)kStage) {
+                                stg_id[q * kStage + li] = id;
+                                stg_code[2 * (q * kStage + li)] = code_lo;
+                                stg_code[2 * (q * kStage + li) + 1] = code_hi;
+                            } else {  // staging full (level 0 keeps everything): straight to HBM
+                                const uint32_t idx = atomicAdd(&a.cand_count[slot0 + q], 1u);
+                                if (idx < (uint32_t)a.cap) {
+                                    const size_t o = (size_t)(slot0 + q) * a.cap + idx;
+                                    a.cand_id[o] = id;
+                                    a.cand_code[2 * o] = code_lo;
+                                    a.cand_code[2 * o + 1] = code_hi;
+                                }
                             }
                         }
                     }
                 }
+            }
+        }
+    }
+
+    // ---- epilogue: flush the staged candidates, wave w serves query w ----
+    __syncthreads();
+    for (int q = wave; q < QG; q += kScanWaves) {
+        const uint32_t n = min(stg_count[q], (uint32_t)kStage);
+        if (n == 0) continue;
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(&a.cand_count[slot0 + q], n);
+        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+        for (uint32_t i = lane; i < n; i += 64) {
+            const uint32_t idx = base + i;
+            if (idx < (uint32_t)a.cap) {
+                const size_t o = (size_t)(slot0 + q) * a.cap + idx;
+                a.cand_id[o] = stg_id[q * kStage + i];
+                a.cand_code[2 * o] = stg_code[2 * (q * kStage + i)];
+                a.cand_code[2 * o + 1] = stg_code[2 * (q * kStage + i) + 1];
             }
         }
     }
@@ -334,7 +366,9 @@ __device__ __forceinline__ int32_t report_id(uint32_t pos, int64_t n_total) {
 }
 
 __global__ __launch_bounds__(kSelectThreads) void select_kernel(const SelectArgs a) {
-    __shared__ uint64_t sel[kMaxTopK];
+    __shared__ uint64_t sel[kMaxTopK];        // winner keys
+    __shared__ uint32_t win_id[kMaxTopK];     // winner entries, staged so they can be
+    __shared__ uint32_t win_code[kMaxTopK * 2];  // compacted to the front in place
     __shared__ uint32_t hist[256];
     __shared__ uint32_t bcast[2];
     __shared__ uint32_t sel_count;
@@ -365,43 +399,66 @@ __global__ __launch_bounds__(kSelectThreads) void select_kernel(const SelectArgs
         }
         keys[i] = make_key((float)dsum, a.cand_id[o]);
     }
-    if (tid == 0) sel_count = 0;
+    if (tid == 0) {
+        sel_count = 0;
+        // candidates were dropped at some level: the final list may miss entries -> host reruns this query
+        if (cnt > (uint32_t)a.cap) a.overflow[slot] = 1u;
+    }
     __syncthreads();
 
     const int kk = min(a.top_k, n);
     uint64_t kth = ~0ull;
     if (kk > 0) kth = block_radix_select(keys, n, kk, hist, bcast, tid, kSelectThreads);
 
-    if (!a.final_pass) {
-        if (tid == 0) {
-            if (n < a.top_k) {  // not enough candidates yet: the next level keeps everything
-                a.thr_key[slot] = ~0ull;
-                a.thr_hi[slot] = INFINITY;
-                a.thr_lo[slot] = INFINITY;
-            } else {
-                const float t = __uint_as_float((uint32_t)(kth >> 32));
-                a.thr_key[slot] = kth;
-                // |fp32 sum - exact| <= 7 * 2^-24 * exact, far inside 2^-20
-                a.thr_hi[slot] = t * (1.0f + 0x1p-20f);
-                a.thr_lo[slot] = t * (1.0f - 0x1p-20f);
-            }
+    // The k-th smallest key seen so far bounds the final k-th key from above
+    // (the candidates are real nodes), so it is the next level's threshold.
+    if (tid == 0) {
+        if (n < a.top_k) {  // fewer than k nodes seen so far: keep everything
+            a.thr_key[slot] = ~0ull;
+            a.thr_hi[slot] = INFINITY;
+            a.thr_lo[slot] = INFINITY;
+        } else {
+            const float t = __uint_as_float((uint32_t)(kth >> 32));
+            a.thr_key[slot] = kth;
+            // |fp32 filter sum - exact| <= 7 * 2^-24 * exact, far inside 2^-20
+            a.thr_hi[slot] = t * (1.0f + 0x1p-20f);
+            a.thr_lo[slot] = t * (1.0f - 0x1p-20f);
         }
-        return;
     }
 
-    if (tid == 0) a.overflow[slot] = cnt > (uint32_t)a.cap ? cnt : 0u;
+    // winners = the kk keys <= kth (keys are unique: the id is part of the key)
     int p2 = 1;
     while (p2 < kk) p2 <<= 1;
-    for (int i = tid; i < p2; i += kSelectThreads) sel[i] = ~0ull;
+    if (a.final_pass)
+        for (int i = tid; i < p2; i += kSelectThreads) sel[i] = ~0ull;
     __syncthreads();
     for (int i = tid; i < n; i += kSelectThreads) {
         const uint64_t key = keys[i];
         if (key <= kth && kk > 0) {
             const uint32_t pos = atomicAdd(&sel_count, 1u);
-            if (pos < (uint32_t)kMaxTopK) sel[pos] = key;
+            if (pos < (uint32_t)kMaxTopK) {
+                sel[pos] = key;
+                if (!a.final_pass) {
+                    const size_t o = (size_t)slot * a.cap + i;
+                    win_id[pos] = a.cand_id[o];
+                    for (int w = 0; w < W && w < 2; ++w) win_code[pos * 2 + w] = a.cand_code[o * W + w];
+                }
+            }
         }
     }
     __syncthreads();
+
+    if (!a.final_pass) {
+        // carry the winners: compact them to the front; the next level appends behind
+        for (int i = tid; i < kk; i += kSelectThreads) {
+            const size_t o = (size_t)slot * a.cap + i;
+            a.cand_id[o] = win_id[i];
+            for (int w = 0; w < W && w < 2; ++w) a.cand_code[o * W + w] = win_code[i * 2 + w];
+        }
+        if (tid == 0) a.cand_count[slot] = (uint32_t)kk;
+        return;
+    }
+
     block_bitonic_sort(sel, p2, tid, kSelectThreads);
     for (int r = tid; r < a.top_k; r += kSelectThreads) {
         const size_t o = (size_t)q * a.top_k + r;
@@ -468,7 +525,11 @@ __global__ __launch_bounds__(kSelectThreads) void merge_kernel(const int32_t* __
 // launchers
 // ---------------------------------------------------------------------------
 
-size_t scan_lds_bytes(int M) { return lut_group_floats(M) * sizeof(float) + 256 * sizeof(uint4); }
+size_t scan_lds_bytes(int M) {
+    const int QG = queries_per_group(M);
+    return lut_group_floats(M) * sizeof(float) + 256 * sizeof(uint4) + 16 * sizeof(uint32_t) +
+           (size_t)QG * kStage * (1 + M / 4) * sizeof(uint32_t);
+}
 
 hipError_t launch_lut_build(const float* d_codebook, const float* d_queries, int nq, int nq_padded, int M, int K,
                             int Ds, float* d_lut, hipStream_t stream) {
@@ -482,10 +543,17 @@ hipError_t launch_scan(const ScanArgs& a, int n_slot_groups, int splits, hipStre
     if (a.img.M != 8) return hipErrorInvalidValue;
     const size_t lds = scan_lds_bytes(8);
     if (a.n_seg_pass <= 0 || n_slot_groups <= 0) return hipSuccess;
-    {   // per call: the attribute is per device and handles may live on several GPUs
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&scan_m8_kernel<16>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    {   // the attribute is per device and handles may live on several GPUs
+        static bool done[64] = {};
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
         if (e != hipSuccess) return e;
+        if (dev < 0 || dev >= 64 || !done[dev]) {
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&scan_m8_kernel<16>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+            if (dev >= 0 && dev < 64) done[dev] = true;
+        }
     }
     dim3 grid((unsigned)splits, (unsigned)n_slot_groups);
     hipLaunchKernelGGL(scan_m8_kernel<16>, grid, dim3(kScanThreads), lds, stream, a);
