@@ -76,6 +76,41 @@ SYMBOLS = [
 ]
 
 _lib = None
+_hip_runtime = None
+
+
+def _bind_hip_runtime():
+    """Load THE HIP runtime of this process with RTLD_GLOBAL before the C-ABI
+    library (which is built with -no-hip-rt and resolves hip* against it).
+    A process must not mix two runtimes: PyTorch-ROCm wheels bundle their own
+    libamdhip64.so, so when torch is installed we bind to that one (whether or
+    not torch has been imported yet); otherwise to /opt/rocm's."""
+    global _hip_runtime
+    if _hip_runtime is not None:
+        return _hip_runtime
+    import importlib.util
+    candidates = []
+    override = os.environ.get("DPQ_HIP_RUNTIME")
+    if override:
+        candidates.append(override)
+    try:
+        spec = importlib.util.find_spec("torch")
+        if spec is not None and spec.submodule_search_locations:
+            candidates.append(os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so"))
+    except (ImportError, ValueError):
+        pass
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    candidates += [os.path.join(rocm, "lib", "libamdhip64.so"), "libamdhip64.so"]
+    last = None
+    for path in candidates:
+        if os.path.isabs(path) and not os.path.exists(path):
+            continue
+        try:
+            _hip_runtime = ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+            return _hip_runtime
+        except OSError as e:
+            last = e
+    raise ImportError("cannot load a HIP runtime (libamdhip64.so): %s" % last)
 
 
 def load():
@@ -87,6 +122,7 @@ def load():
         raise ImportError(
             "%s not found: build it with `make -C deltapq_amd/csrc` (or __graft_entry__.build()); "
             "the DeltaPQ query path has no CPU fallback" % LIB_PATH)
+    _bind_hip_runtime()
     lib = ctypes.CDLL(LIB_PATH)
     for name, restype, argtypes in SYMBOLS:
         fn = getattr(lib, name)          # AttributeError if the library lacks a declared symbol

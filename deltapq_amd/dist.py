@@ -1,0 +1,60 @@
+"""Multi-GPU sharding of the query path.
+
+One process per GPU (torch.distributed; backend "nccl" is RCCL on ROCm, "gloo"
+in the CPU tests).  The index is cut into `world` contiguous DFS-position
+ranges at segment boundaries, balanced by payload bytes (done by the C-ABI
+transcoder: dpq_open_opts.shard_rank/shard_count).  Every rank answers the
+whole query batch on its shard; the only exchange is ONE all-gather of the
+per-shard partial top-k lists (nq * k * 8 bytes per rank), followed by a merge
+by (distance, id).  No all-reduce, no per-query collective.
+"""
+import numpy as np
+
+from . import api
+
+
+def shard_ranges(payload, n_codes, world, M=8, chunks_per_segment=0):
+    """[(node_lo, node_hi, algorithmic_bytes)] of every shard (host only)."""
+    out = []
+    for r in range(world):
+        soa = api.HostSoA(payload, n_codes, M, shard_rank=r, shard_count=world,
+                          chunks_per_segment=chunks_per_segment)
+        out.append((soa.info["node_lo"], soa.info["node_hi"], soa.info["algorithmic_bytes"]))
+    return out
+
+
+def gather_and_merge(ids, dists, group=None):
+    """All-gather the per-shard partial top-k lists and merge them.
+
+    ids/dists: [nq][k] torch tensors (int32 / float32) holding this rank's
+    partial result with GLOBAL DFS positions (padding rows: id -1, dist +inf).
+    CUDA tensors take the device path (RCCL all-gather + dpq_merge_topk_device),
+    CPU tensors the host path (gloo all-gather + dpq_merge_topk_host).
+    Returns (ids, dists) of the merged top-k on every rank."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1:
+        return ids, dists
+    nq, k = ids.shape
+    g_ids = torch.empty((world, nq, k), dtype=ids.dtype, device=ids.device)
+    g_dists = torch.empty((world, nq, k), dtype=dists.dtype, device=dists.device)
+    if ids.is_cuda:
+        dist.all_gather_into_tensor(g_ids, ids.contiguous(), group=group)
+        dist.all_gather_into_tensor(g_dists, dists.contiguous(), group=group)
+        return api.merge_topk_torch(g_ids, g_dists)
+    dist.all_gather(list(g_ids.unbind(0)), ids.contiguous(), group=group)
+    dist.all_gather(list(g_dists.unbind(0)), dists.contiguous(), group=group)
+    mi, md = api.merge_topk_host(g_ids.numpy(), g_dists.numpy())
+    return torch.from_numpy(mi), torch.from_numpy(md)
+
+
+def partial_topk_rows(all_ids, all_dists, k):
+    """Helper for tests: the k best (distance, id) rows of arbitrary candidate
+    arrays, padded with (-1, +inf) -- the shape a shard's partial list has."""
+    order = np.lexsort((all_ids, all_dists.view(np.uint32)))[:k]
+    ids = np.full(k, -1, dtype=np.int32)
+    dists = np.full(k, np.inf, dtype=np.float32)
+    ids[:len(order)] = all_ids[order]
+    dists[:len(order)] = all_dists[order]
+    return ids, dists

@@ -1,0 +1,66 @@
+"""The C-ABI library loads without a GPU and exports exactly what
+include/deltapq_amd.h declares (no compute calls here)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    text = open(os.path.join(ROOT, "include", "deltapq_amd.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(dpq_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_every_declared_symbol_is_exported_and_bound(lib):
+    from deltapq_amd import _lib
+    declared = header_functions()
+    bound = sorted(name for name, _, _ in _lib.SYMBOLS)
+    assert declared == bound, "header and ctypes binding disagree"
+    raw = ctypes.CDLL(_lib.LIB_PATH)        # the HIP runtime is already bound by the `lib` fixture
+    for name in declared:
+        assert hasattr(raw, name), name
+    assert lib.dpq_version() == 100
+    assert lib.dpq_strerror(0) == b"ok" and lib.dpq_strerror(-3) == b"malformed DTC stream"
+
+
+def test_struct_layouts_match_header(lib):
+    from deltapq_amd import _lib
+    assert ctypes.sizeof(_lib.OpenOpts) == 32
+    assert ctypes.sizeof(_lib.Info) == 7 * 8 + 8 * 4
+    assert ctypes.sizeof(_lib.Profile) == 3 * 8 + 8 * 8
+    assert ctypes.sizeof(_lib.DtcStats) == 3 * 8 + 16 * 8 + 2 * 4
+
+
+def test_oracle_is_not_linked_into_the_product(lib):
+    """The product library must not depend on the oracle (no CPU fallback)."""
+    from deltapq_amd import _lib
+    blob = open(_lib.LIB_PATH, "rb").read()
+    assert b"liboracle" not in blob and b"oracle_" not in blob
+    for root, _, files in os.walk(os.path.join(ROOT, "deltapq_amd")):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h")):
+                src = open(os.path.join(root, f), errors="replace").read()
+                assert "import oracle" not in src and "from oracle" not in src and "dtc_oracle" not in src, f
+
+
+def test_open_without_gpu_fails_loudly(lib):
+    from deltapq_amd import api
+    if api.device_count() > 0:
+        pytest.skip("a GPU is present")
+    from conftest import make_case
+    tree, payload, nb = make_case(100, seed=1)
+    with pytest.raises(api.DpqError) as e:
+        api.DeltaPQIndex.open_memory(payload, 100)
+    assert e.value.status == -4 and "no CPU fallback" in str(e.value)
+
+
+def test_cli_usage_without_gpu(built):
+    import subprocess
+    exe = os.path.join(ROOT, "deltapq_amd", "csrc", "deltapq")
+    r = subprocess.run([exe, "-task", "approx_tree"], capture_output=True, text=True)
+    assert r.returncode == 2 and "only -task query" in r.stdout

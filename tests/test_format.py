@@ -1,0 +1,159 @@
+"""CPU tests of the product's host code through the C-ABI: DTC validation,
+serialisation, the SoA transcoder (checked by decoding the image the way the
+GPU kernel is specified to), sharding, and the file loaders."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import make_case
+
+
+def decode_soa(soa, M=8):
+    """Decode a HostSoA image sequentially per segment: stack = checkpoint, then
+    code(i) = stack[depth-1] patched with the node's changed bytes -- the
+    semantics the scan kernel implements with pointer jumping."""
+    info = soa.info
+    S = 64 * info["chunks_per_segment"]
+    n = info["node_hi"] - info["node_lo"]
+    levels = 8 if M <= 8 else 16
+    out = np.zeros((n, M), np.uint8)
+    ck = soa.seg_ckpt.reshape(-1, levels, M)
+    for t in range(info["n_segments"]):
+        stack = ck[t].copy()
+        off = int(soa.seg_delta_off[t])
+        for j in range(S):
+            l = t * S + j
+            if l >= n:
+                break
+            nb = soa.nib[l >> 1]
+            d = (nb >> 4) if (l & 1) else (nb & 15)
+            mk = int(soa.mask[l])
+            c = stack[d - 1].copy() if d > 0 else np.zeros(M, np.uint8)
+            for m in range(M):
+                if (mk >> m) & 1:
+                    c[m] = soa.delta[off]
+                    off += 1
+            stack[d] = c
+            out[l] = c
+        assert off == int(soa.seg_delta_off[t + 1])
+    return out
+
+
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 256, 257, 5000])
+@pytest.mark.parametrize("cps", [1, 4])
+def test_transcode_is_lossless(lib, n, cps):
+    from deltapq_amd import api, synth
+    tree, payload, nb = make_case(n, seed=n)
+    codes = synth.decode_tree_codes(tree)
+    soa = api.HostSoA(payload, n, 8, chunks_per_segment=cps)
+    assert soa.info["node_lo"] == 0 and soa.info["node_hi"] == n
+    assert soa.info["algorithmic_bytes"] == nb == soa.info["n_bytes_total"]
+    assert np.array_equal(decode_soa(soa), codes)
+    # the image costs the DTC payload plus per-segment tables only
+    tables = soa.seg_delta_off.nbytes + soa.seg_ckpt.nbytes
+    pad = soa.info["n_segments"] * 64 * cps - n
+    assert soa.info["device_bytes"] - tables <= nb + 1 + 1.5 * pad + 40
+
+
+def test_c_encoder_matches_reference_layout(lib):
+    from deltapq_amd import api, synth
+    for n in (1, 2, 3, 10, 777, 778):
+        tree, payload, nb = make_case(n, seed=3 * n)
+        enc = api.dtc_encode(tree["root"], tree["depths"], tree["masks"], tree["deltas"])
+        assert np.array_equal(enc, payload)
+        n_diffs = int(synth.popcount16(tree["masks"][1:]).sum())
+        assert nb == 8 + n_diffs + (3 * (n - 1) + 1) // 2          # h:1765
+        st = api.dtc_validate(payload, n)
+        assert st["n_diffs"] == n_diffs and st["n_bytes"] == nb
+        assert st["depth_hist"][:8] == np.bincount(tree["depths"], minlength=8).tolist()
+
+
+def test_shards_partition_the_index(lib):
+    from deltapq_amd import api, dist, synth
+    n = 20000
+    tree, payload, nb = make_case(n, seed=77)
+    codes = synth.decode_tree_codes(tree)
+    for world in (2, 3, 8):
+        ranges = dist.shard_ranges(payload, n, world)
+        assert ranges[0][0] == 0 and ranges[-1][1] == n
+        for a, b in zip(ranges[:-1], ranges[1:]):
+            assert a[1] == b[0]                                     # contiguous, no gap, no overlap
+        assert sum(r[2] for r in ranges) == nb                      # every payload byte owned once
+        assert max(r[2] for r in ranges) < 1.2 * nb / world + 2000  # balanced by bytes
+        for r in range(world):
+            soa = api.HostSoA(payload, n, 8, shard_rank=r, shard_count=world)
+            lo, hi = soa.info["node_lo"], soa.info["node_hi"]
+            assert np.array_equal(decode_soa(soa), codes[lo:hi])    # shard decodes alone from its checkpoints
+
+
+def test_more_shards_than_segments(lib):
+    from deltapq_amd import dist
+    tree, payload, nb = make_case(300, seed=4)                      # 2 segments of 256
+    ranges = dist.shard_ranges(payload, 300, 8)
+    assert ranges[0][0] == 0 and ranges[-1][1] == 300
+    assert sum(hi - lo for lo, hi, _ in ranges) == 300
+    assert sum(1 for lo, hi, _ in ranges if hi > lo) <= 2           # the rest are empty shards
+
+
+def test_malformed_streams_are_rejected(lib):
+    from deltapq_amd import api
+    tree, payload, nb = make_case(1001, seed=8)
+    n = 1001
+    api.dtc_validate(payload, n)
+    cases = {}
+    bad = payload.copy(); bad[8] = (bad[8] & 0xF0) | 0x00            # node 1 at depth 0
+    cases["depth 0"] = (bad, n)
+    bad = payload.copy(); bad[8] = (bad[8] & 0xF0) | 0x03            # node 1 deeper than root+1
+    cases["depth jump"] = (bad, n)
+    cases["truncated"] = (payload[:-3].copy(), n)
+    cases["trailing garbage"] = (np.concatenate([payload, np.zeros(5, np.uint8)]), n)
+    cases["wrong n_codes"] = (payload, n + 2)
+    for name, (pl, nn) in cases.items():
+        with pytest.raises(api.DpqError) as e:
+            api.dtc_validate(pl, nn)
+        assert e.value.status == -3, name                            # DPQ_ERR_FORMAT
+        with pytest.raises(api.DpqError):
+            api.HostSoA(pl, nn)
+    with pytest.raises(api.DpqError) as e:
+        api.dtc_validate(payload, 0)
+    assert e.value.status == -1                                      # DPQ_ERR_ARG
+
+
+def test_loaders_match_oracle_loaders(lib, oracle, tmp_path, codebook):
+    """pq.cpp:288-312 and utils.cpp:14-110 through the product and through the oracle."""
+    from deltapq_amd import api, synth
+    d = str(tmp_path)
+    tree, cb_rt, queries = synth.make_dataset_dir(d, 500, 7, seed=3, ext="fvecs")
+    cw = os.path.join(d, "M8K256codewords.txt")
+    a, b = api.read_codewords(cw), oracle.read_codewords(cw)
+    assert a.shape == (8, 256, 16) and np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    assert np.array_equal(a, cb_rt)
+    qa, qb = api.read_vecs(os.path.join(d, "query.fvecs"), "fvecs"), oracle.read_vecs(os.path.join(d, "query.fvecs"), "fvecs")
+    assert np.array_equal(qa, qb) and np.array_equal(qa, queries)
+    assert api.read_vecs(os.path.join(d, "query.fvecs"), "fvecs", top_n=3).shape == (3, 128)
+    synth.write_bvecs(os.path.join(d, "query.bvecs"), queries.astype(np.uint8))
+    qc = api.read_vecs(os.path.join(d, "query.bvecs"), "bvecs")
+    assert np.array_equal(qc, oracle.read_vecs(os.path.join(d, "query.bvecs"), "bvecs"))
+    assert np.array_equal(qc, queries)                               # integer-valued SIFT-like queries
+    n_codes, payload = api.read_dtc_file(synth.dtc_file_name(d, 8, 256, 500))
+    assert n_codes == 500 and np.array_equal(payload, synth.encode_dtc(tree)[0])
+    with pytest.raises(api.DpqError) as e:
+        api.read_codewords(os.path.join(d, "missing.txt"))
+    assert e.value.status == -2                                      # DPQ_ERR_IO
+
+
+def test_merge_topk_host(lib):
+    from deltapq_amd import api
+    rng = np.random.default_rng(0)
+    nq, k, L = 5, 7, 3
+    d = np.sort(rng.integers(0, 20, size=(L, nq, k)).astype(np.float32), axis=2)   # many ties across lists
+    ids = rng.permutation(L * nq * k).reshape(L, nq, k).astype(np.int32)
+    ids[2, :, 5:] = -1
+    d[2, :, 5:] = np.inf
+    mi, md = api.merge_topk_host(ids, d)
+    for q in range(nq):
+        cand = [(d[l, q, r], ids[l, q, r]) for l in range(L) for r in range(k) if ids[l, q, r] >= 0]
+        cand.sort()
+        assert [c[1] for c in cand[:k]] == mi[q].tolist()
+        assert [c[0] for c in cand[:k]] == md[q].tolist()

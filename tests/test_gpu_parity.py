@@ -1,0 +1,266 @@
+"""GPU parity tests: the HIP path, called through the C-ABI, against the oracle
+on the same seeded inputs.  Bar: ids bit-exact up to exact-distance ties
+(tie-aware comparator), fp32 distances BIT-equal (the north star
+allows 1e-5 relative; we hold the stronger bar)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import assert_parity, make_case, oracle_topk
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture(scope="module")
+def gpu(lib):
+    from deltapq_amd import api
+    if api.device_count() < 1:
+        pytest.fail("no GPU visible: the HIP path is the product and must be what runs here")
+    return api
+
+
+def run(gpu, payload, n, cb, qs, k, **kw):
+    with gpu.DeltaPQIndex.open_memory(payload, n, 8, 256, **kw) as idx:
+        idx.set_codebook(cb)
+        idx.profile_enable(True)
+        ids, dists = idx.query_batch(qs, k)
+        prof = idx.profile_read()
+        info = idx.info()
+    return ids, dists, prof, info
+
+
+@pytest.mark.parametrize("name", ["small_even", "small_odd", "dup_heavy"])
+def test_golden_vectors(gpu, name):
+    """Committed fixtures (tests/golden/make_golden.py): ids as multisets per tie group, distance bits exact."""
+    from oracle.dtc_oracle import tie_aware_equal
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    n, k = int(g["n_codes"]), int(g["top_k"])
+    ids, dists, _, _ = run(gpu, g["payload"], n, g["codebook"], g["queries"], k)
+    for i in range(len(g["queries"])):
+        ok, msg = tie_aware_equal(ids[i], dists[i], g["ids"][i], g["dist_bits"][i].view(np.float32))
+        assert ok, msg
+
+
+# (n_codes, n_queries, top_k, chunks_per_segment)
+SHAPES = [
+    (1, 3, 1, 4), (2, 3, 2, 4), (3, 2, 3, 1), (63, 4, 10, 1), (64, 4, 64, 1), (65, 5, 10, 1),
+    (1000, 20, 10, 4), (10000, 100, 10, 4),          # BASELINE configs[0] shape: siftsmall, 100 queries, topk 10
+    (9999, 33, 100, 2), (10000, 17, 1000, 4), (4097, 5, 2048, 4), (100000, 64, 100, 4), (300001, 40, 100, 16),
+]
+
+
+@pytest.mark.parametrize("n,nq,k,cps", SHAPES)
+def test_parity_with_oracle(gpu, oracle, codebook, n, nq, k, cps):
+    from deltapq_amd import synth
+    tree, payload, nb = make_case(n, seed=n + 7)
+    qs = synth.make_queries(nq, 128, seed=n + 8)
+    ids, dists, prof, info = run(gpu, payload, n, codebook, qs, k, chunks_per_segment=cps)
+    assert info["algorithmic_bytes"] == nb and info["node_hi"] == n
+    assert_parity(ids, dists, oracle_topk(oracle, payload, n, codebook, qs, k), n)
+    if n % 2 == 0 and k == n:
+        assert n in ids[0] and (n - 1) not in ids[0]              # even-N quirk (h:2949, 2970)
+
+
+def test_duplicate_heavy_ties(gpu, oracle, codebook):
+    """Zero-diff children are exact duplicates: equal-distance groups everywhere, also at the k-th boundary."""
+    from deltapq_amd import synth
+    n = 50000
+    tree, payload, _ = make_case(n, seed=5, dup_heavy=True)
+    codes = synth.decode_tree_codes(tree)
+    assert len(np.unique(codes, axis=0)) < 0.8 * n
+    qs = synth.make_queries(24, 128, seed=6)
+    for k in (1, 10, 100):
+        ids, dists, _, _ = run(gpu, payload, n, codebook, qs, k)
+        assert_parity(ids, dists, oracle_topk(oracle, payload, n, codebook, qs, k), n)
+        # canonical tie order of this implementation: ascending id inside equal distances
+        for r in range(len(qs)):
+            key = dists[r].view(np.uint32).astype(np.uint64) << np.uint64(32) | ids[r].astype(np.uint64)
+            assert np.all(np.diff(key.astype(np.float64)) >= 0) and len(set(ids[r].tolist())) == k
+
+
+def test_query_equal_to_a_centroid_gives_zero_entries(gpu, oracle, codebook):
+    """LUT arithmetic at the exact-zero corner and with fractional codebooks (a3)."""
+    rng = np.random.default_rng(3)
+    cb = rng.normal(40, 25, size=(8, 256, 16)).astype(np.float32)
+    n = 4000
+    tree, payload, _ = make_case(n, seed=12)
+    qs = np.stack([cb[np.arange(8), rng.integers(0, 256, 8)].reshape(-1) for _ in range(6)]).astype(np.float32)
+    qs[3:] += rng.normal(0, 1e-3, size=qs[3:].shape).astype(np.float32)
+    ids, dists, _, _ = run(gpu, payload, n, cb, qs, 20)
+    assert_parity(ids, dists, oracle_topk(oracle, payload, n, cb, qs, 20), n)
+
+
+def test_candidate_overflow_is_recovered(gpu, oracle, codebook):
+    """A tiny candidate buffer forces the overflow rerun path; results must not change."""
+    from deltapq_amd import synth
+    n = 60000
+    tree, payload, _ = make_case(n, seed=21)
+    qs = synth.make_queries(40, 128, seed=22)
+    ids, dists, prof, _ = run(gpu, payload, n, codebook, qs, 50, cand_capacity=64)
+    assert prof["overflow_reruns"] > 0
+    assert_parity(ids, dists, oracle_topk(oracle, payload, n, codebook, qs, 50), n)
+
+
+def test_large_batch_is_split_internally(gpu, oracle, codebook):
+    from deltapq_amd import synth
+    n = 3000
+    tree, payload, _ = make_case(n, seed=31)
+    qs = synth.make_queries(2500, 128, seed=32)                  # > 2048: two internal sub-batches
+    ids, dists, _, _ = run(gpu, payload, n, codebook, qs, 5)
+    sel = [0, 1, 2047, 2048, 2049, 2499]
+    ref = oracle_topk(oracle, payload, n, codebook, qs[sel], 5)
+    assert_parity(ids[sel], dists[sel], ref, n)
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_sharded_index_merges_to_the_same_answer(gpu, oracle, codebook, world):
+    """8e: shards are independent (own checkpoints), report global DFS positions, host merge."""
+    from deltapq_amd import synth
+    n, nq, k = 40000, 12, 100
+    tree, payload, _ = make_case(n, seed=41)
+    qs = synth.make_queries(nq, 128, seed=42)
+    pi, pd, covered = [], [], 0
+    for r in range(world):
+        ids, dists, _, info = run(gpu, payload, n, codebook, qs, k, shard_rank=r, shard_count=world)
+        ok = ids >= 0
+        rep_lo, rep_hi = info["node_lo"], info["node_hi"] + (1 if info["node_hi"] == n and n % 2 == 0 else 0)
+        assert np.all((ids[ok] >= rep_lo) & (ids[ok] < rep_hi))
+        covered += info["node_hi"] - info["node_lo"]
+        pi.append(ids)
+        pd.append(dists)
+    assert covered == n
+    mi, md = gpu.merge_topk_host(np.stack(pi), np.stack(pd))
+    assert_parity(mi, md, oracle_topk(oracle, payload, n, codebook, qs, k), n)
+
+
+def test_shard_smaller_than_topk_pads(gpu, oracle, codebook):
+    from deltapq_amd import synth
+    n, k = 300, 200                                               # 2 segments, 4 shards: two are empty
+    tree, payload, _ = make_case(n, seed=51)
+    qs = synth.make_queries(3, 128, seed=52)
+    pi, pd = [], []
+    for r in range(4):
+        ids, dists, _, info = run(gpu, payload, n, codebook, qs, k, shard_rank=r, shard_count=4)
+        held = info["node_hi"] - info["node_lo"]
+        assert np.all((ids >= 0).sum(axis=1) == min(k, held))
+        assert np.all(np.isinf(dists[ids < 0]))
+        pi.append(ids)
+        pd.append(dists)
+    mi, md = gpu.merge_topk_host(np.stack(pi), np.stack(pd))
+    assert_parity(mi, md, oracle_topk(oracle, payload, n, codebook, qs, k), n)
+
+
+def test_device_pointer_entry_and_device_merge(gpu, oracle, codebook):
+    import torch
+    from deltapq_amd import synth
+    n, nq, k = 30000, 20, 64
+    tree, payload, _ = make_case(n, seed=61)
+    qs = synth.make_queries(nq, 128, seed=62)
+    qd = torch.from_numpy(qs).cuda()
+    torch.cuda.synchronize()
+    parts_i, parts_d = [], []
+    side = torch.cuda.Stream()                                     # a non-default stream of torch's runtime:
+    with torch.cuda.stream(side):                                  # library and torch must share ONE HIP runtime
+        for r in range(2):
+            with gpu.DeltaPQIndex.open_memory(payload, n, 8, 256, shard_rank=r, shard_count=2) as idx:
+                idx.set_codebook(codebook)
+                i, d = idx.query_batch_torch(qd, k)
+                parts_i.append(i.clone())
+                parts_d.append(d.clone())
+        mi, md = gpu.merge_topk_torch(torch.stack(parts_i).contiguous(), torch.stack(parts_d).contiguous())
+    side.synchronize()
+    assert_parity(mi.cpu().numpy(), md.cpu().numpy(), oracle_topk(oracle, payload, n, codebook, qs, k), n)
+
+
+def test_error_codes(gpu, codebook):
+    from deltapq_amd import synth
+    tree, payload, _ = make_case(500, seed=71)
+    qs = synth.make_queries(2, 128, seed=72)
+    with gpu.DeltaPQIndex.open_memory(payload, 500, 8, 256) as idx:
+        with pytest.raises(gpu.DpqError) as e:
+            idx.query_batch(qs, 5)
+        assert e.value.status == -7                                # DPQ_ERR_STATE: no codebook yet
+        idx.set_codebook(codebook)
+        with pytest.raises(gpu.DpqError) as e:
+            idx.query_batch(qs, 501)
+        assert e.value.status == -8                                # DPQ_ERR_TOPK (reference: empty-heap pop)
+        with pytest.raises(gpu.DpqError) as e:
+            idx.query_batch(qs, 0)
+        assert e.value.status == -1
+        ids, _ = idx.query_batch(qs, 500)
+        assert sorted(ids[0].tolist()) == list(range(499)) + [500]   # even N
+    with pytest.raises(gpu.DpqError) as e:
+        gpu.DeltaPQIndex.open_memory(payload[:-1], 500, 8, 256)
+    assert e.value.status == -3
+
+
+def test_reference_named_entry_points(gpu, oracle, codebook, tmp_path):
+    """One call per query with the reference's argument lists (h:2805-2810, 3731-3736)."""
+    from deltapq_amd import synth
+    d = str(tmp_path)
+    tree, cb, queries = synth.make_dataset_dir(d, 2001, 3, seed=81)
+    n_codes, payload = gpu.read_dtc_file(synth.dtc_file_name(d, 8, 256, 2001))
+    for q in queries:
+        ref = oracle_topk(oracle, payload, 2001, cb, [q], 10)
+        a = gpu.query_processing_scan_compressed_codes_opt_in_memory(payload, len(payload), q, 10, 8, 256, 16, 2001, cb)
+        b = gpu.query_processing_scan_compressed_codes_opt_o_direct(d, q, 10, 8, 256, 16, 2001, cb)
+        for res in (a, b):
+            ids = np.array([[r[0] for r in res]], np.int32)
+            dd = np.array([[r[1] for r in res]], np.float32)
+            assert_parity(ids, dd, ref, 2001)
+
+
+def test_cli_query_matches_oracle(gpu, oracle, tmp_path):
+    """`deltapq -task query` with the reference's flags on a reference-style dataset directory."""
+    from deltapq_amd import synth
+    d = str(tmp_path)
+    n, nq, k = 10000, 100, 10                                     # BASELINE configs[0]
+    tree, cb, queries = synth.make_dataset_dir(d, n, nq, seed=91)
+    n_codes, payload = gpu.read_dtc_file(synth.dtc_file_name(d, 8, 256, n))
+    exe = os.path.join(ROOT, "deltapq_amd", "csrc", "deltapq")
+    out = os.path.join(d, "results.bin")
+    for task in ("query", "query_im"):
+        r = subprocess.run([exe, "-dataset", d, "-task", task, "-m", "8", "-k", "256", "-h", "1", "-diff", "8",
+                            "-N", str(n), "-query_size", "50", "-topk", str(k), "-debug", "-out", out],
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert "[msec/query]" in r.stdout and "50 queries run" in r.stdout
+        raw = np.fromfile(out, dtype=np.uint8)
+        nq_out, k_out = np.frombuffer(raw[:16], np.int64)
+        assert (nq_out, k_out) == (50, k)
+        ids = np.frombuffer(raw[16:16 + 50 * k * 4], np.int32).reshape(50, k)
+        dists = np.frombuffer(raw[16 + 50 * k * 4:], np.float32).reshape(50, k)
+        assert_parity(ids, dists, oracle_topk(oracle, payload, n, cb, queries[:50], k), n)
+        # -debug prints "<top1 id> <top1 dist>" per query (main:340-343)
+        top1 = [l.split() for l in r.stdout.splitlines() if len(l.split()) == 2 and l.split()[0].lstrip("-").isdigit()]
+        assert [int(t[0]) for t in top1[-50:]] == ids[:, 0].tolist()
+
+
+def test_full_size_sift1m_shape(gpu, oracle, codebook):
+    """BASELINE configs[1] at full size: 1M codes, top-100.  Full oracle parity on a
+    query sample plus size-independent properties on the whole batch."""
+    from deltapq_amd import synth
+    n, nq, k = 1_000_000, 256, 100
+    tree = synth.synth_tree(n, 8, seed=102, mean_diffs=3.0)
+    payload, nb = synth.encode_dtc(tree)
+    qs = synth.make_queries(nq, 128, seed=101)
+    ids, dists, prof, info = run(gpu, payload, n, codebook, qs, k)
+    assert info["algorithmic_bytes"] == nb
+    sample = list(range(0, nq, 16))
+    assert_parity(ids[sample], dists[sample], oracle_topk(oracle, payload, n, codebook, qs[sample], k), n)
+    # properties for every query: ascending, unique ids in range, distance == fp64 sum over the decoded code
+    lut0 = oracle.build_lut(codebook, qs[1])
+    _, _, _, codes = oracle.scan_lut(payload, n, lut0, 1, want_all=True)
+    assert np.all(np.diff(dists, axis=1) >= 0)
+    for r in range(nq):
+        assert len(set(ids[r].tolist())) == k and ids[r].min() >= 0 and ids[r].max() <= n
+        lut = oracle.build_lut(codebook, qs[r])
+        pos = np.where(ids[r] == n, n - 1, ids[r])
+        s = sum(lut[m, codes[pos, m]].astype(np.float64) for m in range(8)).astype(np.float32)
+        assert np.array_equal(s.view(np.uint32), dists[r].view(np.uint32))
+    # every node scanned exactly once per query by the cascade
+    assert prof["scan_node_query_pairs"] == info["n_segments"] * 64 * info["chunks_per_segment"] * nq
