@@ -116,18 +116,13 @@ def main():
     nq, k = args.queries, args.topk
     ids = torch.empty((nq, k), dtype=torch.int32, device=dev)
     dists = torch.empty((nq, k), dtype=torch.float32, device=dev)
-    if world > 1:
-        g_ids = torch.empty((world, nq, k), dtype=torch.int32, device=dev)
-        g_dists = torch.empty((world, nq, k), dtype=torch.float32, device=dev)
+    from deltapq_amd import dist as dpq_dist
 
     def step():
         idx.query_batch_torch(q_dev, k, ids, dists)
-        if world > 1:
-            # the path's one exchange step: gather the candidate lists (nq*k*8 B per rank)
-            dist.all_gather_into_tensor(g_ids, ids)
-            dist.all_gather_into_tensor(g_dists, dists)
-            return api.merge_topk_torch(g_ids, g_dists)
-        return ids, dists
+        # N > 1: the path's one exchange step -- all-gather of the partial lists
+        # (nq*k*8 B per rank) over RCCL, then the device merge
+        return dpq_dist.gather_and_merge(ids, dists)
 
     def sync():
         if world > 1:
