@@ -70,21 +70,22 @@ struct dpq_index {
     float* d_codebook = nullptr;
     // workspace, sized for ws_slots padded queries and ws_cap candidates each
     int ws_slots = 0, ws_cap = 0;
-    float* d_lut = nullptr;
+    float* d_lut32 = nullptr;       // exact tables [query][8][256]
+    float* d_lut_min = nullptr;     // [query][8] minima (filter quantisation in the scan prologue)
     uint32_t *d_cand_count = nullptr, *d_cand_id = nullptr, *d_cand_code = nullptr, *d_overflow = nullptr;
     uint64_t *d_keys = nullptr, *d_thr_key = nullptr;
-    float *d_thr_hi = nullptr, *d_thr_lo = nullptr;
     uint32_t* h_overflow = nullptr;  // pinned
     // staging for the host-pointer entry point
     float* d_q_stage = nullptr;
     int32_t* d_ids_stage = nullptr;
     float* d_dists_stage = nullptr;
     size_t q_stage_floats = 0, out_stage_elems = 0;
-    // cascade plan cache
+    // cascade plan: visiting order of the segments, level bounds, decoded level 0
     int plan_top_k = -1, plan_cap = -1;
     std::vector<int> level_off, level_cnt;
-    uint32_t* d_seg_lists = nullptr;
-    size_t seg_lists_cap = 0;
+    uint32_t* d_order = nullptr;
+    uint32_t *d_l0_id = nullptr, *d_l0_code = nullptr;
+    int l0_segments = 0;
     // profiling
     bool prof = false;
     std::vector<EventPair> events;
@@ -105,19 +106,18 @@ struct dpq_index {
 namespace {
 
 void free_workspace(dpq_index* x) {
-    hipFree(x->d_lut);
+    hipFree(x->d_lut32);
+    hipFree(x->d_lut_min);
     hipFree(x->d_cand_count);
     hipFree(x->d_cand_id);
     hipFree(x->d_cand_code);
     hipFree(x->d_overflow);
     hipFree(x->d_keys);
     hipFree(x->d_thr_key);
-    hipFree(x->d_thr_hi);
-    hipFree(x->d_thr_lo);
-    x->d_lut = nullptr;
+    x->d_lut32 = nullptr;
+    x->d_lut_min = nullptr;
     x->d_cand_count = x->d_cand_id = x->d_cand_code = x->d_overflow = nullptr;
     x->d_keys = x->d_thr_key = nullptr;
-    x->d_thr_hi = x->d_thr_lo = nullptr;
     x->ws_slots = x->ws_cap = 0;
 }
 
@@ -126,17 +126,15 @@ int ensure_workspace(dpq_index* x, int slots, int cap) {
     slots = std::max(slots, x->ws_slots);
     cap = std::max(cap, x->ws_cap);
     free_workspace(x);
-    const size_t W = (size_t)x->M / 4;
     int rc;
-    if ((rc = dev_alloc(&x->d_lut, (size_t)slots * x->M * 256))) return rc;
+    if ((rc = dev_alloc(&x->d_lut32, (size_t)slots * 2048))) return rc;
+    if ((rc = dev_alloc(&x->d_lut_min, (size_t)slots * 8))) return rc;
     if ((rc = dev_alloc(&x->d_cand_count, (size_t)slots))) return rc;
     if ((rc = dev_alloc(&x->d_cand_id, (size_t)slots * cap))) return rc;
-    if ((rc = dev_alloc(&x->d_cand_code, (size_t)slots * cap * W))) return rc;
+    if ((rc = dev_alloc(&x->d_cand_code, (size_t)slots * cap * 2))) return rc;
     if ((rc = dev_alloc(&x->d_overflow, (size_t)slots))) return rc;
     if ((rc = dev_alloc(&x->d_keys, (size_t)slots * cap))) return rc;
     if ((rc = dev_alloc(&x->d_thr_key, (size_t)slots))) return rc;
-    if ((rc = dev_alloc(&x->d_thr_hi, (size_t)slots))) return rc;
-    if ((rc = dev_alloc(&x->d_thr_lo, (size_t)slots))) return rc;
     if (!x->h_overflow) DPQ_HIP(hipHostMalloc(reinterpret_cast<void**>(&x->h_overflow), sizeof(uint32_t) * 4096));
     x->ws_slots = slots;
     x->ws_cap = cap;
@@ -146,17 +144,16 @@ int ensure_workspace(dpq_index* x, int slots, int cap) {
 int auto_cap(int top_k) { return std::max(4096, 32 * top_k); }
 
 // Progressive cascade plan.  Segments are visited in a low-discrepancy order
-// (so every prefix is a spread-out sample of the DFS stream); level l scans
+// (so every prefix is a spread-out sample of the DFS stream); level l covers
 // order[bound[l-1] : bound[l]] -- every segment exactly once over the whole
-// cascade -- with the threshold set to the k-th best key of everything seen
-// before.  Expected survivors of a level = top_k * (bound[l]/bound[l-1] - 1).
+// cascade.  Level 0 (<= 4096 nodes) is query independent: its segments are
+// decoded once here and every query evaluates that list exactly.  Later levels
+// are filter scans; expected survivors of level l = top_k * (bound[l]/bound[l-1] - 1).
 int ensure_plan(dpq_index* x, int top_k, int cap) {
     if (x->plan_top_k == top_k && x->plan_cap == cap) return DPQ_OK;
     const int64_t S = (int64_t)dpq::kChunk * x->img.chunks_per_segment;
     const int64_t nseg = x->img.n_segments;
-    // level 0 keeps every node it sees: at least 2*top_k nodes, at most `cap`
-    int64_t s0 = (std::max<int64_t>(1024, 2 * (int64_t)top_k) + S - 1) / S;
-    s0 = std::max<int64_t>(1, std::min<int64_t>(s0, std::max<int64_t>(1, cap / S)));
+    const int64_t s0 = std::min<int64_t>(nseg, std::max<int64_t>(1, dpq::kSortMax / S));
     std::vector<int64_t> bounds;
     if (s0 >= nseg) {
         bounds.push_back(nseg);
@@ -181,16 +178,27 @@ int ensure_plan(dpq_index* x, int top_k, int cap) {
         x->level_cnt.push_back((int)(bnd - prev));
         prev = bnd;
     }
-    if (!x->d_seg_lists && nseg > 0) {
+    if (!x->d_order && nseg > 0) {
         // order[j] = j * P mod nseg, P ~ nseg / golden ratio, gcd(P, nseg) = 1
         std::vector<uint32_t> order((size_t)nseg);
         int64_t P = std::max<int64_t>(1, (int64_t)((double)nseg * 0.6180339887498949));
         auto gcd = [](int64_t a, int64_t b) { while (b) { int64_t t = a % b; a = b; b = t; } return a; };
         while (gcd(P, nseg) != 1) ++P;
         for (int64_t j = 0; j < nseg; ++j) order[(size_t)j] = (uint32_t)((j * P) % nseg);
-        int rc = dev_alloc(&x->d_seg_lists, (size_t)nseg);
+        int rc = dev_alloc(&x->d_order, (size_t)nseg);
         if (rc) return rc;
-        DPQ_HIP(hipMemcpy(x->d_seg_lists, order.data(), (size_t)nseg * sizeof(uint32_t), hipMemcpyHostToDevice));
+        DPQ_HIP(hipMemcpy(x->d_order, order.data(), (size_t)nseg * sizeof(uint32_t), hipMemcpyHostToDevice));
+    }
+    if (nseg > 0 && x->l0_segments != (int)s0) {
+        hipFree(x->d_l0_id);
+        hipFree(x->d_l0_code);
+        x->d_l0_id = x->d_l0_code = nullptr;
+        int rc = dev_alloc(&x->d_l0_id, (size_t)(s0 * S));
+        if (!rc) rc = dev_alloc(&x->d_l0_code, (size_t)(s0 * S * 2));
+        if (rc) return rc;
+        DPQ_HIP(dpq::launch_decode_segments(x->img, x->d_order, (int)s0, x->d_l0_id, x->d_l0_code, nullptr));
+        DPQ_HIP(hipStreamSynchronize(nullptr));
+        x->l0_segments = (int)s0;
     }
     x->plan_top_k = top_k;
     x->plan_cap = cap;
@@ -220,17 +228,18 @@ struct Timer {
 };
 
 int splits_for(int n_seg_pass, int n_groups) {
-    // One workgroup per CU is resident (LDS), so aim at a whole number of
-    // chip-waves: <= 2 x 256 workgroups, and no more waves than segments.
+    // One workgroup per CU is resident (LDS) and each pays a table-building
+    // prologue, so aim at ONE chip-wave: <= 256 workgroups, and no more waves
+    // than segments.
     const int by_work = (n_seg_pass + dpq::kScanWaves - 1) / dpq::kScanWaves;
-    const int want = std::max(1, 512 / std::max(1, n_groups));
+    const int want = std::max(1, 256 / std::max(1, n_groups));
     return std::max(1, std::min(by_work, want));
 }
 
 // One sub-batch (nq <= kMaxBatchQueries) end to end on `stream`.
 int run_batch(dpq_index* x, const float* d_queries, int nq, int top_k, int32_t* d_ids, float* d_dists,
               hipStream_t stream) {
-    const int QG = dpq::queries_per_group(x->M);
+    const int QG = dpq::kQG;
     const int nqp = (nq + QG - 1) / QG * QG;
     const int ngroups = nqp / QG;
     const int cap = x->cap_auto ? auto_cap(top_k) : std::max(x->cap, top_k);
@@ -240,18 +249,20 @@ int run_batch(dpq_index* x, const float* d_queries, int nq, int top_k, int32_t* 
 
     {
         Timer t(x, stream, 0);
-        DPQ_HIP(dpq::launch_lut_build(x->d_codebook, d_queries, nq, nqp, x->M, x->K, x->Ds, x->d_lut, stream));
+        DPQ_HIP(dpq::launch_lut_build(x->d_codebook, d_queries, nq, x->M, x->K, x->Ds, x->d_lut32, x->d_lut_min,
+                                      stream));
     }
     if (x->prof) x->prof_acc.lut_launches++;
-    DPQ_HIP(dpq::launch_init_thresholds(x->d_thr_key, x->d_thr_hi, x->d_thr_lo, nqp, nq, stream));
+    DPQ_HIP(hipMemsetAsync(x->d_cand_count, 0, sizeof(uint32_t) * nqp, stream));
+    DPQ_HIP(hipMemsetAsync(x->d_overflow, 0, sizeof(uint32_t) * nqp, stream));
 
     dpq::ScanArgs sa{};
     sa.img = x->img;
-    sa.lut = x->d_lut;
-    sa.group_list = nullptr;
-    sa.thr_hi = x->d_thr_hi;
-    sa.thr_lo = x->d_thr_lo;
+    sa.lut32 = x->d_lut32;
+    sa.lut_min = x->d_lut_min;
     sa.thr_key = x->d_thr_key;
+    sa.slot_query = nullptr;
+    sa.n_queries = nq;
     sa.cand_count = x->d_cand_count;
     sa.cand_id = x->d_cand_id;
     sa.cand_code = x->d_cand_code;
@@ -262,24 +273,18 @@ int run_batch(dpq_index* x, const float* d_queries, int nq, int top_k, int32_t* 
     se.cand_id = x->d_cand_id;
     se.cand_code = x->d_cand_code;
     se.cap = cap;
-    se.lut = x->d_lut;
+    se.lut32 = x->d_lut32;
     se.slot_query = nullptr;
     se.keys = x->d_keys;
-    se.M = x->M;
     se.top_k = top_k;
     se.thr_key = x->d_thr_key;
-    se.thr_hi = x->d_thr_hi;
-    se.thr_lo = x->d_thr_lo;
     se.overflow = x->d_overflow;
     se.out_ids = d_ids;
     se.out_dists = d_dists;
     se.n_codes_total = x->img.n_codes_total;
-    se.n_local = x->img.n_local;
 
     const int64_t S = (int64_t)dpq::kChunk * x->img.chunks_per_segment;
     const size_t n_levels = x->img.n_segments > 0 ? x->level_cnt.size() : 0;
-    DPQ_HIP(hipMemsetAsync(x->d_cand_count, 0, sizeof(uint32_t) * nqp, stream));
-    DPQ_HIP(hipMemsetAsync(x->d_overflow, 0, sizeof(uint32_t) * nqp, stream));
     if (n_levels == 0) {  // empty shard: every row is padding
         se.final_pass = 1;
         DPQ_HIP(dpq::launch_select(se, nq, stream));
@@ -287,19 +292,29 @@ int run_batch(dpq_index* x, const float* d_queries, int nq, int top_k, int32_t* 
     }
     for (size_t l = 0; l < n_levels; ++l) {
         const bool final_pass = l + 1 == n_levels;
-        // level l appends behind the winners the previous select carried over
-        sa.seg_list = n_levels == 1 ? nullptr : x->d_seg_lists + x->level_off[l];
-        sa.n_seg_pass = x->level_cnt[l];
-        {
-            Timer t(x, stream, 1);
-            DPQ_HIP(dpq::launch_scan(sa, ngroups, splits_for(sa.n_seg_pass, ngroups), stream));
+        if (l == 0) {
+            // level 0: the pre-decoded, query-independent list; every query evaluates it exactly
+            se.shared_id = x->d_l0_id;
+            se.shared_code = x->d_l0_code;
+            se.shared_n = (int)(x->level_cnt[0] * S);
+        } else {
+            se.shared_id = nullptr;
+            se.shared_code = nullptr;
+            se.shared_n = 0;
+            // filter scan of the next slice of segments; appends behind the carried winners
+            sa.seg_list = x->d_order + x->level_off[l];
+            sa.n_seg_pass = x->level_cnt[l];
+            {
+                Timer t(x, stream, 1);
+                DPQ_HIP(dpq::launch_scan(sa, ngroups, splits_for(sa.n_seg_pass, ngroups), stream));
+            }
+            if (x->prof) {
+                x->prof_acc.scan_launches++;
+                x->prof_acc.scan_stream_bytes +=
+                    (int64_t)((double)x->info.device_bytes * sa.n_seg_pass / std::max(1, x->img.n_segments));
+            }
         }
-        if (x->prof) {
-            x->prof_acc.scan_launches++;
-            x->prof_acc.scan_node_query_pairs += (int64_t)sa.n_seg_pass * S * nq;
-            x->prof_acc.scan_stream_bytes +=
-                (int64_t)((double)x->info.device_bytes * sa.n_seg_pass / std::max(1, x->img.n_segments));
-        }
+        if (x->prof) x->prof_acc.scan_node_query_pairs += (int64_t)x->level_cnt[l] * S * nq;
         se.final_pass = final_pass ? 1 : 0;
         {
             Timer t(x, stream, 2);
@@ -321,80 +336,55 @@ int run_batch(dpq_index* x, const float* d_queries, int nq, int top_k, int32_t* 
     }
     if (over.empty()) return DPQ_OK;
 
-    // Rerun the affected LUT groups over the whole shard in ONE level.  The k-th
-    // key of the incomplete list is still a valid upper bound (its entries are
-    // real nodes), and it is tight, so the number of nodes under it is about
+    // Rerun the affected queries over the whole shard in ONE filter level.  The
+    // k-th key of the incomplete list is still a valid upper bound (its entries
+    // are real nodes) and it is tight, so the number of nodes under it is about
     // top_k; grow the buffer and repeat in the (pathological) case it is not.
-    std::vector<int> groups;
-    for (int q : over) {
-        int g = q / QG;
-        if (groups.empty() || groups.back() != g) groups.push_back(g);
-    }
-    const int ng2 = (int)groups.size();
-    const int slots2 = ng2 * QG;
+    const int slots2 = ((int)over.size() + QG - 1) / QG * QG;
+    const int ng2 = slots2 / QG;
     std::vector<int32_t> slot_query((size_t)slots2, -1);
-    std::vector<uint64_t> h_key((size_t)nqp), k2((size_t)slots2, 0);
-    std::vector<float> h_hi((size_t)nqp), h_lo((size_t)nqp), hi2((size_t)slots2, -1.0f), lo2((size_t)slots2, -1.0f);
+    std::vector<uint64_t> h_key((size_t)nqp), k2((size_t)slots2, ~0ull);
     DPQ_HIP(hipMemcpy(h_key.data(), x->d_thr_key, sizeof(uint64_t) * nqp, hipMemcpyDeviceToHost));
-    DPQ_HIP(hipMemcpy(h_hi.data(), x->d_thr_hi, sizeof(float) * nqp, hipMemcpyDeviceToHost));
-    DPQ_HIP(hipMemcpy(h_lo.data(), x->d_thr_lo, sizeof(float) * nqp, hipMemcpyDeviceToHost));
-    for (int g = 0; g < ng2; ++g)
-        for (int i = 0; i < QG; ++i) {
-            const int q = groups[g] * QG + i;
-            const size_t s = (size_t)g * QG + i;
-            if (q < nq && std::binary_search(over.begin(), over.end(), q)) {
-                slot_query[s] = q;
-                k2[s] = h_key[q];
-                hi2[s] = h_hi[q];
-                lo2[s] = h_lo[q];
-            }
-        }
-    const size_t W = (size_t)x->M / 4;
+    for (size_t i = 0; i < over.size(); ++i) {
+        slot_query[i] = over[i];
+        k2[i] = h_key[(size_t)over[i]];
+    }
     int64_t cap2 = std::max(cap, 8 * top_k);
     for (int attempt = 0;; ++attempt) {
-        int32_t *d_groups = nullptr, *d_slot_query = nullptr;
+        int32_t* d_slot_query = nullptr;
         uint32_t *c_count = nullptr, *c_id = nullptr, *c_code = nullptr, *c_over = nullptr;
         uint64_t *c_keys = nullptr, *c_tk = nullptr;
-        float *c_hi = nullptr, *c_lo = nullptr;
         auto cleanup = [&]() {
-            hipFree(d_groups); hipFree(d_slot_query); hipFree(c_count); hipFree(c_id); hipFree(c_code);
-            hipFree(c_over); hipFree(c_keys); hipFree(c_tk); hipFree(c_hi); hipFree(c_lo);
+            hipFree(d_slot_query); hipFree(c_count); hipFree(c_id);
+            hipFree(c_code); hipFree(c_over); hipFree(c_keys); hipFree(c_tk);
         };
-        rc = dev_alloc(&d_groups, (size_t)ng2);
-        if (!rc) rc = dev_alloc(&d_slot_query, (size_t)slots2);
+        rc = dev_alloc(&d_slot_query, (size_t)slots2);
         if (!rc) rc = dev_alloc(&c_count, (size_t)slots2);
         if (!rc) rc = dev_alloc(&c_id, (size_t)slots2 * cap2);
-        if (!rc) rc = dev_alloc(&c_code, (size_t)slots2 * cap2 * W);
+        if (!rc) rc = dev_alloc(&c_code, (size_t)slots2 * cap2 * 2);
         if (!rc) rc = dev_alloc(&c_over, (size_t)slots2);
         if (!rc) rc = dev_alloc(&c_keys, (size_t)slots2 * cap2);
         if (!rc) rc = dev_alloc(&c_tk, (size_t)slots2);
-        if (!rc) rc = dev_alloc(&c_hi, (size_t)slots2);
-        if (!rc) rc = dev_alloc(&c_lo, (size_t)slots2);
         if (rc) {
             cleanup();
             return rc;
         }
         hipError_t e = hipSuccess;
         auto chk = [&](hipError_t r) { if (e == hipSuccess) e = r; };
-        chk(hipMemcpy(d_groups, groups.data(), sizeof(int32_t) * ng2, hipMemcpyHostToDevice));
         chk(hipMemcpy(d_slot_query, slot_query.data(), sizeof(int32_t) * slots2, hipMemcpyHostToDevice));
         chk(hipMemcpy(c_tk, k2.data(), sizeof(uint64_t) * slots2, hipMemcpyHostToDevice));
-        chk(hipMemcpy(c_hi, hi2.data(), sizeof(float) * slots2, hipMemcpyHostToDevice));
-        chk(hipMemcpy(c_lo, lo2.data(), sizeof(float) * slots2, hipMemcpyHostToDevice));
         chk(hipMemsetAsync(c_count, 0, sizeof(uint32_t) * slots2, stream));
         chk(hipMemsetAsync(c_over, 0, sizeof(uint32_t) * slots2, stream));
         sa.seg_list = nullptr;
         sa.n_seg_pass = x->img.n_segments;
-        sa.group_list = d_groups;
-        sa.thr_hi = c_hi;
-        sa.thr_lo = c_lo;
         sa.thr_key = c_tk;
+        sa.slot_query = d_slot_query;
+        sa.n_queries = slots2;
         sa.cand_count = c_count;
         sa.cand_id = c_id;
         sa.cand_code = c_code;
         sa.cap = (int32_t)cap2;
         chk(dpq::launch_scan(sa, ng2, splits_for(sa.n_seg_pass, ng2), stream));
-        // the scan's counts are exact (rank of the threshold key), read them before select resets anything
         std::vector<uint32_t> h_cnt((size_t)slots2, 0);
         chk(hipMemcpyAsync(h_cnt.data(), c_count, sizeof(uint32_t) * slots2, hipMemcpyDeviceToHost, stream));
         chk(hipStreamSynchronize(stream));
@@ -405,6 +395,9 @@ int run_batch(dpq_index* x, const float* d_queries, int nq, int top_k, int32_t* 
             cap2 = (int64_t)max_cnt + 64;
             continue;
         }
+        se.shared_id = nullptr;
+        se.shared_code = nullptr;
+        se.shared_n = 0;
         se.cand_count = c_count;
         se.cand_id = c_id;
         se.cand_code = c_code;
@@ -412,8 +405,6 @@ int run_batch(dpq_index* x, const float* d_queries, int nq, int top_k, int32_t* 
         se.slot_query = d_slot_query;
         se.keys = c_keys;
         se.thr_key = c_tk;
-        se.thr_hi = c_hi;
-        se.thr_lo = c_lo;
         se.overflow = c_over;
         se.final_pass = 1;
         chk(dpq::launch_select(se, slots2, stream));
@@ -435,6 +426,8 @@ int open_from_payload(const uint8_t* payload, int64_t n_bytes, int64_t n_codes, 
     if (opts) o = *opts;
     if (M != 8) return fail(DPQ_ERR_ARG, "this build has scan kernels for M = 8 only");
     if (K < 1 || K > 256) return fail(DPQ_ERR_ARG, "K must be in 1..256 (one byte per sub-code)");
+    if (o.chunks_per_segment > dpq::kSortMax / dpq::kChunk)
+        return fail(DPQ_ERR_ARG, "chunks_per_segment must be <= 64 (a segment is the cascade's level-0 unit)");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(DPQ_ERR_NO_DEVICE, "no HIP device visible; this library has no CPU fallback");
@@ -699,7 +692,9 @@ int dpq_close(dpq_index* x) {
     hipFree(x->d_ckpt);
     hipFree(x->d_seg_off);
     hipFree(x->d_codebook);
-    hipFree(x->d_seg_lists);
+    hipFree(x->d_order);
+    hipFree(x->d_l0_id);
+    hipFree(x->d_l0_code);
     hipFree(x->d_q_stage);
     hipFree(x->d_ids_stage);
     hipFree(x->d_dists_stage);
@@ -808,30 +803,26 @@ int dpq_merge_topk_device(const int32_t* d_ids, const float* d_dists, int n_list
     return DPQ_OK;
 }
 
-// Developer hook (not in the public header): time `reps` full-index scan launches
-// for nq queries with thresholds fixed at `thr` (-1: nothing survives, +inf:
-// everything survives), to separate decode/ADC cost from candidate handling.
-// Needs a prior dpq_query_batch* call with >= nq queries so that the workspace
-// (LUT images) exists.
-int dpq_debug_scan_time(dpq_index* x, int nq, float thr, int reps, int splits, float* ms_out) {
-    if (!x || !ms_out || !x->d_lut) return fail(DPQ_ERR_STATE, "run a query batch first");
+// Developer hook (not in the public header): time `reps` full-index filter-scan
+// launches for nq query slots with the filter pinned (pass_all == 0: nothing
+// survives; 1: everything survives), to separate decode/ADC cost from
+// candidate handling.  Needs a prior dpq_query_batch* call with >= nq queries.
+int dpq_debug_scan_time(dpq_index* x, int nq, int pass_all, int reps, int splits, float* ms_out) {
+    if (!x || !ms_out || !x->d_lut32) return fail(DPQ_ERR_STATE, "run a query batch first");
     DPQ_HIP(hipSetDevice(x->device));
-    const int QG = dpq::queries_per_group(x->M);
+    const int QG = dpq::kQG;
     const int nqp = (nq + QG - 1) / QG * QG;
     if (nqp > x->ws_slots) return fail(DPQ_ERR_ARG, "nq exceeds the workspace");
-    std::vector<float> h((size_t)nqp, thr);
-    std::vector<uint64_t> hk((size_t)nqp, thr < 0 ? 0ull : ~0ull);
-    DPQ_HIP(hipMemcpy(x->d_thr_hi, h.data(), sizeof(float) * nqp, hipMemcpyHostToDevice));
-    DPQ_HIP(hipMemcpy(x->d_thr_lo, h.data(), sizeof(float) * nqp, hipMemcpyHostToDevice));
-    DPQ_HIP(hipMemcpy(x->d_thr_key, hk.data(), sizeof(uint64_t) * nqp, hipMemcpyHostToDevice));
     dpq::ScanArgs sa{};
     sa.img = x->img;
-    sa.lut = x->d_lut;
+    sa.lut32 = x->d_lut32;
+    sa.lut_min = x->d_lut_min;
+    sa.thr_key = x->d_thr_key;
+    sa.slot_query = nullptr;
+    sa.n_queries = nq;
+    sa.debug_pass = pass_all ? 2 : 1;
     sa.seg_list = nullptr;
     sa.n_seg_pass = x->img.n_segments;
-    sa.thr_hi = x->d_thr_hi;
-    sa.thr_lo = x->d_thr_lo;
-    sa.thr_key = x->d_thr_key;
     sa.cand_count = x->d_cand_count;
     sa.cand_id = x->d_cand_id;
     sa.cand_code = x->d_cand_code;
@@ -847,6 +838,42 @@ int dpq_debug_scan_time(dpq_index* x, int nq, float thr, int reps, int splits, f
         DPQ_HIP(hipMemsetAsync(x->d_cand_count, 0, sizeof(uint32_t) * nqp, nullptr));
         DPQ_HIP(dpq::launch_scan(sa, nqp / QG, splits, nullptr));
     }
+    DPQ_HIP(hipEventRecord(b, nullptr));
+    DPQ_HIP(hipEventSynchronize(b));
+    float ms = 0;
+    DPQ_HIP(hipEventElapsedTime(&ms, a, b));
+    *ms_out = ms / reps;
+    hipEventDestroy(a);
+    hipEventDestroy(b);
+    return DPQ_OK;
+}
+
+// Developer hook: time the level-0 select (shared list) with parts disabled.
+int dpq_debug_select_time(dpq_index* x, int nq, int top_k, int flags, int reps, float* ms_out) {
+    if (!x || !ms_out || !x->d_lut32 || !x->d_l0_id) return fail(DPQ_ERR_STATE, "run a query batch first");
+    DPQ_HIP(hipSetDevice(x->device));
+    dpq::SelectArgs se{};
+    se.shared_id = x->d_l0_id;
+    se.shared_code = x->d_l0_code;
+    se.shared_n = x->l0_segments * dpq::kChunk * x->img.chunks_per_segment;
+    se.cand_count = x->d_cand_count;
+    se.cand_id = x->d_cand_id;
+    se.cand_code = x->d_cand_code;
+    se.cap = x->ws_cap;
+    se.lut32 = x->d_lut32;
+    se.keys = x->d_keys;
+    se.top_k = top_k;
+    se.final_pass = 0;
+    se.thr_key = x->d_thr_key;
+    se.overflow = x->d_overflow;
+    se.n_codes_total = x->img.n_codes_total;
+    se.debug_flags = flags;
+    hipEvent_t a, b;
+    DPQ_HIP(hipEventCreate(&a));
+    DPQ_HIP(hipEventCreate(&b));
+    DPQ_HIP(dpq::launch_select(se, nq, nullptr));
+    DPQ_HIP(hipEventRecord(a, nullptr));
+    for (int r = 0; r < reps; ++r) DPQ_HIP(dpq::launch_select(se, nq, nullptr));
     DPQ_HIP(hipEventRecord(b, nullptr));
     DPQ_HIP(hipEventSynchronize(b));
     float ms = 0;

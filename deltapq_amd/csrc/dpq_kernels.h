@@ -10,12 +10,9 @@ constexpr int kScanThreads = 1024;  // 16 wavefronts, one workgroup per CU (LDS-
 constexpr int kScanWaves = kScanThreads / 64;
 constexpr int kMaxTopK = 2048;
 constexpr int kSelectThreads = 512;
-constexpr int kStage = 128;  // LDS-staged candidates per query per scan workgroup
-
-// queries per LUT group: one scan workgroup keeps QG per-query M x 256 fp32
-// tables in LDS (128 KB) and decodes each chunk once for all of them.
-inline int queries_per_group(int M) { return M <= 8 ? 16 : 8; }
-inline size_t lut_group_floats(int M) { return (size_t)queries_per_group(M) * M * 256; }
+constexpr int kSortMax = 4096;  // candidates the select kernel sorts in LDS; more -> radix select in HBM scratch
+constexpr int kQG = 32;         // queries per scan workgroup: 32 x (8 x 256) u16 filter tables = 128 KB of LDS
+constexpr int kStage = 64;      // LDS-staged candidates per query per scan workgroup
 
 // The SoA image of one shard in HBM (see DESIGN.md "Data layout").
 struct DeviceImage {
@@ -32,50 +29,54 @@ struct DeviceImage {
     int32_t M = 8, K = 256;
 };
 
+// Filter scan of one cascade level.
 struct ScanArgs {
     DeviceImage img;
-    const uint32_t* seg_list;   // segments of this cascade level, or NULL = all
+    const uint32_t* seg_list;   // segments of this level (a slice of the visiting order), or NULL = all
     int32_t n_seg_pass;
-    const float* lut;           // grouped images [group][QG/4][M][256][4]
-    const int32_t* group_list;  // slot -> LUT group, or NULL = identity
-    const float* thr_hi;        // [slots*QG] conservative fp32 accept bound (+inf = take everything)
-    const float* thr_lo;        // [slots*QG] below this the candidate is certainly inside
-    const uint64_t* thr_key;    // [slots*QG] exact threshold key (fp32 bits << 32 | id)
-    uint32_t* cand_count;       // [slots*QG]
-    uint32_t* cand_id;          // [slots*QG][cap]
-    uint32_t* cand_code;        // [slots*QG][cap][M/4] dwords
+    const float* lut32;         // exact tables [query][m][256] fp32
+    const float* lut_min;       // [query][8] per-sub-space minima of the exact tables
+    const uint64_t* thr_key;    // [slots] threshold key of each slot (~0 = keep everything)
+    const int32_t* slot_query;  // slot -> query of the batch, NULL = identity, -1 = unused slot (nothing passes)
+    int32_t n_queries;          // slots >= n_queries are padding when slot_query == NULL
+    int32_t debug_pass;         // developer experiments: 0 normal, 1 nothing passes, 2 everything passes
+    uint32_t* cand_count;       // [slots]
+    uint32_t* cand_id;          // [slots][cap]
+    uint32_t* cand_code;        // [slots][cap][2] dwords
     int32_t cap;
 };
 
 struct SelectArgs {
-    uint32_t* cand_count;        // in: candidates per slot; out (non-final): winners carried to the next level
+    // candidate source: the level-0 list shared by all queries, or the per-slot buffers
+    const uint32_t* shared_id;     // non-NULL: level 0 (0xffffffff = padding node)
+    const uint32_t* shared_code;
+    int32_t shared_n;
+    uint32_t* cand_count;          // in: candidates per slot; out (non-final): winners carried to the next level
     uint32_t* cand_id;
     uint32_t* cand_code;
     int32_t cap;
-    const float* lut;            // grouped images
-    const int32_t* slot_query;   // slot -> query index in the batch (LUT lookup + output row), NULL = identity
-    uint64_t* keys;              // scratch [slots][cap]
-    int32_t M;
+    const float* lut32;            // exact tables [query][m][256] fp32
+    const int32_t* slot_query;     // slot -> query index in the batch (LUT + output row), NULL = identity, -1 = skip
+    uint64_t* keys;                // scratch [slots][cap] for the radix path
     int32_t top_k;
-    int32_t final_pass;          // 1: write ids/dists; 0: write thresholds only
-    uint64_t* thr_key;           // out [slots]
-    float* thr_hi;               // out [slots]
-    float* thr_lo;               // out [slots]
-    uint32_t* overflow;          // out [slots]: set to 1 when a level dropped candidates (sticky)
-    int32_t* out_ids;            // [nq][top_k]
-    float* out_dists;            // [nq][top_k]
+    int32_t final_pass;            // 1: write ids/dists; 0: carry winners to the next level
+    uint64_t* thr_key;             // out [slots]: k-th smallest key seen so far (upper bound of the final one)
+    uint32_t* overflow;            // out [slots]: set to 1 when a level dropped candidates (sticky)
+    int32_t* out_ids;              // [nq][top_k]
+    float* out_dists;              // [nq][top_k]
     int64_t n_codes_total;
-    int64_t n_local;             // nodes in the shard (top_k may exceed it)
+    int32_t debug_flags;           // developer experiments: 1 skip sort, 2 skip quantise, 4 skip exact eval
 };
 
-hipError_t launch_lut_build(const float* d_codebook, const float* d_queries, int nq, int nq_padded, int M, int K,
-                            int Ds, float* d_lut, hipStream_t stream);
-hipError_t launch_scan(const ScanArgs& a, int n_slots_groups, int splits, hipStream_t stream);
+hipError_t launch_lut_build(const float* d_codebook, const float* d_queries, int nq, int M, int K, int Ds,
+                            float* d_lut32, float* d_lut_min, hipStream_t stream);
+hipError_t launch_decode_segments(const DeviceImage& img, const uint32_t* seg_list, int n_seg, uint32_t* out_id,
+                                  uint32_t* out_code, hipStream_t stream);
+hipError_t launch_scan(const ScanArgs& a, int n_slot_groups, int splits, hipStream_t stream);
 hipError_t launch_select(const SelectArgs& a, int n_slots, hipStream_t stream);
-hipError_t launch_init_thresholds(uint64_t* thr_key, float* thr_hi, float* thr_lo, int n, int n_real,
-                                  hipStream_t stream);
 hipError_t launch_merge(const int32_t* d_ids, const float* d_dists, int n_lists, int nq, int top_k, int32_t* d_out_ids,
                         float* d_out_dists, hipStream_t stream);
-size_t scan_lds_bytes(int M);
+size_t scan_lds_bytes();
+size_t select_lds_bytes();
 
 }  // namespace dpq

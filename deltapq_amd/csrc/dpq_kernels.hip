@@ -1,31 +1,35 @@
 // dpq_kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the DeltaPQ
 // query path.  Reference being replaced: the per-query loop of
 // query_processing_scan_compressed_codes_opt_o_direct
-// (/root/reference/deltapq_create_approx_tree.h:2805-2984; "h:" below).
+// (/root/reference/deltapq_create_approx_tree.h:2805-2984; "h:" below,
+// "main:" = deltapq_approx_tree_main.cpp).
 //
-//   lut_build_kernel   a3: T[m][k] = sum_d (c[m][k][d] - q[m*Ds+d])^2 with the
-//                      reference's mixed fp32/fp64 arithmetic (h:2841-2849).
-//   scan_m8_kernel     a5: delta decode + ADC + threshold filter.  One
-//                      wavefront = one 64-node chunk per step; child codes are
-//                      rebuilt from parent + packed deltas by pointer jumping
-//                      over ds_bpermute; distances come from LDS table gathers
-//                      (no MFMA: this is a lookup workload).  Each workgroup
-//                      keeps the tables of QG queries in LDS and decodes every
-//                      chunk once for all of them.
-//   select_kernel      a6: exact fp64 re-evaluation of the surviving candidates,
-//                      radix-select of the k-th smallest (distance, id) key,
-//                      bitonic sort of the top-k.
-//   merge_kernel       8e: merge of per-shard partial top-k lists.
+//   lut_build_kernel        a3: T[m][k] = sum_d (c[m][k][d] - q[m*Ds+d])^2 with the
+//                           reference's mixed fp32/fp64 arithmetic (h:2841-2849).
+//   scan_kernel             a5 + filter half of a6: delta decode + ADC + threshold
+//                           filter.  One wavefront = one 64-node chunk per step;
+//                           child codes are rebuilt from parent + packed deltas by
+//                           pointer jumping over ds_bpermute; distances are LDS table
+//                           gathers (a lookup workload: no MFMA).  A workgroup keeps
+//                           the filter tables of 32 queries in LDS and decodes every
+//                           chunk once for all of them.
+//   decode_segments_kernel  the same decode, writing plain codes (cascade level 0
+//                           is query independent).
+//   select_kernel           exact half of a6: fp64 re-evaluation of the surviving
+//                           candidates, k-th smallest (distance, id) key, winners
+//                           carried to the next level, next-level filter tables;
+//                           on the last level the sorted top-k.
+//   merge_kernel            8e: merge of per-shard partial top-k lists.
 //
-// Top-k strategy (replaces the reference's sequential size-k max-heap,
-// h:2851-2853, 2909-2914): a threshold cascade.  Level 0 scans a small sample
-// of segments and keeps everything; every later level scans a ~rho x larger
-// sample (the last one: everything) and keeps only nodes whose key
-// (fp32 distance bits, id) is <= the k-th smallest key of the previous level,
-// which is a true upper bound of the final k-th key because sample nodes are
-// real nodes.  The filter inside the scan is an fp32 sum with a conservative
-// relative slack; candidates inside the slack band are decided by the exact
-// fp64 rule, so the candidate set is exactly {key <= threshold key}.
+// Top-k strategy (replaces the sequential size-k max-heap, h:2851-2853,
+// 2909-2914): a progressive threshold cascade.  Segments are visited in a
+// low-discrepancy order, every segment exactly once; level l keeps the nodes
+// whose distance can still be <= the k-th best key of everything seen before,
+// which is the key of a real node and therefore a valid upper bound of the
+// final k-th key.  The in-scan filter is a CONSERVATIVE LOWER BOUND of the
+// distance in 16-bit fixed point (tables quantised per query in the scan
+// prologue, scaled to its threshold, rounded down; saturating adds), so it never
+// drops a node the exact rule would keep; select_kernel then applies the exact rule.
 #include "dpq_kernels.h"
 
 #include <cfloat>
@@ -37,6 +41,17 @@ namespace dpq {
 // small device helpers
 // ---------------------------------------------------------------------------
 
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint32_t pk_add_sat_u16(uint32_t a, uint32_t b) {  // v_pk_add_u16 clamp
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_add_sat(__builtin_bit_cast(u16x2, a),
+                                                                      __builtin_bit_cast(u16x2, b)));
+}
+__device__ __forceinline__ uint32_t pk_sub_sat_u16(uint32_t a, uint32_t b) {  // v_pk_sub_u16 clamp
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(__builtin_bit_cast(u16x2, a),
+                                                                      __builtin_bit_cast(u16x2, b)));
+}
+
 __device__ __forceinline__ uint32_t bperm(int src_lane, uint32_t v) {
     return (uint32_t)__builtin_amdgcn_ds_bpermute(src_lane << 2, (int)v);
 }
@@ -46,39 +61,54 @@ __device__ __forceinline__ uint32_t mbcnt64(uint64_t m, uint32_t acc) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, acc));
 }
 
-// LUT image addressing: [group][qi/4][m][k(256)][qi%4]
-__device__ __host__ __forceinline__ size_t lut_image_index(int qi, int m, int k, int M) {
-    return ((size_t)((qi >> 2) * M + m) * 256 + (size_t)k) * 4 + (size_t)(qi & 3);
-}
-
 __device__ __forceinline__ uint64_t make_key(float d, uint32_t id) {
     return ((uint64_t)__float_as_uint(d) << 32) | (uint64_t)id;
 }
 
 // ---------------------------------------------------------------------------
-// a3: LUT build.  grid = (nq_padded, M), block = 256 (one thread per centroid)
+// a3: LUT build.  grid = (nq, M), block = 256 (one thread per centroid).
+// Output layout [query][m][256] fp32 (exact tables, read by select_kernel).
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void lut_build_kernel(const float* __restrict__ codebook,
-                                                         const float* __restrict__ queries, int nq, int M, int K,
-                                                         int Ds, int QG, float* __restrict__ lut) {
+                                                         const float* __restrict__ queries, int M, int K, int Ds,
+                                                         float* __restrict__ lut, float* __restrict__ lut_min) {
+    __shared__ uint32_t minbits;
     const int q = blockIdx.x, m = blockIdx.y, k = threadIdx.x;
-    const int group = q / QG, qi = q % QG;
+    if (k == 0) minbits = 0x7f800000u;
+    __syncthreads();
     float acc = 0.0f;
-    if (q < nq && k < K) {
+    if (k < K) {
         const float* c = codebook + ((size_t)m * K + k) * Ds;
         const float* qv = queries + (size_t)q * M * Ds + (size_t)m * Ds;
-        for (int d = 0; d < Ds; ++d) {
-            // h:2845-2846: `float += pow(float - float, 2)`
-            const float diff = __fsub_rn(c[d], qv[d]);                 // fp32 subtract
+        // h:2845-2846: `float += pow(float - float, 2)`, d ascending
+        auto step = [&](float cv, float qd) {
+            const float diff = __fsub_rn(cv, qd);                      // fp32 subtract
             const double sq = __dmul_rn((double)diff, (double)diff);   // pow(.,2): exact in fp64
             acc = (float)__dadd_rn((double)acc, sq);                   // float += double
+        };
+        if ((Ds & 3) == 0) {  // rows are 16-byte aligned: one dwordx4 load per 4 dimensions
+            const float4* c4 = reinterpret_cast<const float4*>(c);
+            for (int d = 0; d < Ds; d += 4) {
+                const float4 v = c4[d >> 2];
+                step(v.x, qv[d]);
+                step(v.y, qv[d + 1]);
+                step(v.z, qv[d + 2]);
+                step(v.w, qv[d + 3]);
+            }
+        } else {
+            for (int d = 0; d < Ds; ++d) step(c[d], qv[d]);
         }
+        atomicMin(&minbits, __float_as_uint(acc));                     // acc >= 0: uint order == float order
+    } else {
+        acc = INFINITY;  // centroids beyond K do not exist; no valid code points at them
     }
-    lut[(size_t)group * QG * M * 256 + lut_image_index(qi, m, k, M)] = acc;
+    lut[((size_t)q * M + m) * 256 + k] = acc;
+    __syncthreads();
+    if (k == 0) lut_min[(size_t)q * M + m] = __uint_as_float(minbits);  // feeds the filter quantisation
 }
 
 // ---------------------------------------------------------------------------
-// a5: scan (M = 8, one code = 2 dwords)
+// a5: delta decode of one 64-node chunk by one wavefront (M = 8: a code is 2 dwords)
 // ---------------------------------------------------------------------------
 
 // a7: the reference's decoder[256] (main:312-325) as byte-permute selectors.
@@ -99,175 +129,295 @@ __device__ __forceinline__ uint4 make_decode_entry(uint32_t b) {
     return make_uint4(sel[0], sel[1], pm[0], pm[1]);
 }
 
-template <int QG>
-__global__ __launch_bounds__(kScanThreads) void scan_m8_kernel(const ScanArgs a) {
-    constexpr int M = 8;
-    constexpr int NG = QG / 4;  // float4 sub-groups
+struct WaveDecoder {
+    uint32_t stk_lo, stk_hi;  // ancestor stack (vecs_stack, h:2858-2862) in lanes 0..7
+    uint64_t doff;            // offset of the chunk's first changed byte
+
+    __device__ __forceinline__ void begin_segment(const DeviceImage& img, uint32_t seg, int lane) {
+        doff = img.seg_delta_off[seg];
+        stk_lo = 0;
+        stk_hi = 0;
+        if (lane < 8) {
+            const uint64_t v = reinterpret_cast<const uint64_t*>(img.seg_ckpt)[(size_t)seg * 8 + lane];
+            stk_lo = (uint32_t)v;
+            stk_hi = (uint32_t)(v >> 32);
+        }
+    }
+
+    // Decode node `node` (= this lane's node of the chunk).  `carry`: update the
+    // stack for the next chunk of the segment.
+    __device__ __forceinline__ void step(const DeviceImage& img, int64_t node, int lane, uint64_t lt_mask,
+                                         const uint4* dtab, bool carry, uint32_t& code_lo, uint32_t& code_hi) {
+        // depth nibble and mask (coalesced)
+        const uint32_t nb = img.nib[node >> 1];
+        const uint32_t d = (node & 1) ? (nb >> 4) : (nb & 15u);
+        const uint32_t mk = img.mask[node];
+        const uint32_t pc = __popc(mk);
+        // wave exclusive scan of pc (<= 8) by bit planes: v_mbcnt, no LDS traffic
+        const uint64_t b0 = __ballot(pc & 1u), b1 = __ballot(pc & 2u), b2 = __ballot(pc & 4u),
+                       b3 = __ballot(pc & 8u);
+        uint32_t excl = mbcnt64(b3, 0);
+        excl = mbcnt64(b2, excl << 1);
+        excl = mbcnt64(b1, excl << 1);
+        excl = mbcnt64(b0, excl << 1);
+        const uint32_t total = (uint32_t)(__popcll(b0) + 2 * __popcll(b1) + 4 * __popcll(b2) + 8 * __popcll(b3));
+        // up to 8 changed bytes at byte granularity: 3 aligned dwords + funnel shift
+        const uint8_t* dp = img.delta + doff + excl;
+        const uintptr_t ua = reinterpret_cast<uintptr_t>(dp);
+        const uint32_t* wp = reinterpret_cast<const uint32_t*>(ua & ~(uintptr_t)3);
+        const uint32_t sh = (uint32_t)(ua & 3);
+        const uint32_t w0 = wp[0], w1 = wp[1], w2 = wp[2];
+        const uint32_t raw_lo = __builtin_amdgcn_alignbyte(w1, w0, sh);
+        const uint32_t raw_hi = __builtin_amdgcn_alignbyte(w2, w1, sh);
+        doff += total;
+        // scatter the packed bytes to their positions (a7)
+        const uint4 t = dtab[mk];
+        uint32_t pv_lo = __builtin_amdgcn_perm(raw_hi, raw_lo, t.x);
+        uint32_t pv_hi = __builtin_amdgcn_perm(raw_hi, raw_lo, t.y);
+        uint32_t pm_lo = t.z, pm_hi = t.w;
+        // parent = nearest preceding node with depth-1 (h:2888: stack[depth-1])
+        uint64_t B[8];
+#pragma unroll
+        for (int D = 0; D < 8; ++D) B[D] = __ballot(d == (uint32_t)D);
+        uint64_t selB = 0;
+#pragma unroll
+        for (int D = 1; D < 8; ++D) selB = (d == (uint32_t)D) ? B[D - 1] : selB;
+        const uint64_t prev = selB & lt_mask;
+        int P = prev ? 63 - __clzll((long long)prev) : -1;  // -1: the parent precedes the chunk
+        uint32_t td = d;                                     // depth of the top of my resolved chain
+        // pointer jumping: compose patches along the in-chunk ancestor chain (<= 7 links)
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            const int src = P < 0 ? lane : P;
+            const uint32_t q_pv_lo = bperm(src, pv_lo), q_pv_hi = bperm(src, pv_hi);
+            const uint32_t q_pm_lo = bperm(src, pm_lo), q_pm_hi = bperm(src, pm_hi);
+            const uint32_t q_ptd = bperm(src, ((uint32_t)(P & 0xff)) | (td << 8));
+            if (P >= 0) {
+                pv_lo = (q_pv_lo & ~pm_lo) | pv_lo;
+                pv_hi = (q_pv_hi & ~pm_hi) | pv_hi;
+                pm_lo |= q_pm_lo;
+                pm_hi |= q_pm_hi;
+                const uint32_t pp = q_ptd & 0xffu;
+                P = pp == 0xffu ? -1 : (int)pp;
+                td = q_ptd >> 8;
+            }
+        }
+        // apply to the ancestor that precedes the chunk
+        const int e = td > 0 ? (int)td - 1 : 0;
+        const uint32_t anc_lo = bperm(e, stk_lo), anc_hi = bperm(e, stk_hi);
+        code_lo = (anc_lo & ~pm_lo) | pv_lo;
+        code_hi = (anc_hi & ~pm_hi) | pv_hi;
+        // carry the stack: stack[D] = code of the last node with depth D
+        if (carry) {
+            int srcl = -1;
+#pragma unroll
+            for (int D = 0; D < 8; ++D)
+                if (B[D]) srcl = lane == D ? 63 - __clzll((long long)B[D]) : srcl;
+            const uint32_t n_lo = bperm(srcl < 0 ? lane : srcl, code_lo);
+            const uint32_t n_hi = bperm(srcl < 0 ? lane : srcl, code_hi);
+            if (srcl >= 0) {
+                stk_lo = n_lo;
+                stk_hi = n_hi;
+            }
+        }
+    }
+};
+
+// Cascade level 0: plain codes of a list of segments.  grid = n_seg, block = 64.
+__global__ __launch_bounds__(64) void decode_segments_kernel(const DeviceImage img,
+                                                              const uint32_t* __restrict__ seg_list,
+                                                              uint32_t* __restrict__ out_id,
+                                                              uint32_t* __restrict__ out_code) {
+    __shared__ uint4 dtab[256];
+    const int lane = threadIdx.x;
+    for (int i = lane; i < 256; i += 64) dtab[i] = make_decode_entry((uint32_t)i);
+    __syncthreads();
+    const uint32_t seg = seg_list ? seg_list[blockIdx.x] : blockIdx.x;
+    const uint64_t lt_mask = (1ull << lane) - 1ull;
+    const int cps = img.chunks_per_segment;
+    WaveDecoder dec;
+    dec.begin_segment(img, seg, lane);
+    for (int c = 0; c < cps; ++c) {
+        const int64_t node = ((int64_t)seg * cps + c) * 64 + lane;
+        uint32_t code_lo, code_hi;
+        dec.step(img, node, lane, lt_mask, dtab, c + 1 < cps, code_lo, code_hi);
+        const size_t o = ((size_t)blockIdx.x * cps + c) * 64 + lane;
+        out_id[o] = node < img.n_local ? img.id_base + (uint32_t)node : 0xffffffffu;
+        out_code[2 * o] = code_lo;
+        out_code[2 * o + 1] = code_hi;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// scan: decode + ADC filter for 32 queries per workgroup
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanArgs a) {
+    constexpr int QG = kQG;       // 32 queries
+    constexpr int NG = QG / 8;    // 16-byte table entries hold 8 queries
+    constexpr int NA = QG / 2;    // packed u16 accumulators (dwords)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float4* lut4 = reinterpret_cast<float4*>(smem);                         // [NG][M][256]
-    const float* lutf = reinterpret_cast<const float*>(smem);
-    uint4* dtab = reinterpret_cast<uint4*>(smem + (size_t)QG * M * 256 * 4);  // [256]
+    uint4* lut = reinterpret_cast<uint4*>(smem);                                   // [NG][8][256] x 16 B = 128 KB
+    uint4* dtab = reinterpret_cast<uint4*>(smem + (size_t)NG * 8 * 256 * 16);      // [256]
     // candidate staging: survivors are appended with LDS atomics and flushed to
     // HBM once per workgroup (one global atomic per query), see the epilogue
-    uint32_t* stg_count = reinterpret_cast<uint32_t*>(smem + (size_t)QG * M * 256 * 4 + 4096);  // [QG] (+pad)
-    uint32_t* stg_id = stg_count + 16;                                                          // [QG][kStage]
-    uint32_t* stg_code = stg_id + QG * kStage;                                                  // [QG][kStage][2]
+    uint32_t* stg_count = reinterpret_cast<uint32_t*>(smem + (size_t)NG * 8 * 256 * 16 + 4096);  // [QG]
+    uint32_t* stg_id = stg_count + QG;                                                             // [QG][kStage]
+    uint32_t* stg_code = stg_id + QG * kStage;                                                     // [QG][kStage][2]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int slot_group = blockIdx.y;
-    const int group = a.group_list ? a.group_list[slot_group] : slot_group;
+    const int group = blockIdx.y;
+    const int slot0 = group * QG;
 
-    {   // stage the QG tables (one contiguous 128 KB image) and the decode table
-        const float4* src = reinterpret_cast<const float4*>(a.lut) + (size_t)group * (QG * M * 256 / 4);
-        for (int i = tid; i < QG * M * 256 / 4; i += kScanThreads) lut4[i] = src[i];
-        if (tid < 256) dtab[tid] = make_decode_entry((uint32_t)tid);
-        if (tid < 16) stg_count[tid] = 0;
+    // ---- prologue: quantise the 32 queries' exact tables into conservative
+    // 16-bit filter tables, straight into LDS.  For slot q with threshold tau:
+    //   entry[m][k] = floor((T[m][k] - min_m) * s)   rounded DOWN, saturated at 65535
+    //   node passes iff sum_m entry[m][c_m] <= Q = ceil((tau' - sum_m min_m) * s)
+    //   s = 60000 / (tau' - sum_m min_m),  tau' = tau * (1 + 2^-23)  (fp32 rounding of the exact distance)
+    // A node with exact distance <= tau has sum entry <= (d - sum min) * s <= Q;
+    // a saturated entry (>= 65535 > Q) can only belong to a node with d > tau.
+    // Computed as fma(T, s32, -off) in fp32: off >= min * s32 (rounded up), one
+    // rounding of the result, and s32 carries a (1 - 2^-20) factor, so every
+    // entry is <= the exact real value (conservative).
+    float* q_scale = reinterpret_cast<float*>(stg_id);               // [QG]      (staging area is free until the scan loop)
+    float* q_off = q_scale + QG;                                      // [8][QG]   min_m * scale, rounded UP
+    int32_t* q_base = reinterpret_cast<int32_t*>(q_off + 8 * QG);     // [QG]      row offset of the query's tables, -1 = unused
+    uint16_t* q_thr = reinterpret_cast<uint16_t*>(q_base + QG);       // [QG]      accept bound + 1
+    if (tid < 256) dtab[tid] = make_decode_entry((uint32_t)tid);
+    if (tid < QG) {
+        const int slot = slot0 + tid;
+        int qq = a.slot_query ? a.slot_query[slot] : (slot < a.n_queries ? slot : -1);
+        float s32 = 0.0f;
+        uint32_t qb = 0;  // accept bound + 1; 0 = nothing passes
+        float mn[8];
+#pragma unroll
+        for (int m = 0; m < 8; ++m) mn[m] = 0.0f;
+        if (qq >= 0 && a.debug_pass != 1) {
+            const uint64_t key = a.thr_key[slot];
+            double B = 0.0;
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                mn[m] = a.lut_min[(size_t)qq * 8 + m];
+                B += (double)mn[m];
+            }
+            const double taup = (double)__uint_as_float((uint32_t)(key >> 32)) * (1.0 + 0x1p-23);
+            const double R = taup - B;
+            if (key != ~0ull && a.debug_pass != 2 && R > 0.0 && R < 1e300) {
+                const double s = 60000.0 / R;
+                s32 = (float)(s * (1.0 - 0x1p-20));
+                qb = (uint32_t)ceil(R * s * (1.0 + 0x1p-40)) + 1u;  // ~60002
+            } else {
+                s32 = 0.0f;  // no threshold yet (or degenerate): all entries 0, everything passes
+                qb = 1u;
+            }
+        } else {
+            qq = -1;
+        }
+        q_scale[tid] = s32;
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            // entry = fma(T, s32, -off) with off >= min*s32 (rounded up): never above (T - min) * s32
+            const double od = (double)mn[m] * (double)s32;
+            float of = (float)od;
+            if ((double)of < od) of = __uint_as_float(__float_as_uint(of) + 1u);  // od >= 0: next float up
+            q_off[m * QG + tid] = of;
+        }
+        q_base[tid] = qq >= 0 ? qq * 2048 : -1;
+        q_thr[tid] = (uint16_t)qb;
+        stg_count[tid] = 0;
     }
     __syncthreads();
+    // one (g, m, k) tuple = one 16-byte LDS entry = 8 queries; global reads are coalesced over k,
+    // the per-(query, m) constants come from broadcast ds_read_b128
+    for (int e = tid; e < NG * 8 * 256; e += kScanThreads) {
+        const int g = e >> 11, mk = e & 2047, m = mk >> 8;
+        const int4 b0 = *reinterpret_cast<const int4*>(q_base + g * 8), b1 = *reinterpret_cast<const int4*>(q_base + g * 8 + 4);
+        const float4 s0 = *reinterpret_cast<const float4*>(q_scale + g * 8), s1 = *reinterpret_cast<const float4*>(q_scale + g * 8 + 4);
+        const float4 o0 = *reinterpret_cast<const float4*>(q_off + m * QG + g * 8),
+                     o1 = *reinterpret_cast<const float4*>(q_off + m * QG + g * 8 + 4);
+        const int base[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+        const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+        const float of[8] = {o0.x, o0.y, o0.z, o0.w, o1.x, o1.y, o1.z, o1.w};
+        float t[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t[j] = base[j] >= 0 ? a.lut32[(size_t)base[j] + mk] : INFINITY;
+        uint32_t v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float f = __fmaf_rn(t[j], sc[j], -of[j]);
+            // f < 0 only by the round-up of `of` (true value 0); NaN/inf (unused slot, k >= K) saturate
+            v[j] = f < 65535.0f ? (f > 0.0f ? (uint32_t)f : 0u) : 0xffffu;
+            if (base[j] < 0) v[j] = 0xffffu;
+        }
+        lut[e] = make_uint4(v[0] | (v[1] << 16), v[2] | (v[3] << 16), v[4] | (v[5] << 16), v[6] | (v[7] << 16));
+    }
+    // accept bounds (+1), two queries per dword, wave-uniform
+    uint32_t qp1[NA];
+    {
+        const uint32_t* qt = reinterpret_cast<const uint32_t*>(q_thr);
+#pragma unroll
+        for (int j = 0; j < NA; ++j) qp1[j] = qt[j];
+    }
+    __syncthreads();  // tables complete; the staging area (q_* scratch) may be reused from here on
 
-    const int slot0 = slot_group * QG;
     const uint64_t lt_mask = (1ull << lane) - 1ull;
     const int cps = a.img.chunks_per_segment;
-    const uint64_t* ckpt64 = reinterpret_cast<const uint64_t*>(a.img.seg_ckpt);
+    WaveDecoder dec;
 
     for (int s = blockIdx.x * kScanWaves + wave; s < a.n_seg_pass; s += gridDim.x * kScanWaves) {
         const uint32_t seg = (uint32_t)__builtin_amdgcn_readfirstlane(a.seg_list ? (int)a.seg_list[s] : s);
-        uint64_t doff = a.img.seg_delta_off[seg];
-        // ancestor stack (vecs_stack, h:2858-2862) lives in lanes 0..7
-        uint32_t stk_lo = 0, stk_hi = 0;
-        if (lane < 8) {
-            const uint64_t v = ckpt64[(size_t)seg * 8 + lane];
-            stk_lo = (uint32_t)v;
-            stk_hi = (uint32_t)(v >> 32);
-        }
+        dec.begin_segment(a.img, seg, lane);
         for (int c = 0; c < cps; ++c) {
             const int64_t node = ((int64_t)seg * cps + c) * 64 + lane;  // local position
-            // ---- load this node's depth nibble and mask (coalesced) ----
-            const uint32_t nb = a.img.nib[node >> 1];
-            const uint32_t d = (node & 1) ? (nb >> 4) : (nb & 15u);
-            const uint32_t mk = a.img.mask[node];
-            const uint32_t pc = __popc(mk);
-            // ---- wave exclusive scan of pc (<= 8) by bit planes: no LDS traffic ----
-            const uint64_t b0 = __ballot(pc & 1u), b1 = __ballot(pc & 2u), b2 = __ballot(pc & 4u),
-                           b3 = __ballot(pc & 8u);
-            uint32_t excl = mbcnt64(b3, 0);
-            excl = mbcnt64(b2, excl << 1);
-            excl = mbcnt64(b1, excl << 1);
-            excl = mbcnt64(b0, excl << 1);
-            const uint32_t total = (uint32_t)(__popcll(b0) + 2 * __popcll(b1) + 4 * __popcll(b2) + 8 * __popcll(b3));
-            // ---- fetch up to 8 changed bytes at byte granularity: 3 aligned dwords + funnel shift ----
-            const uint8_t* dp = a.img.delta + doff + excl;
-            const uintptr_t ua = reinterpret_cast<uintptr_t>(dp);
-            const uint32_t* wp = reinterpret_cast<const uint32_t*>(ua & ~(uintptr_t)3);
-            const uint32_t sh = (uint32_t)(ua & 3);
-            const uint32_t w0 = wp[0], w1 = wp[1], w2 = wp[2];
-            const uint32_t raw_lo = __builtin_amdgcn_alignbyte(w1, w0, sh);
-            const uint32_t raw_hi = __builtin_amdgcn_alignbyte(w2, w1, sh);
-            doff += total;
-            // ---- scatter the packed bytes to their positions (a7) ----
-            const uint4 t = dtab[mk];
-            uint32_t pv_lo = __builtin_amdgcn_perm(raw_hi, raw_lo, t.x);
-            uint32_t pv_hi = __builtin_amdgcn_perm(raw_hi, raw_lo, t.y);
-            uint32_t pm_lo = t.z, pm_hi = t.w;
-            // ---- parent = nearest preceding node with depth-1 (h:2888: stack[depth-1]) ----
-            uint64_t B[8];
+            uint32_t code_lo, code_hi;
+            dec.step(a.img, node, lane, lt_mask, dtab, c + 1 < cps, code_lo, code_hi);
+
+            // ---- ADC lower bound: 8 LDS gathers per 8 queries, saturating u16 adds ----
+            uint32_t acc[NA];
 #pragma unroll
-            for (int D = 0; D < 8; ++D) B[D] = __ballot(d == (uint32_t)D);
-            uint64_t selB = 0;
+            for (int j = 0; j < NA; ++j) acc[j] = 0;
 #pragma unroll
-            for (int D = 1; D < 8; ++D) selB = (d == (uint32_t)D) ? B[D - 1] : selB;
-            const uint64_t prev = selB & lt_mask;
-            int P = prev ? 63 - __clzll((long long)prev) : -1;  // -1: parent precedes the chunk
-            uint32_t td = d;                                     // depth of the top of my resolved chain
-            // ---- pointer jumping: compose patches along the in-chunk ancestor chain (<= 7 links) ----
-#pragma unroll
-            for (int step = 0; step < 3; ++step) {
-                const int src = P < 0 ? lane : P;
-                const uint32_t q_pv_lo = bperm(src, pv_lo), q_pv_hi = bperm(src, pv_hi);
-                const uint32_t q_pm_lo = bperm(src, pm_lo), q_pm_hi = bperm(src, pm_hi);
-                const uint32_t q_ptd = bperm(src, ((uint32_t)(P & 0xff)) | (td << 8));
-                if (P >= 0) {
-                    pv_lo = (q_pv_lo & ~pm_lo) | pv_lo;
-                    pv_hi = (q_pv_hi & ~pm_hi) | pv_hi;
-                    pm_lo |= q_pm_lo;
-                    pm_hi |= q_pm_hi;
-                    const uint32_t pp = q_ptd & 0xffu;
-                    P = pp == 0xffu ? -1 : (int)pp;
-                    td = q_ptd >> 8;
-                }
-            }
-            // ---- apply to the ancestor that precedes the chunk ----
-            const int e = td > 0 ? (int)td - 1 : 0;
-            const uint32_t anc_lo = bperm(e, stk_lo), anc_hi = bperm(e, stk_hi);
-            const uint32_t code_lo = (anc_lo & ~pm_lo) | pv_lo;
-            const uint32_t code_hi = (anc_hi & ~pm_hi) | pv_hi;
-            // ---- carry the stack: stack[D] = code of the last node with depth D ----
-            if (c + 1 < cps) {
-                int srcl = -1;
-#pragma unroll
-                for (int D = 0; D < 8; ++D)
-                    if (B[D]) srcl = lane == D ? 63 - __clzll((long long)B[D]) : srcl;
-                const uint32_t n_lo = bperm(srcl < 0 ? lane : srcl, code_lo);
-                const uint32_t n_hi = bperm(srcl < 0 ? lane : srcl, code_hi);
-                if (srcl >= 0) {
-                    stk_lo = n_lo;
-                    stk_hi = n_hi;
-                }
-            }
-            // ---- ADC: 8 LDS gathers per 4 queries, fp32 filter sums ----
-            float acc[QG];
-#pragma unroll
-            for (int q = 0; q < QG; ++q) acc[q] = 0.0f;
-#pragma unroll
-            for (int m = 0; m < M; ++m) {
+            for (int m = 0; m < 8; ++m) {
                 const uint32_t byte = ((m < 4 ? code_lo : code_hi) >> (8 * (m & 3))) & 0xffu;
 #pragma unroll
                 for (int g = 0; g < NG; ++g) {
-                    const float4 v = lut4[(g * M + m) * 256 + byte];
-                    acc[4 * g + 0] += v.x;
-                    acc[4 * g + 1] += v.y;
-                    acc[4 * g + 2] += v.z;
-                    acc[4 * g + 3] += v.w;
+                    const uint4 v = lut[(g * 8 + m) * 256 + byte];
+                    acc[4 * g + 0] = pk_add_sat_u16(acc[4 * g + 0], v.x);
+                    acc[4 * g + 1] = pk_add_sat_u16(acc[4 * g + 1], v.y);
+                    acc[4 * g + 2] = pk_add_sat_u16(acc[4 * g + 2], v.z);
+                    acc[4 * g + 3] = pk_add_sat_u16(acc[4 * g + 3], v.w);
                 }
             }
-            // ---- threshold filter (replaces the heap test h:2909-2914) ----
+            // ---- filter (replaces the heap test h:2909-2914): keep iff bound <= accept bound ----
             const bool valid = node < a.img.n_local;
-            bool any = false;
+            uint32_t any = 0;
 #pragma unroll
-            for (int q = 0; q < QG; ++q) any |= acc[q] <= a.thr_hi[slot0 + q];
-            any &= valid;
-            if (__any(any)) {
+            for (int j = 0; j < NA; ++j) any |= pk_sub_sat_u16(qp1[j], acc[j]);  // half != 0 <=> acc <= Q
+            if (!valid) any = 0;
+            if (__any(any != 0)) {
                 const uint32_t id = a.img.id_base + (uint32_t)node;
 #pragma unroll
-                for (int q = 0; q < QG; ++q) {
-                    if (valid && acc[q] <= a.thr_hi[slot0 + q]) {
-                        bool take = true;
-                        if (acc[q] >= a.thr_lo[slot0 + q]) {
-                            // inside the slack band: decide with the exact rule
-                            // (fp64 sum of the fp32 entries, rounded to fp32, then (dist, id) order)
-                            double dsum = 0.0;
+                for (int j = 0; j < NA; ++j) {
+                    const uint32_t t = valid ? pk_sub_sat_u16(qp1[j], acc[j]) : 0u;
+                    if (__any(t != 0)) {
 #pragma unroll
-                            for (int m = 0; m < M; ++m) {
-                                const uint32_t byte = ((m < 4 ? code_lo : code_hi) >> (8 * (m & 3))) & 0xffu;
-                                dsum = __dadd_rn(dsum, (double)lutf[lut_image_index(q, m, (int)byte, M)]);
-                            }
-                            take = make_key((float)dsum, id) <= a.thr_key[slot0 + q];
-                        }
-                        if (take) {
-                            const uint32_t li = atomicAdd(&stg_count[q], 1u);
-                            if (li < (uint32_t)kStage) {
-                                stg_id[q * kStage + li] = id;
-                                stg_code[2 * (q * kStage + li)] = code_lo;
-                                stg_code[2 * (q * kStage + li) + 1] = code_hi;
-                            } else {  // staging full (level 0 keeps everything): straight to HBM
-                                const uint32_t idx = atomicAdd(&a.cand_count[slot0 + q], 1u);
-                                if (idx < (uint32_t)a.cap) {
-                                    const size_t o = (size_t)(slot0 + q) * a.cap + idx;
-                                    a.cand_id[o] = id;
-                                    a.cand_code[2 * o] = code_lo;
-                                    a.cand_code[2 * o + 1] = code_hi;
+                        for (int h = 0; h < 2; ++h) {
+                            if ((t >> (16 * h)) & 0xffffu) {
+                                const int q = 2 * j + h;
+                                const uint32_t li = atomicAdd(&stg_count[q], 1u);
+                                if (li < (uint32_t)kStage) {
+                                    stg_id[q * kStage + li] = id;
+                                    stg_code[2 * (q * kStage + li)] = code_lo;
+                                    stg_code[2 * (q * kStage + li) + 1] = code_hi;
+                                } else {  // staging full: straight to HBM
+                                    const uint32_t idx = atomicAdd(&a.cand_count[slot0 + q], 1u);
+                                    if (idx < (uint32_t)a.cap) {
+                                        const size_t o = (size_t)(slot0 + q) * a.cap + idx;
+                                        a.cand_id[o] = id;
+                                        a.cand_code[2 * o] = code_lo;
+                                        a.cand_code[2 * o + 1] = code_hi;
+                                    }
                                 }
                             }
                         }
@@ -277,7 +427,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_m8_kernel(const ScanArgs a)
         }
     }
 
-    // ---- epilogue: flush the staged candidates, wave w serves query w ----
+    // ---- epilogue: flush the staged candidates, wave w serves queries w, w+16 ----
     __syncthreads();
     for (int q = wave; q < QG; q += kScanWaves) {
         const uint32_t n = min(stg_count[q], (uint32_t)kStage);
@@ -298,21 +448,33 @@ __global__ __launch_bounds__(kScanThreads) void scan_m8_kernel(const ScanArgs a)
 }
 
 // ---------------------------------------------------------------------------
-// a6: select.  grid = slots, block = kSelectThreads
+// a6: select.  grid = slots, block = kSelectThreads, dynamic LDS
 // ---------------------------------------------------------------------------
+
+// exact distance: fp64 sum of the 8 fp32 entries, rounded to fp32 == the
+// reference's incremental fp64 stack (h:2889-2907), see DESIGN.md section 3
+__device__ __forceinline__ float exact_dist(const float* __restrict__ T, uint32_t c_lo, uint32_t c_hi) {
+    double dsum = 0.0;
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        const uint32_t byte = ((m < 4 ? c_lo : c_hi) >> (8 * (m & 3))) & 0xffu;
+        dsum = __dadd_rn(dsum, (double)T[m * 256 + byte]);
+    }
+    return (float)dsum;
+}
 
 __device__ __forceinline__ void block_bitonic_sort(uint64_t* v, int n_pow2, int tid, int nthreads) {
     for (int k = 2; k <= n_pow2; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = tid; i < n_pow2; i += nthreads) {
-                const int ixj = i ^ j;
-                if (ixj > i) {
-                    const uint64_t x = v[i], y = v[ixj];
-                    const bool up = (i & k) == 0;
-                    if ((x > y) == up) {
-                        v[i] = y;
-                        v[ixj] = x;
-                    }
+            for (int t = tid; t < n_pow2 / 2; t += nthreads) {
+                // t-th compare-exchange of this stage: i has bit j clear
+                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                const int ixj = i | j;
+                const uint64_t x = v[i], y = v[ixj];
+                const bool up = (i & k) == 0;
+                if ((x > y) == up) {
+                    v[i] = y;
+                    v[ixj] = x;
                 }
             }
             __syncthreads();
@@ -320,7 +482,9 @@ __device__ __forceinline__ void block_bitonic_sort(uint64_t* v, int n_pow2, int 
     }
 }
 
-// k-th smallest (1-based rank `rank`) of keys[0..n) by MSB-first 8-bit radix select.
+// k-th smallest (1-based rank `rank`) of keys[0..n) -- LDS or HBM -- by MSB-first
+// 8-bit radix select.  Histogram with LDS atomics, bin scan by one wavefront
+// (no barriers inside), 3 barriers per pass.
 __device__ uint64_t block_radix_select(const uint64_t* keys, int n, int rank, uint32_t* hist, uint32_t* bcast,
                                        int tid, int nthreads) {
     uint64_t prefix = 0;
@@ -335,26 +499,27 @@ __device__ uint64_t block_radix_select(const uint64_t* keys, int n, int rank, ui
             if (match) atomicAdd(&hist[(uint32_t)(key >> shift) & 255u], 1u);
         }
         __syncthreads();
-        // inclusive scan of the 256 bins (Hillis-Steele in LDS)
-        for (int off = 1; off < 256; off <<= 1) {
-            uint32_t add = 0;
-            if (tid < 256 && tid >= off) add = hist[tid - off];
-            __syncthreads();
-            if (tid < 256) hist[tid] += add;
-            __syncthreads();
-        }
-        if (tid < 256) {
-            const uint32_t cum = hist[tid];
-            const uint32_t below = tid ? hist[tid - 1] : 0u;
-            if (cum >= rem && below < rem) {
-                bcast[0] = (uint32_t)tid;
-                bcast[1] = rem - below;
+        if (tid < 64) {  // wave 0: lane l owns bins 4l..4l+3
+            const uint32_t h0 = hist[4 * tid], h1 = hist[4 * tid + 1], h2 = hist[4 * tid + 2], h3 = hist[4 * tid + 3];
+            const uint32_t mine = h0 + h1 + h2 + h3;
+            uint32_t incl = mine;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t up = (uint32_t)__shfl_up((int)incl, off, 64);
+                if (tid >= off) incl += up;
+            }
+            const uint32_t before = incl - mine;
+            if (before < rem && rem <= incl) {  // exactly one lane
+                uint32_t r = rem - before;
+                int bin = 4 * tid;
+                if (r > h0) { r -= h0; ++bin; if (r > h1) { r -= h1; ++bin; if (r > h2) { r -= h2; ++bin; } } }
+                bcast[0] = (uint32_t)bin;
+                bcast[1] = r;
             }
         }
         __syncthreads();
         prefix |= (uint64_t)bcast[0] << shift;
         rem = bcast[1];
-        __syncthreads();
     }
     return prefix;
 }
@@ -366,83 +531,70 @@ __device__ __forceinline__ int32_t report_id(uint32_t pos, int64_t n_total) {
 }
 
 __global__ __launch_bounds__(kSelectThreads) void select_kernel(const SelectArgs a) {
-    __shared__ uint64_t sel[kMaxTopK];        // winner keys
-    __shared__ uint32_t win_id[kMaxTopK];     // winner entries, staged so they can be
-    __shared__ uint32_t win_code[kMaxTopK * 2];  // compacted to the front in place
-    __shared__ uint32_t hist[256];
-    __shared__ uint32_t bcast[2];
-    __shared__ uint32_t sel_count;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint64_t* skeys = reinterpret_cast<uint64_t*>(smem);                              // [kSortMax] candidate keys
+    uint64_t* wkeys = skeys + kSortMax;                                               // [kMaxTopK] winner keys
+    uint32_t* win_id = reinterpret_cast<uint32_t*>(wkeys + kMaxTopK);                 // [kMaxTopK]
+    uint32_t* win_code = win_id + kMaxTopK;                                           // [kMaxTopK][2]
+    uint32_t* hist = win_code + 2 * kMaxTopK;                                         // [256]
+    uint32_t* bcast = hist + 256;                                                     // [2]
+    uint32_t* counters = bcast + 2;                                                   // [2]: winners, padding nodes
+
     const int slot = blockIdx.x;
     const int tid = threadIdx.x;
     const int q = a.slot_query ? a.slot_query[slot] : slot;
-    if (q < 0) return;  // padding slot
-    const uint32_t cnt = a.cand_count[slot];
-    const int n = (int)min(cnt, (uint32_t)a.cap);
-    uint64_t* keys = a.keys + (size_t)slot * a.cap;
-    const int QG = a.M <= 8 ? 16 : 8;
-    const float* lut = a.lut + (size_t)(q / QG) * QG * a.M * 256;
-    const int qi = q % QG;
-    const int W = a.M / 4;
-
-    // exact distances of the candidates: fp64 sum of the M fp32 entries, rounded
-    // to fp32 == the reference's incremental fp64 stack (h:2889-2907), see DESIGN.md
-    for (int i = tid; i < n; i += kSelectThreads) {
-        const size_t o = (size_t)slot * a.cap + i;
-        double dsum = 0.0;
-        for (int w = 0; w < W; ++w) {
-            const uint32_t cw = a.cand_code[o * W + w];
-#pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                const int m = 4 * w + b;
-                dsum = __dadd_rn(dsum, (double)lut[lut_image_index(qi, m, (int)((cw >> (8 * b)) & 0xffu), a.M)]);
-            }
-        }
-        keys[i] = make_key((float)dsum, a.cand_id[o]);
-    }
+    if (q < 0) return;  // unused slot of a rerun group
+    const float* T = a.lut32 + (size_t)q * 2048;
+    const bool shared = a.shared_id != nullptr;
+    const uint32_t cnt = shared ? (uint32_t)a.shared_n : a.cand_count[slot];
+    const int n = shared ? a.shared_n : (int)min(cnt, (uint32_t)a.cap);
+    const uint32_t* src_id = shared ? a.shared_id : a.cand_id + (size_t)slot * a.cap;
+    const uint32_t* src_code = shared ? a.shared_code : a.cand_code + (size_t)slot * a.cap * 2;
+    // keys live in LDS for the usual list sizes, in HBM scratch for huge ones (overflow reruns)
+    uint64_t* keys = n <= kSortMax ? skeys : a.keys + (size_t)slot * a.cap;
     if (tid == 0) {
-        sel_count = 0;
-        // candidates were dropped at some level: the final list may miss entries -> host reruns this query
-        if (cnt > (uint32_t)a.cap) a.overflow[slot] = 1u;
+        counters[0] = 0;
+        counters[1] = 0;
+        // candidates were dropped at this level: the final list may miss entries -> host reruns this query
+        if (!shared && cnt > (uint32_t)a.cap) a.overflow[slot] = 1u;
     }
     __syncthreads();
 
-    const int kk = min(a.top_k, n);
+    // exact keys of every candidate
+    for (int i = tid; i < n; i += kSelectThreads) {
+        const uint32_t id = src_id[i];
+        uint64_t key = ~0ull;
+        if (id != 0xffffffffu)
+            key = make_key(exact_dist(T, src_code[2 * i], src_code[2 * i + 1]), id);
+        else
+            atomicAdd(&counters[1], 1u);  // padding node of the shared level-0 list
+        keys[i] = key;
+    }
+    __syncthreads();
+    const int n_valid = n - (int)counters[1];
+    const int kk = min(a.top_k, n_valid);
     uint64_t kth = ~0ull;
     if (kk > 0) kth = block_radix_select(keys, n, kk, hist, bcast, tid, kSelectThreads);
 
     // The k-th smallest key seen so far bounds the final k-th key from above
-    // (the candidates are real nodes), so it is the next level's threshold.
-    if (tid == 0) {
-        if (n < a.top_k) {  // fewer than k nodes seen so far: keep everything
-            a.thr_key[slot] = ~0ull;
-            a.thr_hi[slot] = INFINITY;
-            a.thr_lo[slot] = INFINITY;
-        } else {
-            const float t = __uint_as_float((uint32_t)(kth >> 32));
-            a.thr_key[slot] = kth;
-            // |fp32 filter sum - exact| <= 7 * 2^-24 * exact, far inside 2^-20
-            a.thr_hi[slot] = t * (1.0f + 0x1p-20f);
-            a.thr_lo[slot] = t * (1.0f - 0x1p-20f);
-        }
-    }
+    // (candidates are real nodes), so it is the next level's threshold.
+    if (tid == 0) a.thr_key[slot] = n_valid >= a.top_k ? kth : ~0ull;
 
     // winners = the kk keys <= kth (keys are unique: the id is part of the key)
     int p2 = 1;
     while (p2 < kk) p2 <<= 1;
     if (a.final_pass)
-        for (int i = tid; i < p2; i += kSelectThreads) sel[i] = ~0ull;
+        for (int i = tid; i < p2; i += kSelectThreads) wkeys[i] = ~0ull;
     __syncthreads();
     for (int i = tid; i < n; i += kSelectThreads) {
         const uint64_t key = keys[i];
-        if (key <= kth && kk > 0) {
-            const uint32_t pos = atomicAdd(&sel_count, 1u);
+        if (kk > 0 && key <= kth) {
+            const uint32_t pos = atomicAdd(&counters[0], 1u);
             if (pos < (uint32_t)kMaxTopK) {
-                sel[pos] = key;
-                if (!a.final_pass) {
-                    const size_t o = (size_t)slot * a.cap + i;
-                    win_id[pos] = a.cand_id[o];
-                    for (int w = 0; w < W && w < 2; ++w) win_code[pos * 2 + w] = a.cand_code[o * W + w];
-                }
+                wkeys[pos] = key;
+                win_id[pos] = src_id[i];
+                win_code[2 * pos] = src_code[2 * i];
+                win_code[2 * pos + 1] = src_code[2 * i + 1];
             }
         }
     }
@@ -453,33 +605,23 @@ __global__ __launch_bounds__(kSelectThreads) void select_kernel(const SelectArgs
         for (int i = tid; i < kk; i += kSelectThreads) {
             const size_t o = (size_t)slot * a.cap + i;
             a.cand_id[o] = win_id[i];
-            for (int w = 0; w < W && w < 2; ++w) a.cand_code[o * W + w] = win_code[i * 2 + w];
+            a.cand_code[2 * o] = win_code[2 * i];
+            a.cand_code[2 * o + 1] = win_code[2 * i + 1];
         }
         if (tid == 0) a.cand_count[slot] = (uint32_t)kk;
         return;
     }
 
-    block_bitonic_sort(sel, p2, tid, kSelectThreads);
+    block_bitonic_sort(wkeys, p2, tid, kSelectThreads);
     for (int r = tid; r < a.top_k; r += kSelectThreads) {
         const size_t o = (size_t)q * a.top_k + r;
         if (r < kk) {
-            a.out_ids[o] = report_id((uint32_t)(sel[r] & 0xffffffffu), a.n_codes_total);
-            a.out_dists[o] = __uint_as_float((uint32_t)(sel[r] >> 32));
+            a.out_ids[o] = report_id((uint32_t)(wkeys[r] & 0xffffffffu), a.n_codes_total);
+            a.out_dists[o] = __uint_as_float((uint32_t)(wkeys[r] >> 32));
         } else {
             a.out_ids[o] = -1;
             a.out_dists[o] = INFINITY;
         }
-    }
-}
-
-// Level 0 keeps everything (+inf); padding slots of the last LUT group keep nothing.
-__global__ void init_thresholds_kernel(uint64_t* thr_key, float* thr_hi, float* thr_lo, int n, int n_real) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) {
-        const bool real = i < n_real;
-        thr_key[i] = real ? ~0ull : 0ull;
-        thr_hi[i] = real ? INFINITY : -1.0f;
-        thr_lo[i] = real ? INFINITY : -1.0f;
     }
 }
 
@@ -525,52 +667,62 @@ __global__ __launch_bounds__(kSelectThreads) void merge_kernel(const int32_t* __
 // launchers
 // ---------------------------------------------------------------------------
 
-size_t scan_lds_bytes(int M) {
-    const int QG = queries_per_group(M);
-    return lut_group_floats(M) * sizeof(float) + 256 * sizeof(uint4) + 16 * sizeof(uint32_t) +
-           (size_t)QG * kStage * (1 + M / 4) * sizeof(uint32_t);
+size_t scan_lds_bytes() {
+    return (size_t)(kQG / 8) * 8 * 256 * 16 + 256 * sizeof(uint4) + kQG * sizeof(uint32_t) +
+           (size_t)kQG * kStage * 3 * sizeof(uint32_t);
 }
 
-hipError_t launch_lut_build(const float* d_codebook, const float* d_queries, int nq, int nq_padded, int M, int K,
-                            int Ds, float* d_lut, hipStream_t stream) {
-    dim3 grid((unsigned)nq_padded, (unsigned)M);
-    hipLaunchKernelGGL(lut_build_kernel, grid, dim3(256), 0, stream, d_codebook, d_queries, nq, M, K, Ds,
-                       queries_per_group(M), d_lut);
+size_t select_lds_bytes() {
+    return (size_t)kSortMax * 8 + (size_t)kMaxTopK * 8 + (size_t)kMaxTopK * 3 * 4 + (256 + 2 + 2) * 4;
+}
+
+// hipFuncSetAttribute is per device; handles may live on several GPUs
+static hipError_t ensure_dynamic_lds(const void* fn, size_t bytes, bool* done) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 0 || dev >= 64 || !done[dev]) {
+        e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e != hipSuccess) return e;
+        if (dev >= 0 && dev < 64) done[dev] = true;
+    }
+    return hipSuccess;
+}
+
+hipError_t launch_lut_build(const float* d_codebook, const float* d_queries, int nq, int M, int K, int Ds,
+                            float* d_lut32, float* d_lut_min, hipStream_t stream) {
+    if (nq <= 0) return hipSuccess;
+    hipLaunchKernelGGL(lut_build_kernel, dim3((unsigned)nq, (unsigned)M), dim3(256), 0, stream, d_codebook,
+                       d_queries, M, K, Ds, d_lut32, d_lut_min);
+    return hipGetLastError();
+}
+
+hipError_t launch_decode_segments(const DeviceImage& img, const uint32_t* seg_list, int n_seg, uint32_t* out_id,
+                                  uint32_t* out_code, hipStream_t stream) {
+    if (n_seg <= 0) return hipSuccess;
+    if (img.M != 8) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(decode_segments_kernel, dim3((unsigned)n_seg), dim3(64), 0, stream, img, seg_list, out_id,
+                       out_code);
     return hipGetLastError();
 }
 
 hipError_t launch_scan(const ScanArgs& a, int n_slot_groups, int splits, hipStream_t stream) {
     if (a.img.M != 8) return hipErrorInvalidValue;
-    const size_t lds = scan_lds_bytes(8);
     if (a.n_seg_pass <= 0 || n_slot_groups <= 0) return hipSuccess;
-    {   // the attribute is per device and handles may live on several GPUs
-        static bool done[64] = {};
-        int dev = 0;
-        hipError_t e = hipGetDevice(&dev);
-        if (e != hipSuccess) return e;
-        if (dev < 0 || dev >= 64 || !done[dev]) {
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&scan_m8_kernel<16>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) return e;
-            if (dev >= 0 && dev < 64) done[dev] = true;
-        }
-    }
-    dim3 grid((unsigned)splits, (unsigned)n_slot_groups);
-    hipLaunchKernelGGL(scan_m8_kernel<16>, grid, dim3(kScanThreads), lds, stream, a);
+    static bool done[64] = {};
+    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&scan_kernel), scan_lds_bytes(), done);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(scan_kernel, dim3((unsigned)splits, (unsigned)n_slot_groups), dim3(kScanThreads),
+                       scan_lds_bytes(), stream, a);
     return hipGetLastError();
 }
 
 hipError_t launch_select(const SelectArgs& a, int n_slots, hipStream_t stream) {
     if (n_slots <= 0) return hipSuccess;
-    hipLaunchKernelGGL(select_kernel, dim3((unsigned)n_slots), dim3(kSelectThreads), 0, stream, a);
-    return hipGetLastError();
-}
-
-hipError_t launch_init_thresholds(uint64_t* thr_key, float* thr_hi, float* thr_lo, int n, int n_real,
-                                  hipStream_t stream) {
-    if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(init_thresholds_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, thr_key,
-                       thr_hi, thr_lo, n, n_real);
+    static bool done[64] = {};
+    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&select_kernel), select_lds_bytes(), done);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(select_kernel, dim3((unsigned)n_slots), dim3(kSelectThreads), select_lds_bytes(), stream, a);
     return hipGetLastError();
 }
 
@@ -581,11 +733,9 @@ hipError_t launch_merge(const int32_t* d_ids, const float* d_dists, int n_lists,
     while (p2 < n) p2 <<= 1;
     const size_t lds = (size_t)p2 * sizeof(uint64_t);
     if (lds > 128 * 1024) return hipErrorInvalidValue;
-    {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&merge_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-        if (e != hipSuccess) return e;
-    }
+    static bool done[64] = {};
+    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&merge_kernel), 128 * 1024, done);
+    if (e != hipSuccess) return e;
     hipLaunchKernelGGL(merge_kernel, dim3((unsigned)nq), dim3(kSelectThreads), lds, stream, d_ids, d_dists, n_lists,
                        nq, top_k, d_out_ids, d_out_dists);
     return hipGetLastError();

@@ -10,13 +10,13 @@ qs = synth.make_queries(nq, 128, 101)
 tree = synth.synth_tree(n, 8, seed=102)
 payload, nb = synth.encode_dtc(tree)
 lib = _lib.load()
-lib.dpq_debug_scan_time.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_float)]
+lib.dpq_debug_scan_time.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_float)]
 for cps in [int(x) for x in (sys.argv[3].split(',') if len(sys.argv) > 3 else ['4'])]:
     with api.DeltaPQIndex.open_memory(payload, n, 8, 256, chunks_per_segment=cps) as idx:
         idx.set_codebook(cb)
         idx.query_batch(qs, 100)
-        for thr in (-1.0, float('inf')):
-            for splits in (0, 4, 8, 16):
+        for thr in (0, 1):
+            for splits in (0, 4, 8, 16, 32):
                 ms = ctypes.c_float()
                 rc = lib.dpq_debug_scan_time(idx._h, nq, thr, 5, splits, ms)
                 assert rc == 0, lib.dpq_last_error()
