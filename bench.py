@@ -31,6 +31,19 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
+PMC_SUMMARY = os.path.join(HERE, "profiles", "pmc_summary_default_workload.json")
+
+
+def measured_traffic(args):
+    """HBM bytes per scan-kernel launch from the committed rocprofv3 --pmc passes
+    (scripts/collect_pmc.sh: FETCH_SIZE and WRITE_SIZE in separate runs, gfx950
+    x2 read correction).  Only valid for the default workload it was taken on."""
+    default = (args.n, args.queries, args.topk, args.m, args.mean_diffs, args.gpus) == (1_000_000, 1000, 100, 8, 3.0, 1)
+    if not default or not os.path.exists(PMC_SUMMARY):
+        return None, None
+    with open(PMC_SUMMARY) as f:
+        s = json.load(f)
+    return s.get("scan_kernel_hbm_bytes_per_launch"), s.get("tag")
 
 
 def build_workload(args):
@@ -183,6 +196,7 @@ def main():
         alg_bytes_total = float(all_stats[:, 2].sum())                    # == n_bytes of the DTC payload
         achieved = (nq * alg_bytes_total) / (scan_ms_step * 1e-3) / 1e9 if scan_ms_step > 0 else 0.0
         peak = HBM_PEAK_GBPS * world
+        traffic, traffic_tag = measured_traffic(args)
         result = {
             "metric": "queries/sec, SIFT1M-shaped m=8 k=256 topk=%d" % k,
             "value": nq * steps / elapsed,
@@ -201,16 +215,20 @@ def main():
                             "%.2f B/code, %.2f diffs/node" % (args.n, args.m, k, nq, wl["n_bytes"] / args.n,
                                                               (wl["n_bytes"] - args.m) / args.n - 1.5),
                 "n_codes": args.n, "queries_per_step": nq, "topk": k, "n_bytes": int(wl["n_bytes"]),
-                "sharding": "dfs-range x%d" % world, "queries_per_decode_pass": 16,
+                "sharding": "dfs-range x%d" % world, "queries_per_decode_pass": 32,
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "scan_m8_kernel",
+                "kernel": "scan_kernel",
                 "achieved": achieved,
                 "peak": peak,
                 "unit": "GB/s",
                 "frac": achieved / peak,
-                "traffic": None,
+                "traffic": traffic,
+                "traffic_note": ("HBM bytes per scan launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                                 "passes (%s), 2x gfx950 read correction; compare with algorithmic_bytes_per_launch"
+                                 % traffic_tag) if traffic else "not collected for this workload",
+                "algorithmic_bytes_per_launch": nq * alg_bytes_total / launches_step if launches_step else None,
                 "algorithmic_bytes_per_step": nq * alg_bytes_total,
                 "launches_per_step": launches_step,
                 "avg_launch_ms": scan_ms_step / launches_step if launches_step else None,
@@ -218,8 +236,8 @@ def main():
                 "select_ms_per_step": float(all_stats[:, 4].max()) / steps,
                 "lut_ms_per_step": float(all_stats[:, 5].max()) / steps,
                 "note": "achieved = queries x DTC payload bytes / scan-kernel time (HIP events on the launch "
-                        "stream, all cascade levels of a step summed); each decoded chunk serves 16 queries, so "
-                        "physical HBM/L2 traffic is ~1/16 of this figure (see DESIGN.md)",
+                        "stream, all cascade levels of a step summed); each decoded chunk serves 32 queries, so "
+                        "physical traffic is a small fraction of this figure and frac can exceed 1 (see DESIGN.md)",
             },
             "parity_checked_queries": min(args.check, nq) if parity else 0,
             "index": {"device_bytes_rank0": int(all_stats[0, 3]), "segments_rank0": info["n_segments"],
