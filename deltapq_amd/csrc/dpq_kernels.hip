@@ -271,12 +271,14 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanArgs a) {
     const int slot0 = group * QG;
 
     // ---- prologue: quantise the 32 queries' exact tables into conservative
-    // 16-bit filter tables, straight into LDS.  For slot q with threshold tau:
-    //   entry[m][k] = floor((T[m][k] - min_m) * s)   rounded DOWN, saturated at 65535
+    // 13-bit filter tables (two per dword), straight into LDS.  For slot q with threshold tau:
+    //   entry[m][k] = floor((T[m][k] - min_m) * s)   rounded DOWN, saturated at 8191
     //   node passes iff sum_m entry[m][c_m] <= Q = ceil((tau' - sum_m min_m) * s)
-    //   s = 60000 / (tau' - sum_m min_m),  tau' = tau * (1 + 2^-23)  (fp32 rounding of the exact distance)
+    //   s = 7500 / (tau' - sum_m min_m),  tau' = tau * (1 + 2^-23)  (fp32 rounding of the exact distance)
     // A node with exact distance <= tau has sum entry <= (d - sum min) * s <= Q;
-    // a saturated entry (>= 65535 > Q) can only belong to a node with d > tau.
+    // a saturated entry (8191 > Q) can only belong to a node with d > tau; and
+    // 8 entries <= 8191 cannot overflow 16 bits, so packed pairs are summed with
+    // plain 32-bit adds (v_add3_u32) without carries crossing the halves.
     // Computed as fma(T, s32, -off) in fp32: off >= min * s32 (rounded up), one
     // rounding of the result, and s32 carries a (1 - 2^-20) factor, so every
     // entry is <= the exact real value (conservative).
@@ -304,9 +306,9 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanArgs a) {
             const double taup = (double)__uint_as_float((uint32_t)(key >> 32)) * (1.0 + 0x1p-23);
             const double R = taup - B;
             if (key != ~0ull && a.debug_pass != 2 && R > 0.0 && R < 1e300) {
-                const double s = 60000.0 / R;
+                const double s = 7500.0 / R;
                 s32 = (float)(s * (1.0 - 0x1p-20));
-                qb = (uint32_t)ceil(R * s * (1.0 + 0x1p-40)) + 1u;  // ~60002
+                qb = (uint32_t)ceil(R * s * (1.0 + 0x1p-40)) + 1u;  // ~7502
             } else {
                 s32 = 0.0f;  // no threshold yet (or degenerate): all entries 0, everything passes
                 qb = 1u;
@@ -347,8 +349,8 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanArgs a) {
         for (int j = 0; j < 8; ++j) {
             const float f = __fmaf_rn(t[j], sc[j], -of[j]);
             // f < 0 only by the round-up of `of` (true value 0); NaN/inf (unused slot, k >= K) saturate
-            v[j] = f < 65535.0f ? (f > 0.0f ? (uint32_t)f : 0u) : 0xffffu;
-            if (base[j] < 0) v[j] = 0xffffu;
+            v[j] = f < 8191.0f ? (f > 0.0f ? (uint32_t)f : 0u) : 8191u;
+            if (base[j] < 0) v[j] = 8191u;
         }
         lut[e] = make_uint4(v[0] | (v[1] << 16), v[2] | (v[3] << 16), v[4] | (v[5] << 16), v[6] | (v[7] << 16));
     }
@@ -373,21 +375,21 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanArgs a) {
             uint32_t code_lo, code_hi;
             dec.step(a.img, node, lane, lt_mask, dtab, c + 1 < cps, code_lo, code_hi);
 
-            // ---- ADC lower bound: 8 LDS gathers per 8 queries, saturating u16 adds ----
+            // ---- ADC lower bound: 8 LDS gathers per 8 queries; 13-bit entries, two per
+            // dword, summed with 3-input integer adds (no carry can cross the halves) ----
             uint32_t acc[NA];
 #pragma unroll
-            for (int j = 0; j < NA; ++j) acc[j] = 0;
+            for (int g = 0; g < NG; ++g) {
+                uint4 v[8];
 #pragma unroll
-            for (int m = 0; m < 8; ++m) {
-                const uint32_t byte = ((m < 4 ? code_lo : code_hi) >> (8 * (m & 3))) & 0xffu;
-#pragma unroll
-                for (int g = 0; g < NG; ++g) {
-                    const uint4 v = lut[(g * 8 + m) * 256 + byte];
-                    acc[4 * g + 0] = pk_add_sat_u16(acc[4 * g + 0], v.x);
-                    acc[4 * g + 1] = pk_add_sat_u16(acc[4 * g + 1], v.y);
-                    acc[4 * g + 2] = pk_add_sat_u16(acc[4 * g + 2], v.z);
-                    acc[4 * g + 3] = pk_add_sat_u16(acc[4 * g + 3], v.w);
+                for (int m = 0; m < 8; ++m) {
+                    const uint32_t byte = ((m < 4 ? code_lo : code_hi) >> (8 * (m & 3))) & 0xffu;
+                    v[m] = lut[(g * 8 + m) * 256 + byte];
                 }
+                acc[4 * g + 0] = ((v[0].x + v[1].x + v[2].x) + v[3].x + v[4].x) + (v[5].x + v[6].x + v[7].x);
+                acc[4 * g + 1] = ((v[0].y + v[1].y + v[2].y) + v[3].y + v[4].y) + (v[5].y + v[6].y + v[7].y);
+                acc[4 * g + 2] = ((v[0].z + v[1].z + v[2].z) + v[3].z + v[4].z) + (v[5].z + v[6].z + v[7].z);
+                acc[4 * g + 3] = ((v[0].w + v[1].w + v[2].w) + v[3].w + v[4].w) + (v[5].w + v[6].w + v[7].w);
             }
             // ---- filter (replaces the heap test h:2909-2914): keep iff bound <= accept bound ----
             const bool valid = node < a.img.n_local;
