@@ -74,6 +74,35 @@ def synth_tree(n_codes, M=8, seed=0, mean_diffs=3.0, p_child=0.42, p_sibling=0.3
     return dict(root=root, depths=depths, masks=masks, deltas=deltas, M=M)
 
 
+def synth_tree_large(n_codes, M=8, seed=0, mean_diffs=3.0, block=1 << 22, max_depth=None):
+    """Like synth_tree for 10^7..10^9 nodes: the DFS depth chain of one block of
+    `block` nodes is generated once and repeated (every block starts a new
+    depth-1 subtree, which is valid anywhere); masks and changed bytes are fresh
+    random data per block, generated in bounded memory."""
+    if n_codes <= block:
+        return synth_tree(n_codes, M, seed, mean_diffs, max_depth=max_depth)
+    rng = np.random.default_rng(seed)
+    if max_depth is None:
+        max_depth = MAX_DEPTH_M8 if M <= 8 else 15
+    chain = _depth_chain(block + 1, rng, max_depth, 0.42, 0.33)          # `block` depths, first one == 1
+    depths = np.empty(n_codes, dtype=np.uint8)
+    masks = np.empty(n_codes, dtype=np.uint16)
+    depths[0] = 0
+    masks[0] = 0
+    weights = (1 << np.arange(M)).astype(np.uint16)
+    pos, n_diffs = 1, 0
+    while pos < n_codes:
+        m = min(block, n_codes - pos)
+        depths[pos:pos + m] = chain[:m]
+        bits = rng.random((m, M), dtype=np.float32) < np.float32(mean_diffs / M)
+        masks[pos:pos + m] = (bits * weights).sum(axis=1, dtype=np.uint16)
+        n_diffs += int(bits.sum())
+        pos += m
+    deltas = rng.integers(0, 256, size=n_diffs, dtype=np.uint8)
+    root = rng.integers(0, 256, size=M, dtype=np.uint8)
+    return dict(root=root, depths=depths, masks=masks, deltas=deltas, M=M)
+
+
 def popcount16(x):
     x = x.astype(np.uint32)
     x = x - ((x >> 1) & 0x5555)

@@ -264,3 +264,49 @@ def test_full_size_sift1m_shape(gpu, oracle, codebook):
         assert np.array_equal(s.view(np.uint32), dists[r].view(np.uint32))
     # every node scanned exactly once per query by the cascade
     assert prof["scan_node_query_pairs"] == info["n_segments"] * 64 * info["chunks_per_segment"] * nq
+
+
+def test_large_shard_config3_per_gpu_share(gpu, oracle, codebook):
+    """BASELINE configs[3]: 100M codes over 8 GPUs = 12.5M codes per GPU.  One such
+    shard-sized index on one GPU: oracle parity on a query sample + properties."""
+    from deltapq_amd import synth
+    n, nq, k = 12_500_000, 64, 100
+    tree = synth.synth_tree_large(n, 8, seed=7, mean_diffs=3.0)
+    payload, nb = synth.encode_dtc(tree)
+    del tree
+    qs = synth.make_queries(nq, 128, seed=8)
+    ids, dists, prof, info = run(gpu, payload, n, codebook, qs, k)
+    assert info["algorithmic_bytes"] == nb and info["n_segments"] == (n + 255) // 256
+    sample = [0, 21, 42, 63]
+    assert_parity(ids[sample], dists[sample], oracle_topk(oracle, payload, n, codebook, qs[sample], k), n)
+    assert np.all(np.diff(dists, axis=1) >= 0)
+    for r in range(nq):
+        assert len(set(ids[r].tolist())) == k and ids[r].min() >= 0 and ids[r].max() <= n
+    assert prof["scan_node_query_pairs"] == info["n_segments"] * 256 * nq
+    # the same index as shard 5 of 8 (what one rank of the 8-GPU run holds)
+    ids5, dists5, _, info5 = run(gpu, payload, n, codebook, qs[:8], k, shard_rank=5, shard_count=8)
+    lut = oracle.build_lut(codebook, qs[3])
+    _, _, alld, _ = oracle.scan_lut(payload, n, lut, 1, want_all=True)
+    lo, hi = info5["node_lo"], info5["node_hi"]
+    assert abs((hi - lo) - n / 8) < 0.05 * n / 8
+    order = np.lexsort((np.arange(lo, hi), alld[lo:hi].view(np.uint32)))[:k] + lo
+    assert np.array_equal(dists5[3].view(np.uint32), alld[order].view(np.uint32))
+    assert set(ids5[3].tolist()) == set(order.tolist()) or np.array_equal(np.sort(alld[ids5[3]]), np.sort(alld[order]))
+
+
+def test_two_process_sharded_run_on_one_gpu(gpu, built):
+    """8e end to end with real processes: 2 ranks (both on GPU 0, gloo for the
+    exchange because RCCL wants one device per rank) shard the index, query on
+    the GPU through the C-ABI, all-gather the partial lists and merge."""
+    import socket
+    import sys
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "tests", "_dist_gpu_worker.py")]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0 and "DIST_GPU_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
