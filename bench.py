@@ -198,7 +198,7 @@ def main():
         peak = HBM_PEAK_GBPS * world
         traffic, traffic_tag = measured_traffic(args)
         result = {
-            "metric": "queries/sec, SIFT1M-shaped m=8 k=256 topk=%d" % k,
+            "metric": "queries/sec, SIFT1M-shaped m=%d k=256 topk=%d" % (args.m, k),
             "value": nq * steps / elapsed,
             "unit": "queries/s",
             "n_gpus": world,
@@ -213,9 +213,9 @@ def main():
             "config": {
                 "workload": "SIFT1M-shaped synthetic DeltaTree: N=%d m=%d k=256 h=1 topk=%d, %d queries/step, "
                             "%.2f B/code, %.2f diffs/node" % (args.n, args.m, k, nq, wl["n_bytes"] / args.n,
-                                                              (wl["n_bytes"] - args.m) / args.n - 1.5),
+                                                              (wl["n_bytes"] - args.m) / args.n - (1.5 if args.m <= 8 else 2.5)),
                 "n_codes": args.n, "queries_per_step": nq, "topk": k, "n_bytes": int(wl["n_bytes"]),
-                "sharding": "dfs-range x%d" % world, "queries_per_decode_pass": 32,
+                "sharding": "dfs-range x%d" % world, "queries_per_decode_pass": 32 if args.m <= 8 else 16,
             },
             "roofline": {
                 "bound": "hbm",

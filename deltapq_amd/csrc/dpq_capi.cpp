@@ -127,11 +127,12 @@ int ensure_workspace(dpq_index* x, int slots, int cap) {
     cap = std::max(cap, x->ws_cap);
     free_workspace(x);
     int rc;
-    if ((rc = dev_alloc(&x->d_lut32, (size_t)slots * 2048))) return rc;
-    if ((rc = dev_alloc(&x->d_lut_min, (size_t)slots * 8))) return rc;
+    const size_t W = (size_t)x->M / 4;
+    if ((rc = dev_alloc(&x->d_lut32, (size_t)slots * x->M * 256))) return rc;
+    if ((rc = dev_alloc(&x->d_lut_min, (size_t)slots * x->M))) return rc;
     if ((rc = dev_alloc(&x->d_cand_count, (size_t)slots))) return rc;
     if ((rc = dev_alloc(&x->d_cand_id, (size_t)slots * cap))) return rc;
-    if ((rc = dev_alloc(&x->d_cand_code, (size_t)slots * cap * 2))) return rc;
+    if ((rc = dev_alloc(&x->d_cand_code, (size_t)slots * cap * W))) return rc;
     if ((rc = dev_alloc(&x->d_overflow, (size_t)slots))) return rc;
     if ((rc = dev_alloc(&x->d_keys, (size_t)slots * cap))) return rc;
     if ((rc = dev_alloc(&x->d_thr_key, (size_t)slots))) return rc;
@@ -194,7 +195,7 @@ int ensure_plan(dpq_index* x, int top_k, int cap) {
         hipFree(x->d_l0_code);
         x->d_l0_id = x->d_l0_code = nullptr;
         int rc = dev_alloc(&x->d_l0_id, (size_t)(s0 * S));
-        if (!rc) rc = dev_alloc(&x->d_l0_code, (size_t)(s0 * S * 2));
+        if (!rc) rc = dev_alloc(&x->d_l0_code, (size_t)(s0 * S * (x->M / 4)));
         if (rc) return rc;
         DPQ_HIP(dpq::launch_decode_segments(x->img, x->d_order, (int)s0, x->d_l0_id, x->d_l0_code, nullptr));
         DPQ_HIP(hipStreamSynchronize(nullptr));
@@ -239,7 +240,7 @@ int splits_for(int n_seg_pass, int n_groups) {
 // One sub-batch (nq <= kMaxBatchQueries) end to end on `stream`.
 int run_batch(dpq_index* x, const float* d_queries, int nq, int top_k, int32_t* d_ids, float* d_dists,
               hipStream_t stream) {
-    const int QG = dpq::kQG;
+    const int QG = dpq::queries_per_group(x->M);
     const int nqp = (nq + QG - 1) / QG * QG;
     const int ngroups = nqp / QG;
     const int cap = x->cap_auto ? auto_cap(top_k) : std::max(x->cap, top_k);
@@ -287,7 +288,7 @@ int run_batch(dpq_index* x, const float* d_queries, int nq, int top_k, int32_t* 
     const size_t n_levels = x->img.n_segments > 0 ? x->level_cnt.size() : 0;
     if (n_levels == 0) {  // empty shard: every row is padding
         se.final_pass = 1;
-        DPQ_HIP(dpq::launch_select(se, nq, stream));
+        DPQ_HIP(dpq::launch_select(se, x->M, nq, stream));
         return DPQ_OK;
     }
     for (size_t l = 0; l < n_levels; ++l) {
@@ -318,7 +319,7 @@ int run_batch(dpq_index* x, const float* d_queries, int nq, int top_k, int32_t* 
         se.final_pass = final_pass ? 1 : 0;
         {
             Timer t(x, stream, 2);
-            DPQ_HIP(dpq::launch_select(se, nq, stream));
+            DPQ_HIP(dpq::launch_select(se, x->M, nq, stream));
         }
         if (x->prof) x->prof_acc.select_launches++;
     }
@@ -361,7 +362,7 @@ int run_batch(dpq_index* x, const float* d_queries, int nq, int top_k, int32_t* 
         rc = dev_alloc(&d_slot_query, (size_t)slots2);
         if (!rc) rc = dev_alloc(&c_count, (size_t)slots2);
         if (!rc) rc = dev_alloc(&c_id, (size_t)slots2 * cap2);
-        if (!rc) rc = dev_alloc(&c_code, (size_t)slots2 * cap2 * 2);
+        if (!rc) rc = dev_alloc(&c_code, (size_t)slots2 * cap2 * (x->M / 4));
         if (!rc) rc = dev_alloc(&c_over, (size_t)slots2);
         if (!rc) rc = dev_alloc(&c_keys, (size_t)slots2 * cap2);
         if (!rc) rc = dev_alloc(&c_tk, (size_t)slots2);
@@ -407,7 +408,7 @@ int run_batch(dpq_index* x, const float* d_queries, int nq, int top_k, int32_t* 
         se.thr_key = c_tk;
         se.overflow = c_over;
         se.final_pass = 1;
-        chk(dpq::launch_select(se, slots2, stream));
+        chk(dpq::launch_select(se, x->M, slots2, stream));
         chk(hipStreamSynchronize(stream));
         cleanup();
         if (e != hipSuccess) return fail(DPQ_ERR_HIP, std::string("overflow rerun: ") + hipGetErrorString(e));
@@ -424,7 +425,8 @@ int open_from_payload(const uint8_t* payload, int64_t n_bytes, int64_t n_codes, 
     *out = nullptr;
     dpq_open_opts o{};
     if (opts) o = *opts;
-    if (M != 8) return fail(DPQ_ERR_ARG, "this build has scan kernels for M = 8 only");
+    if (M != 8 && M != 16)
+        return fail(DPQ_ERR_ARG, "this build has scan kernels for M = 8 (reference format) and M = 16 (own extension)");
     if (K < 1 || K > 256) return fail(DPQ_ERR_ARG, "K must be in 1..256 (one byte per sub-code)");
     if (o.chunks_per_segment > dpq::kSortMax / dpq::kChunk)
         return fail(DPQ_ERR_ARG, "chunks_per_segment must be <= 64 (a segment is the cascade's level-0 unit)");
@@ -810,7 +812,7 @@ int dpq_merge_topk_device(const int32_t* d_ids, const float* d_dists, int n_list
 int dpq_debug_scan_time(dpq_index* x, int nq, int pass_all, int reps, int splits, float* ms_out) {
     if (!x || !ms_out || !x->d_lut32) return fail(DPQ_ERR_STATE, "run a query batch first");
     DPQ_HIP(hipSetDevice(x->device));
-    const int QG = dpq::kQG;
+    const int QG = dpq::queries_per_group(x->M);
     const int nqp = (nq + QG - 1) / QG * QG;
     if (nqp > x->ws_slots) return fail(DPQ_ERR_ARG, "nq exceeds the workspace");
     dpq::ScanArgs sa{};
@@ -871,9 +873,9 @@ int dpq_debug_select_time(dpq_index* x, int nq, int top_k, int flags, int reps, 
     hipEvent_t a, b;
     DPQ_HIP(hipEventCreate(&a));
     DPQ_HIP(hipEventCreate(&b));
-    DPQ_HIP(dpq::launch_select(se, nq, nullptr));
+    DPQ_HIP(dpq::launch_select(se, x->M, nq, nullptr));
     DPQ_HIP(hipEventRecord(a, nullptr));
-    for (int r = 0; r < reps; ++r) DPQ_HIP(dpq::launch_select(se, nq, nullptr));
+    for (int r = 0; r < reps; ++r) DPQ_HIP(dpq::launch_select(se, x->M, nq, nullptr));
     DPQ_HIP(hipEventRecord(b, nullptr));
     DPQ_HIP(hipEventSynchronize(b));
     float ms = 0;

@@ -11,7 +11,7 @@ constexpr int kScanWaves = kScanThreads / 64;
 constexpr int kMaxTopK = 2048;
 constexpr int kSelectThreads = 512;
 constexpr int kSortMax = 4096;  // candidates the select kernel sorts in LDS; more -> radix select in HBM scratch
-constexpr int kQG = 32;         // queries per scan workgroup: 32 x (8 x 256) u16 filter tables = 128 KB of LDS
+inline int queries_per_group(int M) { return M <= 8 ? 32 : 16; }  // 128 KB of 16-bit filter tables per workgroup
 constexpr int kStage = 64;      // LDS-staged candidates per query per scan workgroup
 
 // The SoA image of one shard in HBM (see DESIGN.md "Data layout").
@@ -42,7 +42,7 @@ struct ScanArgs {
     int32_t debug_pass;         // developer experiments: 0 normal, 1 nothing passes, 2 everything passes
     uint32_t* cand_count;       // [slots]
     uint32_t* cand_id;          // [slots][cap]
-    uint32_t* cand_code;        // [slots][cap][2] dwords
+    uint32_t* cand_code;        // [slots][cap][M/4] dwords
     int32_t cap;
 };
 
@@ -73,10 +73,10 @@ hipError_t launch_lut_build(const float* d_codebook, const float* d_queries, int
 hipError_t launch_decode_segments(const DeviceImage& img, const uint32_t* seg_list, int n_seg, uint32_t* out_id,
                                   uint32_t* out_code, hipStream_t stream);
 hipError_t launch_scan(const ScanArgs& a, int n_slot_groups, int splits, hipStream_t stream);
-hipError_t launch_select(const SelectArgs& a, int n_slots, hipStream_t stream);
+hipError_t launch_select(const SelectArgs& a, int M, int n_slots, hipStream_t stream);
 hipError_t launch_merge(const int32_t* d_ids, const float* d_dists, int n_lists, int nq, int top_k, int32_t* d_out_ids,
                         float* d_out_dists, hipStream_t stream);
-size_t scan_lds_bytes();
-size_t select_lds_bytes();
+size_t scan_lds_bytes(int M);
+size_t select_lds_bytes(int M);
 
 }  // namespace dpq

@@ -108,13 +108,29 @@ __global__ __launch_bounds__(256) void lut_build_kernel(const float* __restrict_
 }
 
 // ---------------------------------------------------------------------------
-// a5: delta decode of one 64-node chunk by one wavefront (M = 8: a code is 2 dwords)
+// a5: delta decode of one 64-node chunk by one wavefront.
+// M = 8: the reference format (a code is 2 dwords, 8 stack levels).
+// M = 16: this build's extension (4 dwords, 2-byte masks, 16 levels); the
+// reference format stops at M = 8 (h:1765, 1791-1795, 2883).
 // ---------------------------------------------------------------------------
 
+template <int M>
+struct Cfg {
+    static constexpr int W = M / 4;                   // dwords per code
+    static constexpr int LEVELS = M <= 8 ? 8 : 16;    // ancestor stack entries (h:2858-2864: M of them)
+    static constexpr int JUMPS = M <= 8 ? 3 : 4;      // pointer-jumping rounds: 2^JUMPS > deepest in-chunk chain
+    static constexpr int PLANES = M <= 8 ? 4 : 5;     // bits of popcount(mask)
+    static constexpr int QG = M <= 8 ? 32 : 16;       // queries per scan workgroup (128 KB of filter tables)
+    static constexpr int NG = QG / 8;                 // 16-byte table entries hold 8 queries
+    static constexpr int NA = QG / 2;                 // packed accumulators (two queries per dword)
+    static constexpr int SAT = 65535 / M;             // entry saturation: M entries cannot overflow 16 bits
+    static constexpr int QTARGET = M <= 8 ? 7500 : 3700;  // accept bound in filter units (< SAT)
+};
+
 // a7: the reference's decoder[256] (main:312-325) as byte-permute selectors.
-// entry.x/.y: v_perm_b32 selectors that move the node's packed changed bytes to
-// their positions 0..3 / 4..7 (0x0c = constant zero); entry.z/.w: byte masks of
-// the changed positions.
+// entry.x/.y: v_perm_b32 selectors that move a node's packed changed bytes to
+// positions 0..3 / 4..7 of an 8-position group (0x0c = constant zero);
+// entry.z/.w: byte masks of the changed positions.
 __device__ __forceinline__ uint4 make_decode_entry(uint32_t b) {
     uint32_t sel[2] = {0, 0}, pm[2] = {0, 0};
     uint32_t rank = 0;
@@ -129,74 +145,89 @@ __device__ __forceinline__ uint4 make_decode_entry(uint32_t b) {
     return make_uint4(sel[0], sel[1], pm[0], pm[1]);
 }
 
+template <int M>
 struct WaveDecoder {
-    uint32_t stk_lo, stk_hi;  // ancestor stack (vecs_stack, h:2858-2862) in lanes 0..7
-    uint64_t doff;            // offset of the chunk's first changed byte
+    static constexpr int W = Cfg<M>::W;
+    static constexpr int LEVELS = Cfg<M>::LEVELS;
+    uint32_t stk[W];  // ancestor stack (vecs_stack, h:2858-2862) in lanes 0..LEVELS-1
+    uint64_t doff;    // offset of the chunk's first changed byte
 
     __device__ __forceinline__ void begin_segment(const DeviceImage& img, uint32_t seg, int lane) {
         doff = img.seg_delta_off[seg];
-        stk_lo = 0;
-        stk_hi = 0;
-        if (lane < 8) {
-            const uint64_t v = reinterpret_cast<const uint64_t*>(img.seg_ckpt)[(size_t)seg * 8 + lane];
-            stk_lo = (uint32_t)v;
-            stk_hi = (uint32_t)(v >> 32);
+#pragma unroll
+        for (int w = 0; w < W; ++w) stk[w] = 0;
+        if (lane < LEVELS) {
+            const uint32_t* ck = reinterpret_cast<const uint32_t*>(img.seg_ckpt) + ((size_t)seg * LEVELS + lane) * W;
+#pragma unroll
+            for (int w = 0; w < W; ++w) stk[w] = ck[w];
         }
     }
 
     // Decode node `node` (= this lane's node of the chunk).  `carry`: update the
     // stack for the next chunk of the segment.
     __device__ __forceinline__ void step(const DeviceImage& img, int64_t node, int lane, uint64_t lt_mask,
-                                         const uint4* dtab, bool carry, uint32_t& code_lo, uint32_t& code_hi) {
+                                         const uint4* dtab, bool carry, uint32_t (&code)[W]) {
         // depth nibble and mask (coalesced)
         const uint32_t nb = img.nib[node >> 1];
         const uint32_t d = (node & 1) ? (nb >> 4) : (nb & 15u);
-        const uint32_t mk = img.mask[node];
+        const uint32_t mk = M <= 8 ? (uint32_t)img.mask[node]
+                                   : (uint32_t)reinterpret_cast<const uint16_t*>(img.mask)[node];
         const uint32_t pc = __popc(mk);
-        // wave exclusive scan of pc (<= 8) by bit planes: v_mbcnt, no LDS traffic
-        const uint64_t b0 = __ballot(pc & 1u), b1 = __ballot(pc & 2u), b2 = __ballot(pc & 4u),
-                       b3 = __ballot(pc & 8u);
-        uint32_t excl = mbcnt64(b3, 0);
-        excl = mbcnt64(b2, excl << 1);
-        excl = mbcnt64(b1, excl << 1);
-        excl = mbcnt64(b0, excl << 1);
-        const uint32_t total = (uint32_t)(__popcll(b0) + 2 * __popcll(b1) + 4 * __popcll(b2) + 8 * __popcll(b3));
-        // up to 8 changed bytes at byte granularity: 3 aligned dwords + funnel shift
-        const uint8_t* dp = img.delta + doff + excl;
-        const uintptr_t ua = reinterpret_cast<uintptr_t>(dp);
-        const uint32_t* wp = reinterpret_cast<const uint32_t*>(ua & ~(uintptr_t)3);
-        const uint32_t sh = (uint32_t)(ua & 3);
-        const uint32_t w0 = wp[0], w1 = wp[1], w2 = wp[2];
-        const uint32_t raw_lo = __builtin_amdgcn_alignbyte(w1, w0, sh);
-        const uint32_t raw_hi = __builtin_amdgcn_alignbyte(w2, w1, sh);
-        doff += total;
-        // scatter the packed bytes to their positions (a7)
-        const uint4 t = dtab[mk];
-        uint32_t pv_lo = __builtin_amdgcn_perm(raw_hi, raw_lo, t.x);
-        uint32_t pv_hi = __builtin_amdgcn_perm(raw_hi, raw_lo, t.y);
-        uint32_t pm_lo = t.z, pm_hi = t.w;
-        // parent = nearest preceding node with depth-1 (h:2888: stack[depth-1])
-        uint64_t B[8];
+        // wave exclusive scan of pc by bit planes: v_mbcnt, no LDS traffic
+        uint32_t excl = 0, total = 0;
 #pragma unroll
-        for (int D = 0; D < 8; ++D) B[D] = __ballot(d == (uint32_t)D);
+        for (int b = Cfg<M>::PLANES - 1; b >= 0; --b) {
+            const uint64_t plane = __ballot((pc >> b) & 1u);
+            excl = mbcnt64(plane, excl << 1);
+            total = (total << 1) + (uint32_t)__popcll(plane);
+        }
+        // changed bytes at byte granularity, one 8-position group at a time:
+        // 3 aligned dwords + funnel shift, then scatter to positions (a7)
+        uint32_t pv[W], pm[W];
+#pragma unroll
+        for (int h = 0; h < W / 2; ++h) {
+            const uint32_t skip = h == 0 ? 0u : (uint32_t)__popc(mk & 0xffu);
+            const uint8_t* dp = img.delta + doff + excl + skip;
+            const uintptr_t ua = reinterpret_cast<uintptr_t>(dp);
+            const uint32_t* wp = reinterpret_cast<const uint32_t*>(ua & ~(uintptr_t)3);
+            const uint32_t sh = (uint32_t)(ua & 3);
+            const uint32_t w0 = wp[0], w1 = wp[1], w2 = wp[2];
+            const uint32_t raw_lo = __builtin_amdgcn_alignbyte(w1, w0, sh);
+            const uint32_t raw_hi = __builtin_amdgcn_alignbyte(w2, w1, sh);
+            const uint4 t = dtab[(mk >> (8 * h)) & 0xffu];
+            pv[2 * h] = __builtin_amdgcn_perm(raw_hi, raw_lo, t.x);
+            pv[2 * h + 1] = __builtin_amdgcn_perm(raw_hi, raw_lo, t.y);
+            pm[2 * h] = t.z;
+            pm[2 * h + 1] = t.w;
+        }
+        doff += total;
+        // parent = nearest preceding node with depth-1 (h:2888: stack[depth-1])
+        uint64_t B[LEVELS];
+#pragma unroll
+        for (int D = 0; D < LEVELS; ++D) B[D] = __ballot(d == (uint32_t)D);
         uint64_t selB = 0;
 #pragma unroll
-        for (int D = 1; D < 8; ++D) selB = (d == (uint32_t)D) ? B[D - 1] : selB;
+        for (int D = 1; D < LEVELS; ++D) selB = (d == (uint32_t)D) ? B[D - 1] : selB;
         const uint64_t prev = selB & lt_mask;
         int P = prev ? 63 - __clzll((long long)prev) : -1;  // -1: the parent precedes the chunk
         uint32_t td = d;                                     // depth of the top of my resolved chain
-        // pointer jumping: compose patches along the in-chunk ancestor chain (<= 7 links)
+        // pointer jumping: compose patches along the in-chunk ancestor chain
 #pragma unroll
-        for (int s = 0; s < 3; ++s) {
+        for (int s = 0; s < Cfg<M>::JUMPS; ++s) {
             const int src = P < 0 ? lane : P;
-            const uint32_t q_pv_lo = bperm(src, pv_lo), q_pv_hi = bperm(src, pv_hi);
-            const uint32_t q_pm_lo = bperm(src, pm_lo), q_pm_hi = bperm(src, pm_hi);
+            uint32_t q_pv[W], q_pm[W];
+#pragma unroll
+            for (int w = 0; w < W; ++w) {
+                q_pv[w] = bperm(src, pv[w]);
+                q_pm[w] = bperm(src, pm[w]);
+            }
             const uint32_t q_ptd = bperm(src, ((uint32_t)(P & 0xff)) | (td << 8));
             if (P >= 0) {
-                pv_lo = (q_pv_lo & ~pm_lo) | pv_lo;
-                pv_hi = (q_pv_hi & ~pm_hi) | pv_hi;
-                pm_lo |= q_pm_lo;
-                pm_hi |= q_pm_hi;
+#pragma unroll
+                for (int w = 0; w < W; ++w) {
+                    pv[w] = (q_pv[w] & ~pm[w]) | pv[w];
+                    pm[w] |= q_pm[w];
+                }
                 const uint32_t pp = q_ptd & 0xffu;
                 P = pp == 0xffu ? -1 : (int)pp;
                 td = q_ptd >> 8;
@@ -204,30 +235,30 @@ struct WaveDecoder {
         }
         // apply to the ancestor that precedes the chunk
         const int e = td > 0 ? (int)td - 1 : 0;
-        const uint32_t anc_lo = bperm(e, stk_lo), anc_hi = bperm(e, stk_hi);
-        code_lo = (anc_lo & ~pm_lo) | pv_lo;
-        code_hi = (anc_hi & ~pm_hi) | pv_hi;
+#pragma unroll
+        for (int w = 0; w < W; ++w) code[w] = (bperm(e, stk[w]) & ~pm[w]) | pv[w];
         // carry the stack: stack[D] = code of the last node with depth D
         if (carry) {
             int srcl = -1;
 #pragma unroll
-            for (int D = 0; D < 8; ++D)
+            for (int D = 0; D < LEVELS; ++D)
                 if (B[D]) srcl = lane == D ? 63 - __clzll((long long)B[D]) : srcl;
-            const uint32_t n_lo = bperm(srcl < 0 ? lane : srcl, code_lo);
-            const uint32_t n_hi = bperm(srcl < 0 ? lane : srcl, code_hi);
-            if (srcl >= 0) {
-                stk_lo = n_lo;
-                stk_hi = n_hi;
+#pragma unroll
+            for (int w = 0; w < W; ++w) {
+                const uint32_t nv = bperm(srcl < 0 ? lane : srcl, code[w]);
+                if (srcl >= 0) stk[w] = nv;
             }
         }
     }
 };
 
 // Cascade level 0: plain codes of a list of segments.  grid = n_seg, block = 64.
+template <int M>
 __global__ __launch_bounds__(64) void decode_segments_kernel(const DeviceImage img,
                                                               const uint32_t* __restrict__ seg_list,
                                                               uint32_t* __restrict__ out_id,
                                                               uint32_t* __restrict__ out_code) {
+    constexpr int W = Cfg<M>::W;
     __shared__ uint4 dtab[256];
     const int lane = threadIdx.x;
     for (int i = lane; i < 256; i += 64) dtab[i] = make_decode_entry((uint32_t)i);
@@ -235,34 +266,37 @@ __global__ __launch_bounds__(64) void decode_segments_kernel(const DeviceImage i
     const uint32_t seg = seg_list ? seg_list[blockIdx.x] : blockIdx.x;
     const uint64_t lt_mask = (1ull << lane) - 1ull;
     const int cps = img.chunks_per_segment;
-    WaveDecoder dec;
+    WaveDecoder<M> dec;
     dec.begin_segment(img, seg, lane);
     for (int c = 0; c < cps; ++c) {
         const int64_t node = ((int64_t)seg * cps + c) * 64 + lane;
-        uint32_t code_lo, code_hi;
-        dec.step(img, node, lane, lt_mask, dtab, c + 1 < cps, code_lo, code_hi);
+        uint32_t code[W];
+        dec.step(img, node, lane, lt_mask, dtab, c + 1 < cps, code);
         const size_t o = ((size_t)blockIdx.x * cps + c) * 64 + lane;
         out_id[o] = node < img.n_local ? img.id_base + (uint32_t)node : 0xffffffffu;
-        out_code[2 * o] = code_lo;
-        out_code[2 * o + 1] = code_hi;
+#pragma unroll
+        for (int w = 0; w < W; ++w) out_code[W * o + w] = code[w];
     }
 }
 
 // ---------------------------------------------------------------------------
-// scan: decode + ADC filter for 32 queries per workgroup
+// scan: decode + ADC filter for QG queries per workgroup
 // ---------------------------------------------------------------------------
+template <int M>
 __global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanArgs a) {
-    constexpr int QG = kQG;       // 32 queries
-    constexpr int NG = QG / 8;    // 16-byte table entries hold 8 queries
-    constexpr int NA = QG / 2;    // packed u16 accumulators (dwords)
+    constexpr int W = Cfg<M>::W;
+    constexpr int QG = Cfg<M>::QG;
+    constexpr int NG = Cfg<M>::NG;
+    constexpr int NA = Cfg<M>::NA;
+    constexpr int TE = M * 256;  // table entries per query
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint4* lut = reinterpret_cast<uint4*>(smem);                                   // [NG][8][256] x 16 B = 128 KB
-    uint4* dtab = reinterpret_cast<uint4*>(smem + (size_t)NG * 8 * 256 * 16);      // [256]
+    uint4* lut = reinterpret_cast<uint4*>(smem);                                   // [NG][M][256] x 16 B = 128 KB
+    uint4* dtab = reinterpret_cast<uint4*>(smem + (size_t)NG * TE * 16);           // [256]
     // candidate staging: survivors are appended with LDS atomics and flushed to
     // HBM once per workgroup (one global atomic per query), see the epilogue
-    uint32_t* stg_count = reinterpret_cast<uint32_t*>(smem + (size_t)NG * 8 * 256 * 16 + 4096);  // [QG]
-    uint32_t* stg_id = stg_count + QG;                                                             // [QG][kStage]
-    uint32_t* stg_code = stg_id + QG * kStage;                                                     // [QG][kStage][2]
+    uint32_t* stg_count = reinterpret_cast<uint32_t*>(smem + (size_t)NG * TE * 16 + 4096);  // [QG]
+    uint32_t* stg_id = stg_count + 32;                                                        // [QG][kStage]
+    uint32_t* stg_code = stg_id + QG * kStage;                                                // [QG][kStage][W]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -270,21 +304,21 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanArgs a) {
     const int group = blockIdx.y;
     const int slot0 = group * QG;
 
-    // ---- prologue: quantise the 32 queries' exact tables into conservative
-    // 13-bit filter tables (two per dword), straight into LDS.  For slot q with threshold tau:
-    //   entry[m][k] = floor((T[m][k] - min_m) * s)   rounded DOWN, saturated at 8191
+    // ---- prologue: quantise the QG queries' exact tables into conservative
+    // lower-bound tables (two per dword), straight into LDS.  For slot q with threshold tau:
+    //   entry[m][k] = floor((T[m][k] - min_m) * s)   rounded DOWN, saturated at SAT = 65535 / M
     //   node passes iff sum_m entry[m][c_m] <= Q = ceil((tau' - sum_m min_m) * s)
-    //   s = 7500 / (tau' - sum_m min_m),  tau' = tau * (1 + 2^-23)  (fp32 rounding of the exact distance)
+    //   s = QTARGET / (tau' - sum_m min_m),  tau' = tau * (1 + 2^-23)  (fp32 rounding of the exact distance)
     // A node with exact distance <= tau has sum entry <= (d - sum min) * s <= Q;
-    // a saturated entry (8191 > Q) can only belong to a node with d > tau; and
-    // 8 entries <= 8191 cannot overflow 16 bits, so packed pairs are summed with
+    // a saturated entry (SAT > Q) can only belong to a node with d > tau; and
+    // M entries <= SAT cannot overflow 16 bits, so packed pairs are summed with
     // plain 32-bit adds (v_add3_u32) without carries crossing the halves.
     // Computed as fma(T, s32, -off) in fp32: off >= min * s32 (rounded up), one
     // rounding of the result, and s32 carries a (1 - 2^-20) factor, so every
     // entry is <= the exact real value (conservative).
     float* q_scale = reinterpret_cast<float*>(stg_id);               // [QG]      (staging area is free until the scan loop)
-    float* q_off = q_scale + QG;                                      // [8][QG]   min_m * scale, rounded UP
-    int32_t* q_base = reinterpret_cast<int32_t*>(q_off + 8 * QG);     // [QG]      row offset of the query's tables, -1 = unused
+    float* q_off = q_scale + QG;                                      // [M][QG]   min_m * scale, rounded UP
+    int32_t* q_base = reinterpret_cast<int32_t*>(q_off + M * QG);     // [QG]      row offset of the query's tables, -1 = unused
     uint16_t* q_thr = reinterpret_cast<uint16_t*>(q_base + QG);       // [QG]      accept bound + 1
     if (tid < 256) dtab[tid] = make_decode_entry((uint32_t)tid);
     if (tid < QG) {
@@ -292,23 +326,23 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanArgs a) {
         int qq = a.slot_query ? a.slot_query[slot] : (slot < a.n_queries ? slot : -1);
         float s32 = 0.0f;
         uint32_t qb = 0;  // accept bound + 1; 0 = nothing passes
-        float mn[8];
+        float mn[M];
 #pragma unroll
-        for (int m = 0; m < 8; ++m) mn[m] = 0.0f;
+        for (int m = 0; m < M; ++m) mn[m] = 0.0f;
         if (qq >= 0 && a.debug_pass != 1) {
             const uint64_t key = a.thr_key[slot];
             double B = 0.0;
 #pragma unroll
-            for (int m = 0; m < 8; ++m) {
-                mn[m] = a.lut_min[(size_t)qq * 8 + m];
+            for (int m = 0; m < M; ++m) {
+                mn[m] = a.lut_min[(size_t)qq * M + m];
                 B += (double)mn[m];
             }
             const double taup = (double)__uint_as_float((uint32_t)(key >> 32)) * (1.0 + 0x1p-23);
             const double R = taup - B;
             if (key != ~0ull && a.debug_pass != 2 && R > 0.0 && R < 1e300) {
-                const double s = 7500.0 / R;
+                const double s = (double)Cfg<M>::QTARGET / R;
                 s32 = (float)(s * (1.0 - 0x1p-20));
-                qb = (uint32_t)ceil(R * s * (1.0 + 0x1p-40)) + 1u;  // ~7502
+                qb = (uint32_t)ceil(R * s * (1.0 + 0x1p-40)) + 1u;
             } else {
                 s32 = 0.0f;  // no threshold yet (or degenerate): all entries 0, everything passes
                 qb = 1u;
@@ -318,22 +352,22 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanArgs a) {
         }
         q_scale[tid] = s32;
 #pragma unroll
-        for (int m = 0; m < 8; ++m) {
+        for (int m = 0; m < M; ++m) {
             // entry = fma(T, s32, -off) with off >= min*s32 (rounded up): never above (T - min) * s32
             const double od = (double)mn[m] * (double)s32;
             float of = (float)od;
             if ((double)of < od) of = __uint_as_float(__float_as_uint(of) + 1u);  // od >= 0: next float up
             q_off[m * QG + tid] = of;
         }
-        q_base[tid] = qq >= 0 ? qq * 2048 : -1;
+        q_base[tid] = qq >= 0 ? qq * TE : -1;
         q_thr[tid] = (uint16_t)qb;
-        stg_count[tid] = 0;
     }
+    if (tid < 32) stg_count[tid] = 0;
     __syncthreads();
     // one (g, m, k) tuple = one 16-byte LDS entry = 8 queries; global reads are coalesced over k,
     // the per-(query, m) constants come from broadcast ds_read_b128
-    for (int e = tid; e < NG * 8 * 256; e += kScanThreads) {
-        const int g = e >> 11, mk = e & 2047, m = mk >> 8;
+    for (int e = tid; e < NG * TE; e += kScanThreads) {
+        const int g = e / TE, mk = e % TE, m = mk >> 8;
         const int4 b0 = *reinterpret_cast<const int4*>(q_base + g * 8), b1 = *reinterpret_cast<const int4*>(q_base + g * 8 + 4);
         const float4 s0 = *reinterpret_cast<const float4*>(q_scale + g * 8), s1 = *reinterpret_cast<const float4*>(q_scale + g * 8 + 4);
         const float4 o0 = *reinterpret_cast<const float4*>(q_off + m * QG + g * 8),
@@ -349,8 +383,8 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanArgs a) {
         for (int j = 0; j < 8; ++j) {
             const float f = __fmaf_rn(t[j], sc[j], -of[j]);
             // f < 0 only by the round-up of `of` (true value 0); NaN/inf (unused slot, k >= K) saturate
-            v[j] = f < 8191.0f ? (f > 0.0f ? (uint32_t)f : 0u) : 8191u;
-            if (base[j] < 0) v[j] = 8191u;
+            v[j] = f < (float)Cfg<M>::SAT ? (f > 0.0f ? (uint32_t)f : 0u) : (uint32_t)Cfg<M>::SAT;
+            if (base[j] < 0) v[j] = (uint32_t)Cfg<M>::SAT;
         }
         lut[e] = make_uint4(v[0] | (v[1] << 16), v[2] | (v[3] << 16), v[4] | (v[5] << 16), v[6] | (v[7] << 16));
     }
@@ -365,31 +399,40 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanArgs a) {
 
     const uint64_t lt_mask = (1ull << lane) - 1ull;
     const int cps = a.img.chunks_per_segment;
-    WaveDecoder dec;
+    WaveDecoder<M> dec;
 
     for (int s = blockIdx.x * kScanWaves + wave; s < a.n_seg_pass; s += gridDim.x * kScanWaves) {
         const uint32_t seg = (uint32_t)__builtin_amdgcn_readfirstlane(a.seg_list ? (int)a.seg_list[s] : s);
         dec.begin_segment(a.img, seg, lane);
         for (int c = 0; c < cps; ++c) {
             const int64_t node = ((int64_t)seg * cps + c) * 64 + lane;  // local position
-            uint32_t code_lo, code_hi;
-            dec.step(a.img, node, lane, lt_mask, dtab, c + 1 < cps, code_lo, code_hi);
+            uint32_t code[W];
+            dec.step(a.img, node, lane, lt_mask, dtab, c + 1 < cps, code);
 
-            // ---- ADC lower bound: 8 LDS gathers per 8 queries; 13-bit entries, two per
-            // dword, summed with 3-input integer adds (no carry can cross the halves) ----
+            // ---- ADC lower bound: M LDS gathers per 8 queries; entries two per dword,
+            // summed with 3-input integer adds (no carry can cross the halves) ----
             uint32_t acc[NA];
 #pragma unroll
             for (int g = 0; g < NG; ++g) {
-                uint4 v[8];
+                uint32_t sx = 0, sy = 0, sz = 0, sw = 0;
 #pragma unroll
-                for (int m = 0; m < 8; ++m) {
-                    const uint32_t byte = ((m < 4 ? code_lo : code_hi) >> (8 * (m & 3))) & 0xffu;
-                    v[m] = lut[(g * 8 + m) * 256 + byte];
+                for (int m0 = 0; m0 < M; m0 += 8) {
+                    uint4 v[8];
+#pragma unroll
+                    for (int mm = 0; mm < 8; ++mm) {
+                        const int m = m0 + mm;
+                        const uint32_t byte = (code[m >> 2] >> (8 * (m & 3))) & 0xffu;
+                        v[mm] = lut[(g * M + m) * 256 + byte];
+                    }
+                    sx += ((v[0].x + v[1].x + v[2].x) + v[3].x + v[4].x) + (v[5].x + v[6].x + v[7].x);
+                    sy += ((v[0].y + v[1].y + v[2].y) + v[3].y + v[4].y) + (v[5].y + v[6].y + v[7].y);
+                    sz += ((v[0].z + v[1].z + v[2].z) + v[3].z + v[4].z) + (v[5].z + v[6].z + v[7].z);
+                    sw += ((v[0].w + v[1].w + v[2].w) + v[3].w + v[4].w) + (v[5].w + v[6].w + v[7].w);
                 }
-                acc[4 * g + 0] = ((v[0].x + v[1].x + v[2].x) + v[3].x + v[4].x) + (v[5].x + v[6].x + v[7].x);
-                acc[4 * g + 1] = ((v[0].y + v[1].y + v[2].y) + v[3].y + v[4].y) + (v[5].y + v[6].y + v[7].y);
-                acc[4 * g + 2] = ((v[0].z + v[1].z + v[2].z) + v[3].z + v[4].z) + (v[5].z + v[6].z + v[7].z);
-                acc[4 * g + 3] = ((v[0].w + v[1].w + v[2].w) + v[3].w + v[4].w) + (v[5].w + v[6].w + v[7].w);
+                acc[4 * g + 0] = sx;
+                acc[4 * g + 1] = sy;
+                acc[4 * g + 2] = sz;
+                acc[4 * g + 3] = sw;
             }
             // ---- filter (replaces the heap test h:2909-2914): keep iff bound <= accept bound ----
             const bool valid = node < a.img.n_local;
@@ -410,15 +453,15 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanArgs a) {
                                 const uint32_t li = atomicAdd(&stg_count[q], 1u);
                                 if (li < (uint32_t)kStage) {
                                     stg_id[q * kStage + li] = id;
-                                    stg_code[2 * (q * kStage + li)] = code_lo;
-                                    stg_code[2 * (q * kStage + li) + 1] = code_hi;
+#pragma unroll
+                                    for (int w = 0; w < W; ++w) stg_code[W * (q * kStage + li) + w] = code[w];
                                 } else {  // staging full: straight to HBM
                                     const uint32_t idx = atomicAdd(&a.cand_count[slot0 + q], 1u);
                                     if (idx < (uint32_t)a.cap) {
                                         const size_t o = (size_t)(slot0 + q) * a.cap + idx;
                                         a.cand_id[o] = id;
-                                        a.cand_code[2 * o] = code_lo;
-                                        a.cand_code[2 * o + 1] = code_hi;
+#pragma unroll
+                                        for (int w = 0; w < W; ++w) a.cand_code[W * o + w] = code[w];
                                     }
                                 }
                             }
@@ -442,8 +485,8 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanArgs a) {
             if (idx < (uint32_t)a.cap) {
                 const size_t o = (size_t)(slot0 + q) * a.cap + idx;
                 a.cand_id[o] = stg_id[q * kStage + i];
-                a.cand_code[2 * o] = stg_code[2 * (q * kStage + i)];
-                a.cand_code[2 * o + 1] = stg_code[2 * (q * kStage + i) + 1];
+#pragma unroll
+                for (int w = 0; w < W; ++w) a.cand_code[W * o + w] = stg_code[W * (q * kStage + i) + w];
             }
         }
     }
@@ -453,13 +496,14 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanArgs a) {
 // a6: select.  grid = slots, block = kSelectThreads, dynamic LDS
 // ---------------------------------------------------------------------------
 
-// exact distance: fp64 sum of the 8 fp32 entries, rounded to fp32 == the
+// exact distance: fp64 sum of the M fp32 entries, rounded to fp32 == the
 // reference's incremental fp64 stack (h:2889-2907), see DESIGN.md section 3
-__device__ __forceinline__ float exact_dist(const float* __restrict__ T, uint32_t c_lo, uint32_t c_hi) {
+template <int M>
+__device__ __forceinline__ float exact_dist(const float* __restrict__ T, const uint32_t* __restrict__ c) {
     double dsum = 0.0;
 #pragma unroll
-    for (int m = 0; m < 8; ++m) {
-        const uint32_t byte = ((m < 4 ? c_lo : c_hi) >> (8 * (m & 3))) & 0xffu;
+    for (int m = 0; m < M; ++m) {
+        const uint32_t byte = (c[m >> 2] >> (8 * (m & 3))) & 0xffu;
         dsum = __dadd_rn(dsum, (double)T[m * 256 + byte]);
     }
     return (float)dsum;
@@ -532,13 +576,16 @@ __device__ __forceinline__ int32_t report_id(uint32_t pos, int64_t n_total) {
     return (int32_t)pos;
 }
 
+template <int M>
 __global__ __launch_bounds__(kSelectThreads) void select_kernel(const SelectArgs a) {
+    constexpr int W = Cfg<M>::W;
+    constexpr int TE = M * 256;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint64_t* skeys = reinterpret_cast<uint64_t*>(smem);                              // [kSortMax] candidate keys
     uint64_t* wkeys = skeys + kSortMax;                                               // [kMaxTopK] winner keys
     uint32_t* win_id = reinterpret_cast<uint32_t*>(wkeys + kMaxTopK);                 // [kMaxTopK]
-    uint32_t* win_code = win_id + kMaxTopK;                                           // [kMaxTopK][2]
-    uint32_t* hist = win_code + 2 * kMaxTopK;                                         // [256]
+    uint32_t* win_code = win_id + kMaxTopK;                                           // [kMaxTopK][W]
+    uint32_t* hist = win_code + W * kMaxTopK;                                         // [256]
     uint32_t* bcast = hist + 256;                                                     // [2]
     uint32_t* counters = bcast + 2;                                                   // [2]: winners, padding nodes
 
@@ -546,12 +593,12 @@ __global__ __launch_bounds__(kSelectThreads) void select_kernel(const SelectArgs
     const int tid = threadIdx.x;
     const int q = a.slot_query ? a.slot_query[slot] : slot;
     if (q < 0) return;  // unused slot of a rerun group
-    const float* T = a.lut32 + (size_t)q * 2048;
+    const float* T = a.lut32 + (size_t)q * TE;
     const bool shared = a.shared_id != nullptr;
     const uint32_t cnt = shared ? (uint32_t)a.shared_n : a.cand_count[slot];
     const int n = shared ? a.shared_n : (int)min(cnt, (uint32_t)a.cap);
     const uint32_t* src_id = shared ? a.shared_id : a.cand_id + (size_t)slot * a.cap;
-    const uint32_t* src_code = shared ? a.shared_code : a.cand_code + (size_t)slot * a.cap * 2;
+    const uint32_t* src_code = shared ? a.shared_code : a.cand_code + (size_t)slot * a.cap * W;
     // keys live in LDS for the usual list sizes, in HBM scratch for huge ones (overflow reruns)
     uint64_t* keys = n <= kSortMax ? skeys : a.keys + (size_t)slot * a.cap;
     if (tid == 0) {
@@ -567,7 +614,7 @@ __global__ __launch_bounds__(kSelectThreads) void select_kernel(const SelectArgs
         const uint32_t id = src_id[i];
         uint64_t key = ~0ull;
         if (id != 0xffffffffu)
-            key = make_key(exact_dist(T, src_code[2 * i], src_code[2 * i + 1]), id);
+            key = make_key(exact_dist<M>(T, src_code + (size_t)W * i), id);
         else
             atomicAdd(&counters[1], 1u);  // padding node of the shared level-0 list
         keys[i] = key;
@@ -595,8 +642,8 @@ __global__ __launch_bounds__(kSelectThreads) void select_kernel(const SelectArgs
             if (pos < (uint32_t)kMaxTopK) {
                 wkeys[pos] = key;
                 win_id[pos] = src_id[i];
-                win_code[2 * pos] = src_code[2 * i];
-                win_code[2 * pos + 1] = src_code[2 * i + 1];
+#pragma unroll
+                for (int w = 0; w < W; ++w) win_code[W * pos + w] = src_code[(size_t)W * i + w];
             }
         }
     }
@@ -607,8 +654,8 @@ __global__ __launch_bounds__(kSelectThreads) void select_kernel(const SelectArgs
         for (int i = tid; i < kk; i += kSelectThreads) {
             const size_t o = (size_t)slot * a.cap + i;
             a.cand_id[o] = win_id[i];
-            a.cand_code[2 * o] = win_code[2 * i];
-            a.cand_code[2 * o + 1] = win_code[2 * i + 1];
+#pragma unroll
+            for (int w = 0; w < W; ++w) a.cand_code[W * o + w] = win_code[W * i + w];
         }
         if (tid == 0) a.cand_count[slot] = (uint32_t)kk;
         return;
@@ -669,13 +716,14 @@ __global__ __launch_bounds__(kSelectThreads) void merge_kernel(const int32_t* __
 // launchers
 // ---------------------------------------------------------------------------
 
-size_t scan_lds_bytes() {
-    return (size_t)(kQG / 8) * 8 * 256 * 16 + 256 * sizeof(uint4) + kQG * sizeof(uint32_t) +
-           (size_t)kQG * kStage * 3 * sizeof(uint32_t);
+size_t scan_lds_bytes(int M) {
+    const size_t QG = M <= 8 ? 32 : 16, W = (size_t)M / 4;
+    return (QG / 8) * (size_t)M * 256 * 16 + 256 * sizeof(uint4) + 32 * sizeof(uint32_t) +
+           QG * kStage * (1 + W) * sizeof(uint32_t);
 }
 
-size_t select_lds_bytes() {
-    return (size_t)kSortMax * 8 + (size_t)kMaxTopK * 8 + (size_t)kMaxTopK * 3 * 4 + (256 + 2 + 2) * 4;
+size_t select_lds_bytes(int M) {
+    return (size_t)kSortMax * 8 + (size_t)kMaxTopK * 8 + (size_t)kMaxTopK * (1 + M / 4) * 4 + (256 + 2 + 2) * 4;
 }
 
 // hipFuncSetAttribute is per device; handles may live on several GPUs
@@ -702,30 +750,49 @@ hipError_t launch_lut_build(const float* d_codebook, const float* d_queries, int
 hipError_t launch_decode_segments(const DeviceImage& img, const uint32_t* seg_list, int n_seg, uint32_t* out_id,
                                   uint32_t* out_code, hipStream_t stream) {
     if (n_seg <= 0) return hipSuccess;
-    if (img.M != 8) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(decode_segments_kernel, dim3((unsigned)n_seg), dim3(64), 0, stream, img, seg_list, out_id,
-                       out_code);
+    if (img.M == 8)
+        hipLaunchKernelGGL(decode_segments_kernel<8>, dim3((unsigned)n_seg), dim3(64), 0, stream, img, seg_list,
+                           out_id, out_code);
+    else if (img.M == 16)
+        hipLaunchKernelGGL(decode_segments_kernel<16>, dim3((unsigned)n_seg), dim3(64), 0, stream, img, seg_list,
+                           out_id, out_code);
+    else
+        return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+template <int M>
+static hipError_t launch_scan_m(const ScanArgs& a, int n_slot_groups, int splits, hipStream_t stream) {
+    static bool done[64] = {};
+    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&scan_kernel<M>), scan_lds_bytes(M), done);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(scan_kernel<M>, dim3((unsigned)splits, (unsigned)n_slot_groups), dim3(kScanThreads),
+                       scan_lds_bytes(M), stream, a);
     return hipGetLastError();
 }
 
 hipError_t launch_scan(const ScanArgs& a, int n_slot_groups, int splits, hipStream_t stream) {
-    if (a.img.M != 8) return hipErrorInvalidValue;
     if (a.n_seg_pass <= 0 || n_slot_groups <= 0) return hipSuccess;
+    if (a.img.M == 8) return launch_scan_m<8>(a, n_slot_groups, splits, stream);
+    if (a.img.M == 16) return launch_scan_m<16>(a, n_slot_groups, splits, stream);
+    return hipErrorInvalidValue;
+}
+
+template <int M>
+static hipError_t launch_select_m(const SelectArgs& a, int n_slots, hipStream_t stream) {
     static bool done[64] = {};
-    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&scan_kernel), scan_lds_bytes(), done);
+    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&select_kernel<M>), select_lds_bytes(M), done);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(scan_kernel, dim3((unsigned)splits, (unsigned)n_slot_groups), dim3(kScanThreads),
-                       scan_lds_bytes(), stream, a);
+    hipLaunchKernelGGL(select_kernel<M>, dim3((unsigned)n_slots), dim3(kSelectThreads), select_lds_bytes(M), stream,
+                       a);
     return hipGetLastError();
 }
 
-hipError_t launch_select(const SelectArgs& a, int n_slots, hipStream_t stream) {
+hipError_t launch_select(const SelectArgs& a, int M, int n_slots, hipStream_t stream) {
     if (n_slots <= 0) return hipSuccess;
-    static bool done[64] = {};
-    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&select_kernel), select_lds_bytes(), done);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(select_kernel, dim3((unsigned)n_slots), dim3(kSelectThreads), select_lds_bytes(), stream, a);
-    return hipGetLastError();
+    if (M == 8) return launch_select_m<8>(a, n_slots, stream);
+    if (M == 16) return launch_select_m<16>(a, n_slots, stream);
+    return hipErrorInvalidValue;
 }
 
 hipError_t launch_merge(const int32_t* d_ids, const float* d_dists, int n_lists, int nq, int top_k,

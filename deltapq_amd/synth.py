@@ -120,20 +120,22 @@ def encode_dtc(tree):
     a final unpaired node gets a full depth byte.  Returns (payload u8[], n_bytes)
     where n_bytes == M + n_diffs + (3*(N-1)+1)//2 (h:1765)."""
     M = tree["M"]
-    assert M <= 8, "the reference format is hard-wired to M <= 8 (h:1765, 1791-1795)"
+    # M <= 8 is the reference format (h:1765, 1791-1795).  M in 9..16 is this build's
+    # own extension (the reference has none): 2-byte little-endian masks, 4-bit depths.
+    mb = 1 if M <= 8 else 2
     depths, masks, deltas, root = tree["depths"], tree["masks"], tree["deltas"], tree["root"]
     n = len(depths)
-    assert n >= 1 and np.all(depths[1:] >= 1) and np.all(depths[1:] <= 7)
+    assert n >= 1 and np.all(depths[1:] >= 1) and np.all(depths[1:] <= (7 if M <= 8 else 15))
     pc = popcount16(masks)
     pc[0] = 0
     idx = np.arange(n, dtype=np.int64)
     # every odd node i >= 1 is preceded by one depth byte (shared with i+1, or alone)
     n_depth_bytes_before = (idx + 1) // 2                      # odd j <= i
-    size = 1 + pc                                              # mask byte + changed bytes
+    size = mb + pc                                             # mask byte(s) + changed bytes
     size[0] = 0
     cum = np.cumsum(size) - size                               # bytes of nodes 1..i-1
     mask_off = M + cum + n_depth_bytes_before                  # offset of node i's mask byte
-    n_bytes = M + int(pc.sum()) + (3 * (n - 1) + 1) // 2
+    n_bytes = M + int(pc.sum()) + mb * (n - 1) + n // 2        # == h:1765 for M == 8
     out = np.zeros(n_bytes, dtype=np.uint8)
     out[:M] = root
     if n > 1:
@@ -143,15 +145,17 @@ def encode_dtc(tree):
         has_pair = odd + 1 < n
         dbytes[has_pair] |= (depths[odd[has_pair] + 1].astype(np.uint8) << 4)
         out[depth_off] = dbytes
-        out[mask_off[1:]] = masks[1:].astype(np.uint8)
-        # changed bytes follow each node's mask byte
-        starts = mask_off[1:] + 1
+        out[mask_off[1:]] = (masks[1:] & 0xFF).astype(np.uint8)
+        if mb == 2:
+            out[mask_off[1:] + 1] = (masks[1:] >> 8).astype(np.uint8)
+        # changed bytes follow each node's mask byte(s)
+        starts = mask_off[1:] + mb
         reps = pc[1:]
         if reps.sum() > 0:
             base = np.repeat(starts, reps)
             within = np.arange(int(reps.sum()), dtype=np.int64) - np.repeat(np.cumsum(reps) - reps, reps)
             out[base + within] = deltas
-        last = mask_off[n - 1] + 1 + pc[n - 1]
+        last = mask_off[n - 1] + mb + pc[n - 1]
         assert last == n_bytes, (last, n_bytes)
     return out, n_bytes
 

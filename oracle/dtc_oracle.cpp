@@ -24,6 +24,12 @@
 //   * even-N quirk: the trailing node is reported with id N, not N-1 (h:2949,2970)
 //   * 3-bit depth fields in the pair byte, full byte for the trailing node
 //
+// M > 8 has NO reference semantics: the reference format is hard-wired to
+// M <= 8 (1-byte mask h:1791-1795, 3-bit depth h:2883, 8-byte parent copy h:2888)
+// and `-task query -m 16` crashes.  For M in 9..16 this file applies the same
+// stack machine to this build's own format extension (2-byte little-endian
+// masks, 4-bit depth fields) -- a consistency oracle, not a reference one.
+//
 // Build: see oracle/Makefile (g++ -O2 -ffp-contract=off).
 
 #include <algorithm>
@@ -140,20 +146,37 @@ void scan(Source& src, const float* lut, int top_k, int M, int K, long long num_
     if (all_dists) all_dists[0] = (float)qdist;
     if (all_codes) memcpy(all_codes, vecs_stack[0], M);
 
+    const int mask_bytes = M > 8 ? 2 : 1;               // M > 8: this build's format extension
+    const int dmask = M > 8 ? 15 : 7;                   // h:2883 uses & 7
     auto process = [&](int depth, long id_to_report, long pos, bool store_dist) {
         // h:2888: parent copy (one 8-byte word for M == 8; bytewise otherwise,
         // as the trailing-node branch h:2954-2955 does)
         memcpy(vecs_stack[depth], vecs_stack[depth - 1], M);
         double dist = dists_stack[depth - 1];           // h:2889
-        uchar bitmap = (uchar)src.next();               // h:2891
-        int n_diff = g_decoder.tab[bitmap][0];
-        for (int j = 0; j < n_diff; j++) {              // h:2896-2905
-            int m = g_decoder.tab[bitmap][j + 1];
-            uchar cid = (uchar)src.next();
-            vecs_stack[depth][m] = cid;
-            uchar from = vecs_stack[depth - 1][m];
-            dist -= lut[(size_t)m * K + from];
-            dist += lut[(size_t)m * K + cid];
+        for (int mb = 0; mb < mask_bytes; mb++) {       // bitmap byte(s), low positions first
+            uchar bitmap = (uchar)src.next();           // h:2891
+            if (mb == 0 && mask_bytes == 2) {           // both mask bytes precede the changed bytes
+                uchar hi = (uchar)src.next();
+                int n_lo = g_decoder.tab[bitmap][0], n_hi = g_decoder.tab[hi][0];
+                for (int j = 0; j < n_lo + n_hi; j++) {
+                    int m = j < n_lo ? g_decoder.tab[bitmap][j + 1] : 8 + g_decoder.tab[hi][j - n_lo + 1];
+                    uchar cid = (uchar)src.next();
+                    vecs_stack[depth][m] = cid;
+                    uchar from = vecs_stack[depth - 1][m];
+                    dist -= lut[(size_t)m * K + from];
+                    dist += lut[(size_t)m * K + cid];
+                }
+                break;
+            }
+            int n_diff = g_decoder.tab[bitmap][0];
+            for (int j = 0; j < n_diff; j++) {          // h:2896-2905
+                int m = g_decoder.tab[bitmap][j + 1];
+                uchar cid = (uchar)src.next();
+                vecs_stack[depth][m] = cid;
+                uchar from = vecs_stack[depth - 1][m];
+                dist -= lut[(size_t)m * K + from];
+                dist += lut[(size_t)m * K + cid];
+            }
         }
         if (store_dist) dists_stack[depth] = dist;      // h:2907 (not in the trailing branch)
         if ((int)max_heap.size() < top_k) {             // h:2909-2914
@@ -169,8 +192,8 @@ void scan(Source& src, const float* lut, int top_k, int M, int K, long long num_
     long i = 1;
     for (; i + 1 < (long)num_codes; i = i + 2) {        // h:2876
         int depths = src.next();
-        process(depths & 7, i, i, true);                // h:2883
-        process((depths >> 4) & 7, i + 1, i + 1, true); // h:2916
+        process(depths & dmask, i, i, true);                // h:2883
+        process((depths >> 4) & dmask, i + 1, i + 1, true); // h:2916
     }
     if (i == (long)num_codes - 1) {                     // h:2949: trailing node
         int depth = src.next();                         // whole byte

@@ -28,7 +28,7 @@ def decode_soa(soa, M=8):
                 break
             nb = soa.nib[l >> 1]
             d = (nb >> 4) if (l & 1) else (nb & 15)
-            mk = int(soa.mask[l])
+            mk = int(soa.mask[l]) if M <= 8 else int(soa.mask[2 * l]) | (int(soa.mask[2 * l + 1]) << 8)
             c = stack[d - 1].copy() if d > 0 else np.zeros(M, np.uint8)
             for m in range(M):
                 if (mk >> m) & 1:
@@ -54,6 +54,26 @@ def test_transcode_is_lossless(lib, n, cps):
     tables = soa.seg_delta_off.nbytes + soa.seg_ckpt.nbytes
     pad = soa.info["n_segments"] * 64 * cps - n
     assert soa.info["device_bytes"] - tables <= nb + 1 + 1.5 * pad + 40
+
+
+@pytest.mark.parametrize("n", [1, 2, 65, 1000, 1001])
+def test_m16_extension_is_lossless(lib, oracle, n):
+    """M = 16 has no reference format (h:1765, 1791-1795 stop at M = 8): this build's
+    extension (2-byte masks, 4-bit depths) must still round-trip every code."""
+    from deltapq_amd import api, synth
+    tree = synth.synth_tree(n, 16, seed=n, mean_diffs=5.0)
+    payload, nb = synth.encode_dtc(tree)
+    codes = synth.decode_tree_codes(tree)
+    assert np.array_equal(api.dtc_encode(tree["root"], tree["depths"], tree["masks"], tree["deltas"], 16), payload)
+    st = api.dtc_validate(payload, n, 16)
+    assert st["n_bytes"] == nb and st["max_depth"] <= 15
+    soa = api.HostSoA(payload, n, 16, chunks_per_segment=2)
+    assert np.array_equal(decode_soa(soa, 16), codes)
+    lut = np.random.default_rng(0).random((16, 256)).astype(np.float32)
+    _, _, alld, allc = oracle.scan_lut(payload, n, lut, 1, want_all=True)
+    assert np.array_equal(allc, codes)
+    s = sum(lut[m, codes[:, m]].astype(np.float64) for m in range(16)).astype(np.float32)
+    assert np.array_equal(s.view(np.uint32), alld.view(np.uint32))
 
 
 def test_c_encoder_matches_reference_layout(lib):

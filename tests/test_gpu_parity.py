@@ -23,8 +23,8 @@ def gpu(lib):
     return api
 
 
-def run(gpu, payload, n, cb, qs, k, **kw):
-    with gpu.DeltaPQIndex.open_memory(payload, n, 8, 256, **kw) as idx:
+def run(gpu, payload, n, cb, qs, k, M=8, **kw):
+    with gpu.DeltaPQIndex.open_memory(payload, n, M, 256, **kw) as idx:
         idx.set_codebook(cb)
         idx.profile_enable(True)
         ids, dists = idx.query_batch(qs, k)
@@ -310,3 +310,46 @@ def test_two_process_sharded_run_on_one_gpu(gpu, built):
            os.path.join(ROOT, "tests", "_dist_gpu_worker.py")]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert r.returncode == 0 and "DIST_GPU_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+M16_SHAPES = [(1, 3, 1), (2, 2, 2), (65, 5, 10), (1000, 20, 10), (10000, 50, 100), (100001, 40, 1000), (300000, 33, 100)]
+
+
+@pytest.mark.parametrize("n,nq,k", M16_SHAPES)
+def test_m16_parity(gpu, oracle, n, nq, k):
+    """BASELINE configs[2] family (16-byte codes).  The reference has no M = 16 query
+    (format hard-wired to M <= 8), so the oracle here is the same stack machine on
+    this build's format extension: a consistency check, plus losslessness."""
+    from deltapq_amd import synth
+    cb = synth.make_codebook(16, 256, 8, seed=3)
+    tree = synth.synth_tree(n, 16, seed=n + 1, mean_diffs=5.0)
+    payload, nb = synth.encode_dtc(tree)
+    qs = synth.make_queries(nq, 128, seed=n + 2)
+    ids, dists, prof, info = run(gpu, payload, n, cb, qs, k, M=16)
+    assert info["algorithmic_bytes"] == nb and info["M"] == 16
+    assert_parity(ids, dists, oracle_topk(oracle, payload, n, cb, qs, k), n)
+
+
+def test_m16_sift1m_shape_top1000(gpu, oracle):
+    """BASELINE configs[2] at full size: 1M 16-byte codes, top-1000, sharded 2 ways as well."""
+    from deltapq_amd import synth
+    n, nq, k = 1_000_000, 48, 1000
+    cb = synth.make_codebook(16, 256, 8, seed=5)
+    tree = synth.synth_tree(n, 16, seed=6, mean_diffs=5.0)
+    payload, nb = synth.encode_dtc(tree)
+    codes = synth.decode_tree_codes(tree)
+    del tree
+    qs = synth.make_queries(nq, 128, seed=7)
+    ids, dists, prof, info = run(gpu, payload, n, cb, qs, k, M=16)
+    sample = [0, 17, 47]
+    assert_parity(ids[sample], dists[sample], oracle_topk(oracle, payload, n, cb, qs[sample], k), n)
+    assert np.all(np.diff(dists, axis=1) >= 0)
+    for r in range(nq):
+        assert len(set(ids[r].tolist())) == k
+        lut = oracle.build_lut(cb, qs[r])
+        pos = np.where(ids[r] == n, n - 1, ids[r])
+        s = sum(lut[m, codes[pos, m]].astype(np.float64) for m in range(16)).astype(np.float32)
+        assert np.array_equal(s.view(np.uint32), dists[r].view(np.uint32))
+    parts = [run(gpu, payload, n, cb, qs[sample], k, M=16, shard_rank=r, shard_count=2)[:2] for r in range(2)]
+    mi, md = gpu.merge_topk_host(np.stack([p[0] for p in parts]), np.stack([p[1] for p in parts]))
+    assert np.array_equal(md.view(np.uint32), dists[sample].view(np.uint32))
