@@ -60,6 +60,17 @@ SYMBOLS = [
     ("dpq_soa_array", ctypes.c_int, [_VP, ctypes.c_int, P(_VP), P(c_i64)]),
     ("dpq_soa_free", None, [_VP]),
     ("dpq_dtc_encode", ctypes.c_int, [_VP, _VP, _VP, _VP, c_i64, ctypes.c_int, _VP, P(c_i64)]),
+    ("dpq_tree_build", ctypes.c_int, [_VP, c_i64, ctypes.c_int, ctypes.c_int, ctypes.c_int, _VP, ctypes.c_int, P(_VP)]),
+    ("dpq_tree_stats", ctypes.c_int, [_VP, P(DtcStats)]),
+    ("dpq_tree_array", ctypes.c_int, [_VP, ctypes.c_int, P(_VP), P(c_i64)]),
+    ("dpq_tree_encode", ctypes.c_int, [_VP, _VP, P(c_i64)]),
+    ("dpq_tree_write_files", ctypes.c_int, [_VP, ctypes.c_char_p]),
+    ("dpq_tree_free", None, [_VP]),
+    ("dpq_read_qnode_ids", ctypes.c_int, [ctypes.c_char_p, c_i64, _VP]),
+    ("dpq_read_codes_plain", ctypes.c_int, [ctypes.c_char_p, ctypes.c_int, P(c_i64), _VP]),
+    ("dpq_write_codes_plain", ctypes.c_int, [ctypes.c_char_p, _VP, c_i64, ctypes.c_int]),
+    ("dpq_encode_pq", ctypes.c_int,
+     [_VP, c_i64, ctypes.c_int, _VP, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _VP]),
     ("dpq_open_file", ctypes.c_int, [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, P(OpenOpts), P(_VP)]),
     ("dpq_open_memory", ctypes.c_int, [_VP, c_i64, c_i64, ctypes.c_int, ctypes.c_int, P(OpenOpts), P(_VP)]),
     ("dpq_set_codebook", ctypes.c_int, [_VP, _VP, ctypes.c_int]),

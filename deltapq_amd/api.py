@@ -100,6 +100,92 @@ class HostSoA:
         self._h = None
 
 
+class DeltaTree:
+    """DeltaTree built from raw PQ codes on the host (`deltapq -task approx_tree`, method 1;
+    create_approx_tree, deltapq_create_approx_tree.h:970-1065)."""
+
+    _ARRAYS = [("vec_id", np.uint32), ("parent_pos", np.uint32), ("depth", np.uint8), ("mask", np.uint16),
+               ("deltas", np.uint8), ("root", np.uint8), ("edges", np.uint32)]
+
+    def __init__(self, codes, K=256, max_height_folds=1, codebook=None):
+        lib = _lib.load()
+        self._lib = lib
+        c = np.ascontiguousarray(codes, dtype=np.uint8)
+        assert c.ndim == 2
+        n, M = c.shape
+        cb = None if codebook is None else np.ascontiguousarray(codebook, dtype=np.float32)
+        h = ctypes.c_void_p()
+        check(lib.dpq_tree_build(_np_ptr(c), n, M, K, max_height_folds, None if cb is None else _np_ptr(cb),
+                                 0 if cb is None else cb.shape[2], h), "dpq_tree_build")
+        self._h = h
+        self.M, self.K, self.n = M, K, n
+        st = _lib.DtcStats()
+        check(lib.dpq_tree_stats(h, st), "dpq_tree_stats")
+        self.stats = dict(n_codes=st.n_codes, n_bytes=st.n_bytes, n_diffs=st.n_diffs, max_depth=st.max_depth,
+                          depth_hist=list(st.depth_hist))
+        for which, (name, dt) in enumerate(self._ARRAYS):
+            ptr, nb = ctypes.c_void_p(), _lib.c_i64()
+            check(lib.dpq_tree_array(h, which, ptr, nb), "dpq_tree_array")
+            buf = (ctypes.c_ubyte * nb.value).from_address(ptr.value) if nb.value else b""
+            setattr(self, name, np.frombuffer(buf, dtype=np.uint8).copy().view(dt))
+        self.edges = self.edges.reshape(-1, 2)
+
+    def payload(self):
+        nb = _lib.c_i64()
+        check(self._lib.dpq_tree_encode(self._h, None, nb), "dpq_tree_encode")
+        out = np.empty(nb.value, dtype=np.uint8)
+        check(self._lib.dpq_tree_encode(self._h, _np_ptr(out), nb), "dpq_tree_encode")
+        return out
+
+    def write_files(self, dataset_dir):
+        check(self._lib.dpq_tree_write_files(self._h, dataset_dir.encode()), "dpq_tree_write_files")
+
+    def close(self):
+        if self._h is not None:
+            self._lib.dpq_tree_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def encode_pq(vectors, codebook, device=0):
+    """PQTree::EncodePlain (pq_tree.cpp:215-237) on the GPU: uint8 codes [n][M]."""
+    lib = _lib.load()
+    v = np.ascontiguousarray(vectors, dtype=np.float32)
+    cb = np.ascontiguousarray(codebook, dtype=np.float32)
+    M, K, Ds = cb.shape
+    out = np.empty((v.shape[0], M), dtype=np.uint8)
+    check(lib.dpq_encode_pq(_np_ptr(v), v.shape[0], v.shape[1], _np_ptr(cb), M, K, Ds, device, _np_ptr(out)),
+          "dpq_encode_pq")
+    return out
+
+
+def read_codes_plain(path, M):
+    """PQTree::Read (pq_tree.cpp:1032-1081): uint8 [N][M]."""
+    lib = _lib.load()
+    n = _lib.c_i64()
+    check(lib.dpq_read_codes_plain(path.encode(), M, n, None), "dpq_read_codes_plain")
+    out = np.empty((n.value, M), dtype=np.uint8)
+    check(lib.dpq_read_codes_plain(path.encode(), M, n, _np_ptr(out)), "dpq_read_codes_plain")
+    return out
+
+
+def write_codes_plain(path, codes):
+    c = np.ascontiguousarray(codes, dtype=np.uint8)
+    check(_lib.load().dpq_write_codes_plain(path.encode(), _np_ptr(c), c.shape[0], c.shape[1]), "dpq_write_codes_plain")
+
+
+def read_qnode_ids(path, n_codes):
+    """DFS position -> original vector id (QNode.vec_id) from a TreeNodesDFS file."""
+    out = np.empty(n_codes, dtype=np.uint32)
+    check(_lib.load().dpq_read_qnode_ids(path.encode(), n_codes, _np_ptr(out)), "dpq_read_qnode_ids")
+    return out
+
+
 class DeltaPQIndex:
     """One DTC index (or one shard) resident on one MI355X."""
 

@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "../../include/deltapq_amd.h"
+#include "dpq_build.h"
 #include "dpq_format.h"
 #include "dpq_kernels.h"
 
@@ -55,6 +56,10 @@ constexpr int kMaxBatchQueries = 2048;
 
 struct dpq_soa {
     dpq::SoA soa;
+};
+
+struct dpq_tree {
+    dpq::Tree tree;
 };
 
 struct dpq_index {
@@ -637,6 +642,129 @@ int dpq_dtc_encode(const uint8_t* root_code, const uint8_t* depths, const uint16
     std::string err;
     int rc = dpq::encode(root_code, depths, masks, deltas, n_codes, M, out, n_bytes, &err);
     return rc ? fail(rc, err) : DPQ_OK;
+}
+
+int dpq_tree_build(const uint8_t* codes, int64_t n_codes, int M, int K, int max_height_folds, const float* codewords,
+                   int Ds, dpq_tree** out) {
+    if (!out) return fail(DPQ_ERR_ARG, "out is NULL");
+    *out = nullptr;
+    dpq_tree* t = new dpq_tree();
+    std::string err;
+    int rc = dpq::build_tree(codes, n_codes, M, K, max_height_folds, codewords, Ds, &t->tree, &err);
+    if (rc) {
+        delete t;
+        return fail(rc, err);
+    }
+    *out = t;
+    return DPQ_OK;
+}
+
+int dpq_tree_stats(const dpq_tree* t, dpq_dtc_stats* stats) {
+    if (!t || !stats) return fail(DPQ_ERR_ARG, "NULL argument");
+    const dpq::Tree& tr = t->tree;
+    memset(stats, 0, sizeof *stats);
+    stats->n_codes = tr.n;
+    stats->n_diffs = tr.n_diffs;
+    stats->n_bytes = tr.M + tr.n_diffs + (tr.n - 1) * dpq::mask_bytes_for(tr.M) + tr.n / 2;  // h:1765 for M = 8
+    for (int d = 0; d < 16; ++d) stats->depth_hist[d] = tr.depth_hist[d];
+    stats->max_depth = tr.max_depth;
+    stats->M = tr.M;
+    return DPQ_OK;
+}
+
+int dpq_tree_array(const dpq_tree* t, int which, const void** ptr, int64_t* n_bytes) {
+    if (!t || !ptr || !n_bytes) return fail(DPQ_ERR_ARG, "NULL argument");
+    const dpq::Tree& tr = t->tree;
+    switch (which) {
+        case 0: *ptr = tr.vec_id.data(); *n_bytes = (int64_t)tr.vec_id.size() * 4; break;
+        case 1: *ptr = tr.parent_pos.data(); *n_bytes = (int64_t)tr.parent_pos.size() * 4; break;
+        case 2: *ptr = tr.depth.data(); *n_bytes = (int64_t)tr.depth.size(); break;
+        case 3: *ptr = tr.mask.data(); *n_bytes = (int64_t)tr.mask.size() * 2; break;
+        case 4: *ptr = tr.deltas.data(); *n_bytes = (int64_t)tr.deltas.size(); break;
+        case 5: *ptr = tr.root_code.data(); *n_bytes = (int64_t)tr.root_code.size(); break;
+        case 6: *ptr = tr.edges.data(); *n_bytes = (int64_t)tr.edges.size() * 8; break;
+        default: return fail(DPQ_ERR_ARG, "which must be 0..6");
+    }
+    return DPQ_OK;
+}
+
+int dpq_tree_encode(const dpq_tree* t, uint8_t* out, int64_t* n_bytes) {
+    if (!t || !n_bytes) return fail(DPQ_ERR_ARG, "NULL argument");
+    const dpq::Tree& tr = t->tree;
+    std::string err;
+    int rc = dpq::encode(tr.root_code.data(), tr.depth.data(), tr.mask.data(), tr.deltas.data(), tr.n, tr.M, out,
+                         n_bytes, &err);
+    return rc ? fail(rc, err) : DPQ_OK;
+}
+
+int dpq_tree_write_files(const dpq_tree* t, const char* dataset_dir) {
+    if (!t || !dataset_dir) return fail(DPQ_ERR_ARG, "NULL argument");
+    std::string err;
+    int rc = dpq::tree_write_files(t->tree, dataset_dir, &err);
+    return rc ? fail(rc, err) : DPQ_OK;
+}
+
+void dpq_tree_free(dpq_tree* t) { delete t; }
+
+int dpq_read_qnode_ids(const char* path, int64_t n_codes, uint32_t* vec_ids) {
+    if (!path || !vec_ids || n_codes < 0) return fail(DPQ_ERR_ARG, "bad argument");
+    std::vector<uint32_t> ids;
+    std::string err;
+    int rc = dpq::read_qnode_ids(path, n_codes, &ids, &err);
+    if (rc) return fail(rc, err);
+    memcpy(vec_ids, ids.data(), ids.size() * 4);
+    return DPQ_OK;
+}
+
+int dpq_read_codes_plain(const char* path, int M, int64_t* n_codes, uint8_t* out) {
+    if (!path || !n_codes || M < 1) return fail(DPQ_ERR_ARG, "bad argument");
+    std::vector<uint8_t> codes;
+    std::string err;
+    int rc = dpq::read_codes_plain(path, M, n_codes, out ? &codes : nullptr, &err);
+    if (rc) return fail(rc, err);
+    if (out) memcpy(out, codes.data(), codes.size());
+    return DPQ_OK;
+}
+
+int dpq_write_codes_plain(const char* path, const uint8_t* codes, int64_t n_codes, int M) {
+    if (!path || (!codes && n_codes > 0) || n_codes < 0 || M < 1) return fail(DPQ_ERR_ARG, "bad argument");
+    std::string err;
+    int rc = dpq::write_codes_plain(path, codes, n_codes, M, &err);
+    return rc ? fail(rc, err) : DPQ_OK;
+}
+
+int dpq_encode_pq(const float* vectors, int64_t n, int D, const float* codewords, int M, int K, int Ds, int device,
+                  uint8_t* codes_out) {
+    if (!vectors || !codewords || !codes_out || n < 0 || D < 1 || M < 1 || K < 1 || K > 256 || Ds < 1)
+        return fail(DPQ_ERR_ARG, "bad argument to dpq_encode_pq");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(DPQ_ERR_NO_DEVICE, "no HIP device visible; this library has no CPU fallback");
+    if (device < 0 || device >= ndev) return fail(DPQ_ERR_NO_DEVICE, "device ordinal out of range");
+    if (n == 0) return DPQ_OK;
+    DPQ_HIP(hipSetDevice(device));
+    float *d_v = nullptr, *d_c = nullptr;
+    uint8_t* d_o = nullptr;
+    const int64_t tile = 1 << 20;  // vectors per upload
+    int rc = dev_alloc(&d_v, (size_t)std::min(n, tile) * D);
+    if (!rc) rc = dev_alloc(&d_c, (size_t)M * K * Ds);
+    if (!rc) rc = dev_alloc(&d_o, (size_t)std::min(n, tile) * M);
+    hipError_t e = hipSuccess;
+    if (!rc) {
+        e = hipMemcpy(d_c, codewords, (size_t)M * K * Ds * sizeof(float), hipMemcpyHostToDevice);
+        for (int64_t base = 0; base < n && e == hipSuccess; base += tile) {
+            const int64_t m = std::min(tile, n - base);
+            e = hipMemcpy(d_v, vectors + (size_t)base * D, (size_t)m * D * sizeof(float), hipMemcpyHostToDevice);
+            if (e == hipSuccess) e = dpq::launch_encode_pq(d_v, m, D, d_c, M, K, Ds, d_o, nullptr);
+            if (e == hipSuccess) e = hipMemcpy(codes_out + (size_t)base * M, d_o, (size_t)m * M, hipMemcpyDeviceToHost);
+        }
+    }
+    hipFree(d_v);
+    hipFree(d_c);
+    hipFree(d_o);
+    if (rc) return rc;
+    if (e != hipSuccess) return fail(DPQ_ERR_HIP, std::string("dpq_encode_pq: ") + hipGetErrorString(e));
+    return DPQ_OK;
 }
 
 int dpq_open_file(const char* path, int M, int K, const dpq_open_opts* opts, dpq_index** out) {

@@ -3,7 +3,7 @@
 //
 // Mirrors the flag surface and output of the reference driver
 // (/root/reference/deltapq_approx_tree_main.cpp:14-70 flags, :265-349 `-task
-// query`, :617-710 `-task query_im`):
+// query`, :617-710 `-task query_im`, :72-149 `-task approx_tree` with -method 1):
 //
 //   deltapq -dataset DIR -task query -m 8 -k 256 -h 1 -diff 8 -N 1000000
 //           -query_size 1000 -topk 100 [-ext fvecs|bvecs] [-debug]
@@ -62,10 +62,56 @@ int main(int argc, char* argv[]) {
         if (arg == "-gpus") gpus = atoi(nx);
         if (arg == "-out") out_path = nx;
     }
-    (void)diff_argument; (void)max_height_folds; (void)method; (void)queryset;
+    (void)diff_argument; (void)method; (void)queryset;
 
+    if (task == "approx_tree") {
+        // main:72-149: codes.bin.plain -> DeltaTree -> the three index artefacts
+        if (PQ_M <= 0 || PQ_K <= 0 || dataset.empty() || N < 0) {
+            std::cout << "usage: deltapq -dataset DIR -task approx_tree -m M -k K -N N [-h FOLDS]" << std::endl;
+            return 2;
+        }
+        std::cout << "M = " << PQ_M << std::endl;
+        const std::string codes_path = dataset + "/codes.bin.plain.M" + std::to_string(PQ_M) + "K" +
+                                       std::to_string(PQ_K) + "N" + std::to_string(N);  // main:76-77
+        int64_t NN = 0;
+        int rc = dpq_read_codes_plain(codes_path.c_str(), PQ_M, &NN, nullptr);
+        if (rc) return die("PQTree::Read", rc);
+        std::cout << "Read: N = " << NN << std::endl;
+        std::vector<uint8_t> vecs((size_t)NN * PQ_M);
+        rc = dpq_read_codes_plain(codes_path.c_str(), PQ_M, &NN, vecs.data());
+        if (rc) return die("PQTree::Read", rc);
+        const std::string cw_path =
+            dataset + "/M" + std::to_string(PQ_M) + "K" + std::to_string(PQ_K) + "codewords.txt";  // main:88-89
+        int32_t cM = 0, cK = 0, cDs = 0;
+        rc = dpq_read_codewords(cw_path.c_str(), &cM, &cK, &cDs, nullptr);
+        if (rc) return die("ReadCodewords", rc);
+        std::vector<float> codewords((size_t)cM * cK * cDs);
+        rc = dpq_read_codewords(cw_path.c_str(), &cM, &cK, &cDs, codewords.data());
+        if (rc) return die("ReadCodewords", rc);
+        if (cM != PQ_M || cK != PQ_K) {
+            std::cout << "codewords file is M=" << cM << " K=" << cK << std::endl;
+            return 1;
+        }
+        std::cout << "K = " << PQ_K << std::endl << "N = " << NN << std::endl << dataset << std::endl;
+        const double t0 = Elapsed();  // main:98
+        dpq_tree* tree = nullptr;
+        rc = dpq_tree_build(vecs.data(), NN, PQ_M, PQ_K, max_height_folds, codewords.data(), cDs, &tree);
+        if (rc) return die("create_approx_tree", rc);
+        dpq_dtc_stats st;
+        dpq_tree_stats(tree, &st);
+        std::cout << "   ++++ TOTAL number of Diffs " << st.n_diffs << std::endl;                       // h:1315
+        for (int d = 0; d < PQ_M + 2 && d < 16; ++d) std::cout << st.depth_hist[d] << " nodes at depth " << d << std::endl;  // h:1467-1469
+        std::cout << "number of bytes is " << st.n_bytes << std::endl;                                  // h:1768
+        rc = dpq_tree_write_files(tree, dataset.c_str());
+        if (rc) return die("write index files", rc);
+        dpq_tree_free(tree);
+        std::cout << "==========================BUILD DELTATREE INDEX IN " << (Elapsed() - t0) << " [sec] "
+                  << "==========================" << std::endl << std::endl;                           // main:136-137
+        std::cout << "WARNING: Just built an index. no query processed." << std::endl;                 // main:140
+        return 0;
+    }
     if (task != "query" && task != "query_im") {
-        std::cout << "deltapq (MI355X build): only -task query and -task query_im are implemented; got '" << task
+        std::cout << "deltapq (MI355X build): -task query, query_im and approx_tree are implemented; got '" << task
                   << "'" << std::endl;
         return 2;
     }

@@ -76,6 +76,9 @@ hipError_t launch_scan(const ScanArgs& a, int n_slot_groups, int splits, hipStre
 hipError_t launch_select(const SelectArgs& a, int M, int n_slots, hipStream_t stream);
 hipError_t launch_merge(const int32_t* d_ids, const float* d_dists, int n_lists, int nq, int top_k, int32_t* d_out_ids,
                         float* d_out_dists, hipStream_t stream);
+// PQ encoding: codes[n][M] = argmin_k |v_m - c[m][k]|^2 in fp32.
+hipError_t launch_encode_pq(const float* d_vectors, int64_t n, int D, const float* d_codebook, int M, int K, int Ds,
+                            uint8_t* d_codes, hipStream_t stream);
 size_t scan_lds_bytes(int M);
 size_t select_lds_bytes(int M);
 

@@ -713,8 +713,69 @@ __global__ __launch_bounds__(kSelectThreads) void merge_kernel(const int32_t* __
 }
 
 // ---------------------------------------------------------------------------
+// 8f row 2: PQ encoding, PQTree::EncodePlain (pq_tree.cpp:215-237): per
+// sub-space the nearest codeword in fp32 -- `diff = v - c; dist += diff * diff`
+// (separately rounded multiply and add), strict `<` so the first minimum wins.
+// grid = (ceil(n / 256), M), block = 256 threads = 256 vectors; the sub-space's
+// codewords sit in LDS and are read as broadcasts.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void encode_pq_kernel(const float* __restrict__ vectors, int64_t n, int D,
+                                                         const float* __restrict__ codebook, int M, int K, int Ds,
+                                                         uint8_t* __restrict__ codes) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* cw = reinterpret_cast<float*>(smem);       // [K][Ds]
+    float* sv = cw + (size_t)K * Ds;                  // [Ds][256]: this thread's sub-vector, conflict-free
+    const int m = blockIdx.y, tid = threadIdx.x;
+    const int64_t v = (int64_t)blockIdx.x * 256 + tid;
+    for (int i = tid; i < K * Ds; i += 256) cw[i] = codebook[(size_t)m * K * Ds + i];
+    for (int d = 0; d < Ds; ++d) {
+        const int col = m * Ds + d;
+        sv[d * 256 + tid] = (v < n && col < D) ? vectors[(size_t)v * D + col] : 0.0f;  // short vectors are zero padded
+    }
+    __syncthreads();
+    if (v >= n) return;
+    float best = FLT_MAX;
+    int best_k = 0;
+    for (int k = 0; k < K; ++k) {
+        float dist = 0.0f;
+        for (int d = 0; d < Ds; ++d) {
+            const float diff = __fsub_rn(sv[d * 256 + tid], cw[k * Ds + d]);
+            dist = __fadd_rn(dist, __fmul_rn(diff, diff));
+        }
+        if (dist < best) {
+            best = dist;
+            best_k = k;
+        }
+    }
+    codes[(size_t)v * M + m] = (uint8_t)best_k;
+}
+
+// ---------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------
+
+hipError_t launch_encode_pq(const float* d_vectors, int64_t n, int D, const float* d_codebook, int M, int K, int Ds,
+                            uint8_t* d_codes, hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    const size_t lds = ((size_t)K * Ds + (size_t)Ds * 256) * sizeof(float);
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    static bool done[64] = {};
+    hipError_t e = hipSuccess;
+    {
+        int dev = 0;
+        e = hipGetDevice(&dev);
+        if (e != hipSuccess) return e;
+        if (dev < 0 || dev >= 64 || !done[dev]) {
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&encode_pq_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return e;
+            if (dev >= 0 && dev < 64) done[dev] = true;
+        }
+    }
+    hipLaunchKernelGGL(encode_pq_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)M), dim3(256), lds, stream,
+                       d_vectors, n, D, d_codebook, M, K, Ds, d_codes);
+    return hipGetLastError();
+}
 
 size_t scan_lds_bytes(int M) {
     const size_t QG = M <= 8 ? 32 : 16, W = (size_t)M / 4;

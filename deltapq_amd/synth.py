@@ -40,6 +40,57 @@ def make_queries(nq, D=128, seed=1, integer=True):
     return q.astype(np.float32)
 
 
+def make_clustered_vectors(n, D=128, seed=0, n_clusters=2000, spread=9.0):
+    """SIFT-shaped base vectors: mixture of Gaussians around
+    gamma-distributed non-negative centres, rounded and clipped to 0..218."""
+    rng = np.random.default_rng(seed)
+    centres = np.clip(rng.gamma(shape=1.2, scale=28.0, size=(n_clusters, D)), 0, 218)
+    which = rng.integers(0, n_clusters, size=n)
+    v = centres[which] + rng.normal(0.0, spread, size=(n, D))
+    return np.clip(np.rint(v), 0, 218).astype(np.float32)
+
+
+def kmeans_codebook(vectors, M=8, K=256, iters=8, seed=0, sample=20000):
+    """Lloyd k-means per sub-space (stand-in for PQ::Learn / cv::kmeans, pq.cpp:139-155,
+    which needs OpenCV): float32 codebook [M][K][Ds]."""
+    rng = np.random.default_rng(seed)
+    v = np.asarray(vectors, dtype=np.float32)
+    if len(v) > sample:
+        v = v[rng.choice(len(v), sample, replace=False)]
+    n, D = v.shape
+    Ds = D // M
+    cb = np.zeros((M, K, Ds), dtype=np.float32)
+    for m in range(M):
+        x = v[:, m * Ds:(m + 1) * Ds].astype(np.float64)
+        c = x[rng.choice(n, K, replace=n < K)].copy()
+        for _ in range(iters):
+            d2 = (x * x).sum(1)[:, None] - 2.0 * x @ c.T + (c * c).sum(1)[None, :]
+            a = d2.argmin(1)
+            for k in range(K):
+                sel = a == k
+                if sel.any():
+                    c[k] = x[sel].mean(0)
+        cb[m] = c.astype(np.float32)
+    return cb
+
+
+def encode_pq_numpy(vectors, codebook):
+    """PQTree::EncodePlain (pq_tree.cpp:215-237) in numpy float32: `diff = v - c;
+    dist += diff * diff` with separately rounded multiply and add, first minimum wins."""
+    v = np.asarray(vectors, dtype=np.float32)
+    cb = np.asarray(codebook, dtype=np.float32)
+    M, K, Ds = cb.shape
+    codes = np.zeros((len(v), M), dtype=np.uint8)
+    for m in range(M):
+        sub = v[:, m * Ds:(m + 1) * Ds]
+        dist = np.zeros((len(v), K), dtype=np.float32)
+        for d in range(Ds):
+            diff = (sub[:, d:d + 1] - cb[m, :, d][None, :]).astype(np.float32)
+            dist = (dist + (diff * diff).astype(np.float32)).astype(np.float32)
+        codes[:, m] = dist.argmin(1)              # argmin returns the first minimum
+    return codes
+
+
 def _depth_chain(n, rng, max_depth, p_child, p_sibling):
     """DFS depth sequence for nodes 1..n-1: d_i in [1, min(d_{i-1}+1, max_depth)]."""
     if n <= 1:

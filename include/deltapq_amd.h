@@ -72,6 +72,7 @@ typedef enum dpq_status {
 
 typedef struct dpq_index dpq_index; /* opaque: one DTC index (or one shard of it) resident on one GPU */
 typedef struct dpq_soa dpq_soa;     /* opaque: host-side transcoded image (no GPU needed) */
+typedef struct dpq_tree dpq_tree;   /* opaque: a DeltaTree in DFS layout built from raw PQ codes (host) */
 
 /* Options for dpq_open_*.  Zero-initialise, then set what you need. */
 typedef struct dpq_open_opts {
@@ -155,6 +156,32 @@ void dpq_soa_free(dpq_soa* soa);
  * order, ascending position.  Call with out == NULL to get n_bytes. */
 int dpq_dtc_encode(const uint8_t* root_code, const uint8_t* depths, const uint16_t* masks, const uint8_t* deltas,
                    int64_t n_codes, int M, uint8_t* out, int64_t* n_bytes);
+
+/* ---- callers either side of the path -------------- */
+/* DeltaTree construction, `deltapq -task approx_tree` with -method 1 (create_approx_tree h:970-1065:
+ * find_edges_by_diff_approx h:1207-1332, edges_to_tree_index_approx_dfs_layout h:1334-1487).  Host code.
+ * codes[n][M] raw PQ codes; codewords [M][K][Ds] may be NULL (it only orders siblings). */
+int dpq_tree_build(const uint8_t* codes, int64_t n_codes, int M, int K, int max_height_folds, const float* codewords,
+                   int Ds, dpq_tree** out);
+int dpq_tree_stats(const dpq_tree* t, dpq_dtc_stats* stats);
+/* Borrowed arrays: which = 0 vec_id u32[n] (DFS position -> original id, QNode.vec_id h:80), 1 parent_pos u32[n],
+ * 2 depth u8[n], 3 mask u16[n], 4 changed bytes, 5 root code u8[M], 6 edges (parent id, child id) u32[n-1][2]. */
+int dpq_tree_array(const dpq_tree* t, int which, const void** ptr, int64_t* n_bytes);
+/* DTC payload of the tree (qnodes_to_compressed_codes_opt h:1765-1826); out == NULL returns the size. */
+int dpq_tree_encode(const dpq_tree* t, uint8_t* out, int64_t* n_bytes);
+/* Writes the reference's three artefacts into dataset_dir: M{M}K{K}H{h}_Approx_Edges_N{N} (h:1326-1327),
+ * M{M}K{K}_Approx_TreeNodesDFS_N{N} (60-byte QNode records h:1484; M <= 8), the DTC index (h:1839-1842). */
+int dpq_tree_write_files(const dpq_tree* t, const char* dataset_dir);
+void dpq_tree_free(dpq_tree* t);
+/* DFS position -> original vector id from a TreeNodesDFS file (QNode.vec_id, h:80, h:1166). */
+int dpq_read_qnode_ids(const char* path, int64_t n_codes, uint32_t* vec_ids);
+/* codes.bin.plain.M{M}K{K}N{N}: PQTree::Read / Write (pq_tree.cpp:1011-1081).  out == NULL returns n_codes. */
+int dpq_read_codes_plain(const char* path, int M, int64_t* n_codes, uint8_t* out);
+int dpq_write_codes_plain(const char* path, const uint8_t* codes, int64_t n_codes, int M);
+/* PQ encoding on the GPU: nearest centroid per sub-space in fp32, first minimum wins
+ * (PQTree::EncodePlain pq_tree.cpp:215-237; host buffers in/out). */
+int dpq_encode_pq(const float* vectors, int64_t n, int D, const float* codewords, int M, int K, int Ds, int device,
+                  uint8_t* codes_out);
 
 /* ---- index lifetime (GPU) ---------------------------------------------- */
 /* Replaces the per-query open()/read() of h:2812-2824: loads

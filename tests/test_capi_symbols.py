@@ -62,5 +62,30 @@ def test_open_without_gpu_fails_loudly(lib):
 def test_cli_usage_without_gpu(built):
     import subprocess
     exe = os.path.join(ROOT, "deltapq_amd", "csrc", "deltapq")
-    r = subprocess.run([exe, "-task", "approx_tree"], capture_output=True, text=True)
-    assert r.returncode == 2 and "only -task query" in r.stdout
+    r = subprocess.run([exe, "-task", "batch_query"], capture_output=True, text=True)
+    assert r.returncode == 2 and "are implemented" in r.stdout
+
+
+def test_cli_approx_tree_builds_the_index_without_gpu(built, tmp_path):
+    """`deltapq -task approx_tree` (main:72-149) is host code: codes.bin.plain -> the three artefacts."""
+    import subprocess
+    from deltapq_amd import api, synth
+    d = str(tmp_path)
+    n = 3000
+    cb = synth.make_codebook(8, 256, 16, seed=1)
+    synth.write_codewords_txt(os.path.join(d, "M8K256codewords.txt"), cb)
+    rng = np.random.default_rng(0)
+    protos = rng.integers(0, 256, size=(40, 8), dtype=np.uint8)
+    codes = protos[rng.integers(0, 40, size=n)].copy()
+    codes[np.arange(n), rng.integers(0, 8, size=n)] = rng.integers(0, 256, size=n)
+    api.write_codes_plain(os.path.join(d, "codes.bin.plain.M8K256N%d" % n), codes)
+    exe = os.path.join(ROOT, "deltapq_amd", "csrc", "deltapq")
+    r = subprocess.run([exe, "-dataset", d, "-task", "approx_tree", "-m", "8", "-k", "256", "-h", "1", "-diff", "8",
+                        "-N", str(n)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "BUILD DELTATREE INDEX IN" in r.stdout and "no query processed" in r.stdout
+    n_codes, payload = api.read_dtc_file(synth.dtc_file_name(d, 8, 256, n))
+    assert n_codes == n
+    api.dtc_validate(payload, n)
+    vec_id = api.read_qnode_ids(os.path.join(d, "M8K256_Approx_TreeNodesDFS_N%d" % n), n)
+    assert sorted(vec_id.tolist()) == list(range(n))
