@@ -38,7 +38,7 @@ def measured_traffic(args):
     """HBM bytes per scan-kernel launch from the committed rocprofv3 --pmc passes
     (scripts/collect_pmc.sh: FETCH_SIZE and WRITE_SIZE in separate runs, gfx950
     x2 read correction).  Only valid for the default workload it was taken on."""
-    default = (args.n, args.queries, args.topk, args.m, args.mean_diffs, args.gpus) == (1_000_000, 1000, 100, 8, 3.0, 1)
+    default = (args.n, args.queries, args.topk, args.m, args.data, args.gpus) == (1_000_000, 1000, 100, 8, "pipeline", 1)
     if not default or not os.path.exists(PMC_SUMMARY):
         return None, None
     with open(PMC_SUMMARY) as f:
@@ -46,14 +46,32 @@ def measured_traffic(args):
     return s.get("scan_kernel_hbm_bytes_per_launch"), s.get("tag")
 
 
-def build_workload(args):
-    from deltapq_amd import synth
+def build_workload(args, device):
+    """`pipeline` (default): SIFT-shaped vectors (mixture of 20 000 Gaussians, values 0..218) ->
+    k-means codebook -> PQ codes (GPU encoder) -> DeltaTree (host builder, reference method 1) -> DTC.
+    `stream`: random DeltaTree emitted directly as (depth, mask, bytes) triples."""
+    from deltapq_amd import api, synth
     t0 = time.time()
-    cb = synth.make_codebook(args.m, 256, args.dim // args.m, seed=100)
-    queries = synth.make_queries(args.queries, args.dim, seed=101)
-    tree = synth.synth_tree(args.n, args.m, seed=102, mean_diffs=args.mean_diffs)
-    payload, n_bytes = synth.encode_dtc(tree)
-    return dict(codebook=cb, queries=queries, payload=payload, n_bytes=n_bytes, gen_s=time.time() - t0)
+    if args.data == "pipeline":
+        base = synth.make_clustered_vectors(args.n, args.dim, seed=100, n_clusters=20000, spread=12.0, centre_seed=7)
+        queries = synth.make_clustered_vectors(args.queries, args.dim, seed=101, n_clusters=20000, spread=12.0,
+                                               centre_seed=7)
+        cb = synth.kmeans_codebook(base, args.m, 256, iters=6, seed=102)
+        codes = api.encode_pq(base, cb, device=device)
+        del base
+        tree = api.DeltaTree(codes, codebook=cb)
+        payload = tree.payload()
+        n_bytes = len(payload)
+        uniq = len(np.unique(codes.view("V%d" % args.m))) / args.n
+        desc = "vectors->kmeans->PQ encode->built DeltaTree, %.1f%% unique codes" % (100 * uniq)
+        tree.close()
+    else:
+        cb = synth.make_codebook(args.m, 256, args.dim // args.m, seed=100)
+        queries = synth.make_queries(args.queries, args.dim, seed=101)
+        tree = synth.synth_tree(args.n, args.m, seed=102, mean_diffs=args.mean_diffs)
+        payload, n_bytes = synth.encode_dtc(tree)
+        desc = "random (depth, mask, bytes) stream"
+    return dict(codebook=cb, queries=queries, payload=payload, n_bytes=n_bytes, gen_s=time.time() - t0, desc=desc)
 
 
 def cpu_baseline(wl, args):
@@ -91,7 +109,8 @@ def main():
     ap.add_argument("--topk", type=int, default=100)
     ap.add_argument("--m", type=int, default=8)
     ap.add_argument("--dim", type=int, default=128)
-    ap.add_argument("--mean-diffs", type=float, default=3.0, help="changed bytes per node of the synthetic tree")
+    ap.add_argument("--data", choices=["pipeline", "stream"], default="pipeline")
+    ap.add_argument("--mean-diffs", type=float, default=3.0, help="changed bytes per node (--data stream)")
     ap.add_argument("--chunks-per-segment", type=int, default=0)
     ap.add_argument("--cpu-queries", type=int, default=256, help="queries timed on the CPU oracle (1 thread)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -120,7 +139,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    wl = build_workload(args)
+    wl = build_workload(args, local_rank)
     idx = api.DeltaPQIndex.open_memory(wl["payload"], args.n, args.m, 256, device=local_rank, shard_rank=rank,
                                        shard_count=world, chunks_per_segment=args.chunks_per_segment)
     idx.set_codebook(wl["codebook"])
@@ -211,8 +230,8 @@ def main():
             "dtype": "f64-sum-of-f32 (u8 code decode)",
             "data": "synthetic",
             "config": {
-                "workload": "SIFT1M-shaped synthetic DeltaTree: N=%d m=%d k=256 h=1 topk=%d, %d queries/step, "
-                            "%.2f B/code, %.2f diffs/node" % (args.n, args.m, k, nq, wl["n_bytes"] / args.n,
+                "workload": "SIFT1M-shaped synthetic (%s): N=%d m=%d k=256 h=1 topk=%d, %d queries/step, "
+                            "%.2f B/code, %.2f diffs/node" % (wl["desc"], args.n, args.m, k, nq, wl["n_bytes"] / args.n,
                                                               (wl["n_bytes"] - args.m) / args.n - (1.5 if args.m <= 8 else 2.5)),
                 "n_codes": args.n, "queries_per_step": nq, "topk": k, "n_bytes": int(wl["n_bytes"]),
                 "sharding": "dfs-range x%d" % world, "queries_per_decode_pass": 32 if args.m <= 8 else 16,

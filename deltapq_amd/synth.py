@@ -40,11 +40,13 @@ def make_queries(nq, D=128, seed=1, integer=True):
     return q.astype(np.float32)
 
 
-def make_clustered_vectors(n, D=128, seed=0, n_clusters=2000, spread=9.0):
-    """SIFT-shaped base vectors: mixture of Gaussians around
-    gamma-distributed non-negative centres, rounded and clipped to 0..218."""
+def make_clustered_vectors(n, D=128, seed=0, n_clusters=2000, spread=9.0, centre_seed=None):
+    """SIFT-shaped vectors: mixture of Gaussians around
+    gamma-distributed non-negative centres, rounded and clipped to 0..218.
+    Base and query sets share `centre_seed` (same mixture, different draws)."""
+    crng = np.random.default_rng(seed if centre_seed is None else centre_seed)
+    centres = np.clip(crng.gamma(shape=1.2, scale=28.0, size=(n_clusters, D)), 0, 218)
     rng = np.random.default_rng(seed)
-    centres = np.clip(rng.gamma(shape=1.2, scale=28.0, size=(n_clusters, D)), 0, 218)
     which = rng.integers(0, n_clusters, size=n)
     v = centres[which] + rng.normal(0.0, spread, size=(n, D))
     return np.clip(np.rint(v), 0, 218).astype(np.float32)
