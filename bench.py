@@ -115,6 +115,8 @@ def main():
     ap.add_argument("--cpu-queries", type=int, default=256, help="queries timed on the CPU oracle (1 thread)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--check", type=int, default=4, help="queries verified against the oracle before timing")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                    help="gloo = rehearsal of the N > 1 path on a box with fewer GPUs than ranks (ranks share GPUs)")
     args = ap.parse_args()
 
     import torch
@@ -133,11 +135,17 @@ def main():
     if not torch.cuda.is_available():
         print("bench.py needs a GPU: the DeltaPQ query path has no CPU fallback", file=sys.stderr)
         sys.exit(3)
+    if args.backend == "gloo":
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    cpu_coll = args.backend == "gloo"   # gloo collectives take host tensors
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if cpu_coll:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     wl = build_workload(args, local_rank)
     idx = api.DeltaPQIndex.open_memory(wl["payload"], args.n, args.m, 256, device=local_rank, shard_rank=rank,
@@ -193,14 +201,15 @@ def main():
     prof = idx.profile_read()
     idx.profile_enable(False)
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    cdev = torch.device("cpu") if cpu_coll else dev
+    t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
     # per-rank scan figures -> rank 0 (sum of algorithmic bytes, max of kernel time)
     stats = torch.tensor([prof["scan_ms"], float(prof["scan_launches"]), float(info["algorithmic_bytes"]),
                           float(info["device_bytes"]), prof["select_ms"], prof["lut_ms"]], dtype=torch.float64,
-                         device=dev)
+                         device=cdev)
     if world > 1:
         all_stats = [torch.zeros_like(stats) for _ in range(world)]
         dist.all_gather(all_stats, stats)

@@ -39,10 +39,18 @@ def gather_and_merge(ids, dists, group=None):
     nq, k = ids.shape
     g_ids = torch.empty((world, nq, k), dtype=ids.dtype, device=ids.device)
     g_dists = torch.empty((world, nq, k), dtype=dists.dtype, device=dists.device)
-    if ids.is_cuda:
+    if ids.is_cuda and dist.get_backend(group) != "gloo":
         dist.all_gather_into_tensor(g_ids, ids.contiguous(), group=group)
         dist.all_gather_into_tensor(g_dists, dists.contiguous(), group=group)
         return api.merge_topk_torch(g_ids, g_dists)
+    if ids.is_cuda:
+        # rehearsal mode (gloo with device tensors, e.g. several ranks sharing one GPU):
+        # exchange through host memory, merge on the device as the RCCL path does
+        h_ids = torch.empty((world, nq, k), dtype=ids.dtype)
+        h_dists = torch.empty((world, nq, k), dtype=dists.dtype)
+        dist.all_gather(list(h_ids.unbind(0)), ids.cpu().contiguous(), group=group)
+        dist.all_gather(list(h_dists.unbind(0)), dists.cpu().contiguous(), group=group)
+        return api.merge_topk_torch(h_ids.to(ids.device), h_dists.to(dists.device))
     dist.all_gather(list(g_ids.unbind(0)), ids.contiguous(), group=group)
     dist.all_gather(list(g_dists.unbind(0)), dists.contiguous(), group=group)
     mi, md = api.merge_topk_host(g_ids.numpy(), g_dists.numpy())

@@ -353,3 +353,27 @@ def test_m16_sift1m_shape_top1000(gpu, oracle):
     parts = [run(gpu, payload, n, cb, qs[sample], k, M=16, shard_rank=r, shard_count=2)[:2] for r in range(2)]
     mi, md = gpu.merge_topk_host(np.stack([p[0] for p in parts]), np.stack([p[1] for p in parts]))
     assert np.array_equal(md.view(np.uint32), dists[sample].view(np.uint32))
+
+
+def test_tie_explosion_thousands_of_duplicates_of_the_nearest_code(gpu, oracle, codebook):
+    """Pathological ties: 9000 exact copies of the code nearest to the query.  The
+    filter cannot separate equal distances, so every copy is a candidate and the
+    per-query buffer (4096) overflows; the rerun loop must grow it and still return
+    the canonical answer (lowest ids of the tie group)."""
+    from deltapq_amd import api, synth
+    rng = np.random.default_rng(5)
+    n = 40000
+    codes = rng.integers(0, 256, size=(n, 8), dtype=np.uint8)
+    q = synth.make_queries(3, 128, seed=9)
+    lut = oracle.build_lut(codebook, q[0])
+    best = np.array([int(np.argmin(lut[m])) for m in range(8)], dtype=np.uint8)   # the nearest possible code
+    dup_at = rng.choice(n, 9000, replace=False)
+    codes[dup_at] = best
+    tree = api.DeltaTree(codes)
+    payload = tree.payload()
+    ids, dists, prof, _ = run(gpu, payload, n, codebook, q, 100)
+    assert prof["overflow_reruns"] >= 1
+    assert_parity(ids, dists, oracle_topk(oracle, payload, n, codebook, q, 100), n)
+    # query 0: all 100 results are copies of `best`, and they are the 100 lowest DFS positions holding it
+    pos_of_best = np.flatnonzero((codes[tree.vec_id] == best).all(1))
+    assert np.array_equal(np.sort(ids[0]), pos_of_best[:100]) and len(set(dists[0].tolist())) == 1
