@@ -71,6 +71,8 @@ SYMBOLS = [
     ("dpq_write_codes_plain", ctypes.c_int, [ctypes.c_char_p, _VP, c_i64, ctypes.c_int]),
     ("dpq_encode_pq", ctypes.c_int,
      [_VP, c_i64, ctypes.c_int, _VP, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _VP]),
+    ("dpq_open_plain_memory", ctypes.c_int, [_VP, c_i64, ctypes.c_int, ctypes.c_int, P(OpenOpts), P(_VP)]),
+    ("dpq_open_plain_file", ctypes.c_int, [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, P(OpenOpts), P(_VP)]),
     ("dpq_open_file", ctypes.c_int, [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, P(OpenOpts), P(_VP)]),
     ("dpq_open_memory", ctypes.c_int, [_VP, c_i64, c_i64, ctypes.c_int, ctypes.c_int, P(OpenOpts), P(_VP)]),
     ("dpq_set_codebook", ctypes.c_int, [_VP, _VP, ctypes.c_int]),

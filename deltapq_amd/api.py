@@ -212,6 +212,16 @@ class DeltaPQIndex:
         check(lib.dpq_open_memory(_np_ptr(pl), pl.size, n_codes, M, K, opts, h), "dpq_open_memory")
         return cls(h)
 
+    @classmethod
+    def open_plain(cls, codes, K=256, device=0, shard_rank=0, shard_count=1, chunks_per_segment=0, cand_capacity=0):
+        """Uncompressed comparator index (`-task pqscan`, h:2590-2678): raw codes, fp32-accumulated distances."""
+        lib = _lib.load()
+        c = np.ascontiguousarray(codes, dtype=np.uint8)
+        opts = OpenOpts(device, shard_rank, shard_count, chunks_per_segment, cand_capacity)
+        h = ctypes.c_void_p()
+        check(lib.dpq_open_plain_memory(_np_ptr(c), c.shape[0], c.shape[1], K, opts, h), "dpq_open_plain_memory")
+        return cls(h)
+
     def set_codebook(self, codebook):
         cb = np.ascontiguousarray(codebook, dtype=np.float32)
         assert cb.ndim == 3

@@ -70,7 +70,8 @@ struct dpq_index {
     dpq_info info{};
     dpq::DeviceImage img;
     // owned device memory of the image
-    uint8_t *d_nib = nullptr, *d_mask = nullptr, *d_delta = nullptr, *d_ckpt = nullptr;
+    uint8_t *d_nib = nullptr, *d_mask = nullptr, *d_delta = nullptr, *d_ckpt = nullptr, *d_raw = nullptr;
+    bool plain = false;  // uncompressed comparator index (fp32-accumulate rule, no id quirk)
     uint64_t* d_seg_off = nullptr;
     float* d_codebook = nullptr;
     // workspace, sized for ws_slots padded queries and ws_cap candidates each
@@ -287,7 +288,8 @@ int run_batch(dpq_index* x, const float* d_queries, int nq, int top_k, int32_t* 
     se.overflow = x->d_overflow;
     se.out_ids = d_ids;
     se.out_dists = d_dists;
-    se.n_codes_total = x->img.n_codes_total;
+    se.n_codes_total = x->plain ? -1 : x->img.n_codes_total;
+    se.fp32_accum = x->plain ? 1 : 0;
 
     const int64_t S = (int64_t)dpq::kChunk * x->img.chunks_per_segment;
     const size_t n_levels = x->img.n_segments > 0 ? x->level_cnt.size() : 0;
@@ -499,6 +501,71 @@ int open_from_payload(const uint8_t* payload, int64_t n_bytes, int64_t n_codes, 
     inf.n_segments = (int32_t)soa.n_segments;
     inf.chunks_per_segment = soa.chunks_per_segment;
     inf.max_depth = soa.max_depth;
+    inf.device = o.device;
+    inf.cand_capacity = x->cap;
+    *out = x;
+    return DPQ_OK;
+}
+
+int open_plain(const uint8_t* codes, int64_t n_codes, int M, int K, const dpq_open_opts* opts, dpq_index** out) {
+    if (!out) return fail(DPQ_ERR_ARG, "out is NULL");
+    *out = nullptr;
+    dpq_open_opts o{};
+    if (opts) o = *opts;
+    if (!codes || n_codes < 1 || n_codes >= (int64_t)INT32_MAX) return fail(DPQ_ERR_ARG, "bad codes / n_codes");
+    if (M != 8 && M != 16) return fail(DPQ_ERR_ARG, "M must be 8 or 16");
+    if (K < 1 || K > 256) return fail(DPQ_ERR_ARG, "K must be in 1..256 (one byte per sub-code)");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(DPQ_ERR_NO_DEVICE, "no HIP device visible; this library has no CPU fallback");
+    if (o.device < 0 || o.device >= ndev) return fail(DPQ_ERR_NO_DEVICE, "device ordinal out of range");
+    int cps = o.chunks_per_segment <= 0 ? 4 : o.chunks_per_segment;
+    if (cps > dpq::kSortMax / dpq::kChunk) return fail(DPQ_ERR_ARG, "chunks_per_segment must be <= 64");
+    int count = o.shard_count <= 0 ? 1 : o.shard_count;
+    if (o.shard_rank < 0 || o.shard_rank >= count) return fail(DPQ_ERR_ARG, "bad shard_rank / shard_count");
+    const int64_t S = (int64_t)dpq::kChunk * cps;
+    const int64_t nseg_total = (n_codes + S - 1) / S;
+    const int64_t seg_lo = nseg_total * o.shard_rank / count, seg_hi = nseg_total * (o.shard_rank + 1) / count;
+    const int64_t lo = std::min(seg_lo * S, n_codes), hi = std::min(seg_hi * S, n_codes);
+    DPQ_HIP(hipSetDevice(o.device));
+    dpq_index* x = new dpq_index();
+    x->device = o.device;
+    x->M = M;
+    x->K = K;
+    x->plain = true;
+    x->cap_auto = o.cand_capacity <= 0;
+    x->cap = o.cand_capacity;
+    const size_t padded = (size_t)(seg_hi - seg_lo) * S * M;
+    int rc = dev_alloc(&x->d_raw, padded + 64);
+    if (!rc) {
+        hipError_t e = hipMemset(x->d_raw, 0, padded + 64);
+        if (e == hipSuccess && hi > lo)
+            e = hipMemcpy(x->d_raw, codes + (size_t)lo * M, (size_t)(hi - lo) * M, hipMemcpyHostToDevice);
+        if (e != hipSuccess) rc = fail(DPQ_ERR_HIP, std::string("upload: ") + hipGetErrorString(e));
+    }
+    if (rc) {
+        dpq_close(x);
+        return rc;
+    }
+    x->img.raw = x->d_raw;
+    x->img.n_local = hi - lo;
+    x->img.n_codes_total = n_codes;
+    x->img.id_base = (uint32_t)lo;
+    x->img.n_segments = (int32_t)(seg_hi - seg_lo);
+    x->img.chunks_per_segment = cps;
+    x->img.M = M;
+    x->img.K = K;
+    dpq_info& inf = x->info;
+    inf.n_codes_total = n_codes;
+    inf.n_bytes_total = n_codes * M;
+    inf.node_lo = lo;
+    inf.node_hi = hi;
+    inf.algorithmic_bytes = (hi - lo) * M;
+    inf.device_bytes = (int64_t)padded;
+    inf.M = M;
+    inf.K = K;
+    inf.n_segments = x->img.n_segments;
+    inf.chunks_per_segment = cps;
     inf.device = o.device;
     inf.cand_capacity = x->cap;
     *out = x;
@@ -786,6 +853,21 @@ int dpq_open_memory(const uint8_t* payload, int64_t n_bytes, int64_t n_codes, in
     return open_from_payload(payload, n_bytes, n_codes, M, K, opts, out);
 }
 
+int dpq_open_plain_memory(const uint8_t* codes, int64_t n_codes, int M, int K, const dpq_open_opts* opts,
+                          dpq_index** out) {
+    return open_plain(codes, n_codes, M, K, opts, out);
+}
+
+int dpq_open_plain_file(const char* path, int M, int K, const dpq_open_opts* opts, dpq_index** out) {
+    if (!path || !out) return fail(DPQ_ERR_ARG, "NULL argument");
+    std::vector<uint8_t> codes;
+    int64_t n = 0;
+    std::string err;
+    int rc = dpq::read_codes_plain(path, M, &n, &codes, &err);
+    if (rc) return fail(rc, err);
+    return open_plain(codes.data(), n, M, K, opts, out);
+}
+
 int dpq_set_codebook(dpq_index* x, const float* codewords, int Ds) {
     if (!x || !codewords || Ds < 1 || Ds > 4096) return fail(DPQ_ERR_ARG, "bad codebook argument");
     DPQ_HIP(hipSetDevice(x->device));
@@ -820,6 +902,7 @@ int dpq_close(dpq_index* x) {
     hipFree(x->d_mask);
     hipFree(x->d_delta);
     hipFree(x->d_ckpt);
+    hipFree(x->d_raw);
     hipFree(x->d_seg_off);
     hipFree(x->d_codebook);
     hipFree(x->d_order);

@@ -110,8 +110,9 @@ int main(int argc, char* argv[]) {
         std::cout << "WARNING: Just built an index. no query processed." << std::endl;                 // main:140
         return 0;
     }
-    if (task != "query" && task != "query_im") {
-        std::cout << "deltapq (MI355X build): -task query, query_im and approx_tree are implemented; got '" << task
+    const bool pqscan = task == "pqscan";  // main:496-556: uncompressed comparator over codes.bin.plain
+    if (task != "query" && task != "query_im" && !pqscan) {
+        std::cout << "deltapq (MI355X build): -task query, query_im, pqscan and approx_tree are implemented; got '" << task
                   << "'" << std::endl;
         return 2;
     }
@@ -137,15 +138,29 @@ int main(int argc, char* argv[]) {
         return 1;
     }
 
-    // index file (h:2812-2814); N == -1: take it from the only header we can find is not
-    // possible without the name, so like the reference the caller must pass -N.
+    // index file (h:2812-2814), or the plain code file for pqscan (h:2616-2618); like the
+    // reference the caller must pass -N (it is part of the file name)
     char fname[4096];
-    rc = dpq_dtc_file_name(dataset.c_str(), PQ_M, PQ_K, N, fname, sizeof fname);
-    if (rc) return die("file name", rc);
-    std::cout << fname << std::endl;
     int64_t n_codes = 0, n_bytes = 0;
-    rc = dpq_read_dtc_header(fname, &n_codes, &n_bytes);
-    if (rc) return die("open index", rc);
+    if (pqscan) {
+        // the reference's pqscan opens codes.bin.plain.M{M}K{K} (h:2616-2617); the encoder and approx_tree
+        // use the name with the N{N} suffix (main:76-77) -- accept either
+        snprintf(fname, sizeof fname, "%s/codes.bin.plain.M%dK%d", dataset.c_str(), PQ_M, PQ_K);
+        rc = dpq_read_codes_plain(fname, PQ_M, &n_codes, nullptr);
+        if (rc) {
+            snprintf(fname, sizeof fname, "%s/codes.bin.plain.M%dK%dN%lld", dataset.c_str(), PQ_M, PQ_K, N);
+            rc = dpq_read_codes_plain(fname, PQ_M, &n_codes, nullptr);
+        }
+        std::cout << fname << std::endl;
+        if (rc) return die("open codes", rc);
+        std::cout << "top_k = " << top_k << std::endl;  // main:504
+    } else {
+        rc = dpq_dtc_file_name(dataset.c_str(), PQ_M, PQ_K, N, fname, sizeof fname);
+        if (rc) return die("file name", rc);
+        std::cout << fname << std::endl;
+        rc = dpq_read_dtc_header(fname, &n_codes, &n_bytes);
+        if (rc) return die("open index", rc);
+    }
     if (N != n_codes) {  // h:2826-2829 / main:629-632
         std::cout << "scan only part of the codes " << N << " / " << n_codes
                   << " is not supported by this build: pass -N " << n_codes << std::endl;
@@ -201,7 +216,8 @@ int main(int argc, char* argv[]) {
         o.device = g;
         o.shard_rank = g;
         o.shard_count = gpus;
-        rc = dpq_open_file(fname, PQ_M, PQ_K, &o, &shards[(size_t)g]);
+        rc = pqscan ? dpq_open_plain_file(fname, PQ_M, PQ_K, &o, &shards[(size_t)g])
+                    : dpq_open_file(fname, PQ_M, PQ_K, &o, &shards[(size_t)g]);
         if (rc) return die("dpq_open_file", rc);
         rc = dpq_set_codebook(shards[(size_t)g], codewords.data(), cDs);
         if (rc) return die("dpq_set_codebook", rc);

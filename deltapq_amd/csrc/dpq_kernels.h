@@ -21,6 +21,7 @@ struct DeviceImage {
     const uint8_t* delta = nullptr;           // changed bytes
     const uint64_t* seg_delta_off = nullptr;  // [n_segments + 1]
     const uint8_t* seg_ckpt = nullptr;        // [n_segments][levels][M]
+    const uint8_t* raw = nullptr;             // non-NULL: plain (uncompressed) index, codes[n][M], padded to whole segments
     int64_t n_local = 0;                      // nodes in this shard
     int64_t n_codes_total = 0;                // N of the whole index (even-N id quirk)
     uint32_t id_base = 0;                     // global DFS position of local node 0
@@ -64,7 +65,8 @@ struct SelectArgs {
     uint32_t* overflow;            // out [slots]: set to 1 when a level dropped candidates (sticky)
     int32_t* out_ids;              // [nq][top_k]
     float* out_dists;              // [nq][top_k]
-    int64_t n_codes_total;
+    int64_t n_codes_total;         // N for the even-N id quirk of the DTC scan; odd (-1) for the plain scan
+    int32_t fp32_accum;            // 1: plain-scan rule, distance accumulated in fp32 (h:2658-2662)
     int32_t debug_flags;           // developer experiments: 1 skip sort, 2 skip quantise, 4 skip exact eval
 };
 

@@ -267,11 +267,16 @@ __global__ __launch_bounds__(64) void decode_segments_kernel(const DeviceImage i
     const uint64_t lt_mask = (1ull << lane) - 1ull;
     const int cps = img.chunks_per_segment;
     WaveDecoder<M> dec;
-    dec.begin_segment(img, seg, lane);
+    if (!img.raw) dec.begin_segment(img, seg, lane);
     for (int c = 0; c < cps; ++c) {
         const int64_t node = ((int64_t)seg * cps + c) * 64 + lane;
         uint32_t code[W];
-        dec.step(img, node, lane, lt_mask, dtab, c + 1 < cps, code);
+        if (img.raw) {
+#pragma unroll
+            for (int w = 0; w < W; ++w) code[w] = reinterpret_cast<const uint32_t*>(img.raw)[(size_t)node * W + w];
+        } else {
+            dec.step(img, node, lane, lt_mask, dtab, c + 1 < cps, code);
+        }
         const size_t o = ((size_t)blockIdx.x * cps + c) * 64 + lane;
         out_id[o] = node < img.n_local ? img.id_base + (uint32_t)node : 0xffffffffu;
 #pragma unroll
@@ -282,7 +287,7 @@ __global__ __launch_bounds__(64) void decode_segments_kernel(const DeviceImage i
 // ---------------------------------------------------------------------------
 // scan: decode + ADC filter for QG queries per workgroup
 // ---------------------------------------------------------------------------
-template <int M>
+template <int M, bool PLAIN>
 __global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanArgs a) {
     constexpr int W = Cfg<M>::W;
     constexpr int QG = Cfg<M>::QG;
@@ -308,7 +313,8 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanArgs a) {
     // lower-bound tables (two per dword), straight into LDS.  For slot q with threshold tau:
     //   entry[m][k] = floor((T[m][k] - min_m) * s)   rounded DOWN, saturated at SAT = 65535 / M
     //   node passes iff sum_m entry[m][c_m] <= Q = ceil((tau' - sum_m min_m) * s)
-    //   s = QTARGET / (tau' - sum_m min_m),  tau' = tau * (1 + 2^-23)  (fp32 rounding of the exact distance)
+    //   s = QTARGET / (tau' - sum_m min_m),  tau' = tau * (1 + 2^-20): covers the fp32 rounding of the exact
+    //   distance and, for the plain scan, the M fp32 roundings of its accumulated distance (<= M * 2^-24 relative)
     // A node with exact distance <= tau has sum entry <= (d - sum min) * s <= Q;
     // a saturated entry (SAT > Q) can only belong to a node with d > tau; and
     // M entries <= SAT cannot overflow 16 bits, so packed pairs are summed with
@@ -337,7 +343,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanArgs a) {
                 mn[m] = a.lut_min[(size_t)qq * M + m];
                 B += (double)mn[m];
             }
-            const double taup = (double)__uint_as_float((uint32_t)(key >> 32)) * (1.0 + 0x1p-23);
+            const double taup = (double)__uint_as_float((uint32_t)(key >> 32)) * (1.0 + 0x1p-20);
             const double R = taup - B;
             if (key != ~0ull && a.debug_pass != 2 && R > 0.0 && R < 1e300) {
                 const double s = (double)Cfg<M>::QTARGET / R;
@@ -403,11 +409,17 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanArgs a) {
 
     for (int s = blockIdx.x * kScanWaves + wave; s < a.n_seg_pass; s += gridDim.x * kScanWaves) {
         const uint32_t seg = (uint32_t)__builtin_amdgcn_readfirstlane(a.seg_list ? (int)a.seg_list[s] : s);
-        dec.begin_segment(a.img, seg, lane);
+        if (!PLAIN) dec.begin_segment(a.img, seg, lane);
         for (int c = 0; c < cps; ++c) {
             const int64_t node = ((int64_t)seg * cps + c) * 64 + lane;  // local position
             uint32_t code[W];
-            dec.step(a.img, node, lane, lt_mask, dtab, c + 1 < cps, code);
+            if (PLAIN) {  // uncompressed comparator (h:2590-2678): the code is simply there
+#pragma unroll
+                for (int w = 0; w < W; ++w)
+                    code[w] = reinterpret_cast<const uint32_t*>(a.img.raw)[(size_t)node * W + w];
+            } else {
+                dec.step(a.img, node, lane, lt_mask, dtab, c + 1 < cps, code);
+            }
 
             // ---- ADC lower bound: M LDS gathers per 8 queries; entries two per dword,
             // summed with 3-input integer adds (no carry can cross the halves) ----
@@ -499,7 +511,13 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanArgs a) {
 // exact distance: fp64 sum of the M fp32 entries, rounded to fp32 == the
 // reference's incremental fp64 stack (h:2889-2907), see DESIGN.md section 3
 template <int M>
-__device__ __forceinline__ float exact_dist(const float* __restrict__ T, const uint32_t* __restrict__ c) {
+__device__ __forceinline__ float exact_dist(const float* __restrict__ T, const uint32_t* __restrict__ c, bool fp32_accum) {
+    if (fp32_accum) {  // plain scan (h:2658-2662): `float dist += lut[m][code]`, m ascending
+        float fsum = 0.0f;
+#pragma unroll
+        for (int m = 0; m < M; ++m) fsum = __fadd_rn(fsum, T[m * 256 + ((c[m >> 2] >> (8 * (m & 3))) & 0xffu)]);
+        return fsum;
+    }
     double dsum = 0.0;
 #pragma unroll
     for (int m = 0; m < M; ++m) {
@@ -614,7 +632,7 @@ __global__ __launch_bounds__(kSelectThreads) void select_kernel(const SelectArgs
         const uint32_t id = src_id[i];
         uint64_t key = ~0ull;
         if (id != 0xffffffffu)
-            key = make_key(exact_dist<M>(T, src_code + (size_t)W * i), id);
+            key = make_key(exact_dist<M>(T, src_code + (size_t)W * i, a.fp32_accum != 0), id);
         else
             atomicAdd(&counters[1], 1u);  // padding node of the shared level-0 list
         keys[i] = key;
@@ -822,20 +840,23 @@ hipError_t launch_decode_segments(const DeviceImage& img, const uint32_t* seg_li
     return hipGetLastError();
 }
 
-template <int M>
+template <int M, bool PLAIN>
 static hipError_t launch_scan_m(const ScanArgs& a, int n_slot_groups, int splits, hipStream_t stream) {
     static bool done[64] = {};
-    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&scan_kernel<M>), scan_lds_bytes(M), done);
+    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&scan_kernel<M, PLAIN>), scan_lds_bytes(M), done);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(scan_kernel<M>, dim3((unsigned)splits, (unsigned)n_slot_groups), dim3(kScanThreads),
+    hipLaunchKernelGGL((scan_kernel<M, PLAIN>), dim3((unsigned)splits, (unsigned)n_slot_groups), dim3(kScanThreads),
                        scan_lds_bytes(M), stream, a);
     return hipGetLastError();
 }
 
 hipError_t launch_scan(const ScanArgs& a, int n_slot_groups, int splits, hipStream_t stream) {
     if (a.n_seg_pass <= 0 || n_slot_groups <= 0) return hipSuccess;
-    if (a.img.M == 8) return launch_scan_m<8>(a, n_slot_groups, splits, stream);
-    if (a.img.M == 16) return launch_scan_m<16>(a, n_slot_groups, splits, stream);
+    const bool plain = a.img.raw != nullptr;
+    if (a.img.M == 8) return plain ? launch_scan_m<8, true>(a, n_slot_groups, splits, stream)
+                                   : launch_scan_m<8, false>(a, n_slot_groups, splits, stream);
+    if (a.img.M == 16) return plain ? launch_scan_m<16, true>(a, n_slot_groups, splits, stream)
+                                    : launch_scan_m<16, false>(a, n_slot_groups, splits, stream);
     return hipErrorInvalidValue;
 }
 

@@ -183,6 +183,14 @@ int dpq_write_codes_plain(const char* path, const uint8_t* codes, int64_t n_code
 int dpq_encode_pq(const float* vectors, int64_t n, int D, const float* codewords, int M, int K, int Ds, int device,
                   uint8_t* codes_out);
 
+/* Plain (uncompressed) PQ index for the comparator scan `-task pqscan` (h:2590-2678): raw codes[n][M],
+ * distance accumulated in **fp32** in ascending m (h:2658-2662), ids = positions in the code file (no
+ * even-N quirk).  The handle is used with dpq_set_codebook / dpq_query_batch* like a DTC index. */
+int dpq_open_plain_memory(const uint8_t* codes, int64_t n_codes, int M, int K, const dpq_open_opts* opts,
+                          dpq_index** out);
+/* <path> = codes.bin.plain.M{M}K{K}N{N} (pq_tree.cpp:1011-1031). */
+int dpq_open_plain_file(const char* path, int M, int K, const dpq_open_opts* opts, dpq_index** out);
+
 /* ---- index lifetime (GPU) ---------------------------------------------- */
 /* Replaces the per-query open()/read() of h:2812-2824: loads
  * <path> = int64 n_codes, int64 n_bytes, payload. */

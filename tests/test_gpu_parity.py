@@ -377,3 +377,82 @@ def test_tie_explosion_thousands_of_duplicates_of_the_nearest_code(gpu, oracle, 
     # query 0: all 100 results are copies of `best`, and they are the 100 lowest DFS positions holding it
     pos_of_best = np.flatnonzero((codes[tree.vec_id] == best).all(1))
     assert np.array_equal(np.sort(ids[0]), pos_of_best[:100]) and len(set(dists[0].tolist())) == 1
+
+
+def plain_dists(lut, codes):
+    """h:2658-2662: float dist = 0; for m: dist += lut[m][code]  (fp32, m ascending)."""
+    d = np.zeros(len(codes), dtype=np.float32)
+    for m in range(codes.shape[1]):
+        d = (d + lut[m, codes[:, m]]).astype(np.float32)
+    return d
+
+
+@pytest.mark.parametrize("n,nq,k,M", [(1, 2, 1, 8), (300, 5, 50, 8), (20000, 40, 10, 8), (200000, 33, 100, 8),
+                                       (50000, 10, 100, 16)])
+def test_plain_pqscan_comparator(gpu, oracle, n, nq, k, M):
+    """`-task pqscan` (h:2590-2678): raw codes, fp32 accumulation, ids = file positions."""
+    from oracle.dtc_oracle import tie_aware_equal
+    from deltapq_amd import synth
+    rng = np.random.default_rng(n)
+    protos = rng.integers(0, 256, size=(max(2, n // 20), M), dtype=np.uint8)
+    codes = protos[rng.integers(0, len(protos), size=n)].copy()                 # many exact duplicates -> ties
+    codes[np.arange(n), rng.integers(0, M, size=n)] = rng.integers(0, 256, size=n)
+    cb = synth.make_codebook(M, 256, 128 // M, seed=1)
+    qs = synth.make_queries(nq, 128, seed=2)
+    with gpu.DeltaPQIndex.open_plain(codes) as idx:
+        idx.set_codebook(cb)
+        ids, dists = idx.query_batch(qs, k)
+        info = idx.info()
+    assert info["algorithmic_bytes"] == n * M
+    for i in range(nq):
+        lut = oracle.build_lut(cb, qs[i])
+        oi, od = oracle.pqscan_plain(codes, lut, k)
+        ok, msg = tie_aware_equal(ids[i], dists[i], oi, od, plain_dists(lut, codes), n + 1)   # n+1: odd/even quirk off
+        assert ok, "query %d: %s" % (i, msg)
+    # sharded: positions stay global
+    parts = []
+    for r in range(3):
+        with gpu.DeltaPQIndex.open_plain(codes, shard_rank=r, shard_count=3) as idx:
+            idx.set_codebook(cb)
+            parts.append(idx.query_batch(qs, min(k, n)))
+    mi, md = gpu.merge_topk_host(np.stack([p[0] for p in parts]), np.stack([p[1] for p in parts]))
+    assert np.array_equal(md.view(np.uint32), dists.view(np.uint32)) and np.array_equal(mi, ids)
+
+
+def test_cli_pqscan_and_compressed_query_agree_through_vec_id(gpu, oracle, tmp_path):
+    """The compressed scan (DFS positions, fp64 rule) and the plain scan (file positions, fp32 rule) find the
+    same vectors: map the former through QNode.vec_id (TreeNodesDFS file) and compare as sets."""
+    from deltapq_amd import api, synth
+    d = str(tmp_path)
+    n, nq, k = 20001, 16, 10
+    base = synth.make_clustered_vectors(n, 128, seed=3, n_clusters=500)
+    queries = synth.make_clustered_vectors(nq, 128, seed=4, n_clusters=500, centre_seed=3)
+    cb = synth.kmeans_codebook(base, 8, 256, iters=3, seed=5)
+    synth.write_codewords_txt(os.path.join(d, "M8K256codewords.txt"), cb)
+    cb = synth.read_codewords_txt(os.path.join(d, "M8K256codewords.txt"))
+    synth.write_fvecs(os.path.join(d, "query.fvecs"), queries)
+    codes = api.encode_pq(base, cb)
+    api.write_codes_plain(os.path.join(d, "codes.bin.plain.M8K256N%d" % n), codes)
+    exe = os.path.join(ROOT, "deltapq_amd", "csrc", "deltapq")
+    common = ["-dataset", d, "-m", "8", "-k", "256", "-N", str(n), "-topk", str(k), "-query_size", str(nq)]
+    r = subprocess.run([exe, "-task", "approx_tree"] + common, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout
+    res = {}
+    for task in ("query", "pqscan"):
+        out = os.path.join(d, task + ".bin")
+        r = subprocess.run([exe, "-task", task, "-out", out] + common, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0 and "[msec/query]" in r.stdout, r.stdout + r.stderr
+        raw = np.fromfile(out, dtype=np.uint8)
+        res[task] = (np.frombuffer(raw[16:16 + nq * k * 4], np.int32).reshape(nq, k),
+                     np.frombuffer(raw[16 + nq * k * 4:], np.float32).reshape(nq, k))
+    vec_id = api.read_qnode_ids(os.path.join(d, "M8K256_Approx_TreeNodesDFS_N%d" % n), n)
+    for i in range(nq):
+        lut = oracle.build_lut(cb, queries[i])
+        d32 = plain_dists(lut, codes)
+        got_plain, got_tree = res["pqscan"][0][i], vec_id[res["query"][0][i]]
+        assert np.array_equal(d32[got_plain].view(np.uint32), res["pqscan"][1][i].view(np.uint32))
+        # same k-th distance up to fp32-vs-fp64 rounding; the id sets may differ only inside that band
+        kth = res["pqscan"][1][i][-1]
+        assert abs(res["query"][1][i][-1] - kth) <= 2e-6 * kth
+        strictly_inside = d32 < kth * (1 - 2e-6)
+        assert set(np.flatnonzero(strictly_inside).tolist()) <= set(got_tree.tolist()) & set(got_plain.tolist())
