@@ -112,7 +112,7 @@ def main():
     ap.add_argument("--data", choices=["pipeline", "stream"], default="pipeline")
     ap.add_argument("--mean-diffs", type=float, default=3.0, help="changed bytes per node (--data stream)")
     ap.add_argument("--chunks-per-segment", type=int, default=0)
-    ap.add_argument("--cpu-queries", type=int, default=256, help="queries timed on the CPU oracle (1 thread)")
+    ap.add_argument("--cpu-queries", type=int, default=700, help="queries timed on the CPU oracle (1 thread)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--check", type=int, default=4, help="queries verified against the oracle before timing")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",

@@ -1061,7 +1061,7 @@ int dpq_debug_scan_time(dpq_index* x, int nq, int pass_all, int reps, int splits
     return DPQ_OK;
 }
 
-// Developer hook: time the level-0 select (shared list) with parts disabled.
+// Developer hook: time the level-0 select (shared, query-independent candidate list).
 int dpq_debug_select_time(dpq_index* x, int nq, int top_k, int flags, int reps, float* ms_out) {
     if (!x || !ms_out || !x->d_lut32 || !x->d_l0_id) return fail(DPQ_ERR_STATE, "run a query batch first");
     DPQ_HIP(hipSetDevice(x->device));
@@ -1080,7 +1080,7 @@ int dpq_debug_select_time(dpq_index* x, int nq, int top_k, int flags, int reps, 
     se.thr_key = x->d_thr_key;
     se.overflow = x->d_overflow;
     se.n_codes_total = x->img.n_codes_total;
-    se.debug_flags = flags;
+    (void)flags;
     hipEvent_t a, b;
     DPQ_HIP(hipEventCreate(&a));
     DPQ_HIP(hipEventCreate(&b));

@@ -67,7 +67,6 @@ struct SelectArgs {
     float* out_dists;              // [nq][top_k]
     int64_t n_codes_total;         // N for the even-N id quirk of the DTC scan; odd (-1) for the plain scan
     int32_t fp32_accum;            // 1: plain-scan rule, distance accumulated in fp32 (h:2658-2662)
-    int32_t debug_flags;           // developer experiments: 1 skip sort, 2 skip quantise, 4 skip exact eval
 };
 
 hipError_t launch_lut_build(const float* d_codebook, const float* d_queries, int nq, int M, int K, int Ds,

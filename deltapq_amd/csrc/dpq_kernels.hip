@@ -43,10 +43,6 @@ namespace dpq {
 
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 
-__device__ __forceinline__ uint32_t pk_add_sat_u16(uint32_t a, uint32_t b) {  // v_pk_add_u16 clamp
-    return __builtin_bit_cast(uint32_t, __builtin_elementwise_add_sat(__builtin_bit_cast(u16x2, a),
-                                                                      __builtin_bit_cast(u16x2, b)));
-}
 __device__ __forceinline__ uint32_t pk_sub_sat_u16(uint32_t a, uint32_t b) {  // v_pk_sub_u16 clamp
     return __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(__builtin_bit_cast(u16x2, a),
                                                                       __builtin_bit_cast(u16x2, b)));

@@ -9,6 +9,6 @@ lib = _lib.load()
 lib.dpq_debug_select_time.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_float)]
 with api.DeltaPQIndex.open_memory(payload, n, 8, 256) as idx:
     idx.set_codebook(cb); idx.query_batch(qs, 100)
-    for flags, name in [(0,'full'),(1,'no sort'),(2,'no quantise'),(4,'no exact'),(3,'no sort+quant'),(7,'nothing')]:
+    for flags, name in [(0,'full')]:
         ms = ctypes.c_float(); rc = lib.dpq_debug_select_time(idx._h, nq, 100, flags, 5, ms); assert rc == 0
         print('%-14s %.1f us' % (name, ms.value * 1e3), flush=True)
