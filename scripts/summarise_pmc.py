@@ -18,7 +18,7 @@ for r in csv.DictReader(open(stats)):
     k = r["Name"].split("(")[0].replace("void ", "")
     summary["kernels"].setdefault(k, {})["stats"] = {"calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"]),
                                                      "total_ns": int(r["TotalDurationNs"]), "pct": float(r["Percentage"])}
-sc = summary["kernels"].get("dpq::scan_kernel", {})
+sc = next((v for k, v in summary["kernels"].items() if k.startswith("dpq::scan_kernel")), {})
 if "FETCH_SIZE" in sc and "WRITE_SIZE" in sc:
     summary["scan_kernel_hbm_bytes_per_launch"] = 2 * sc["FETCH_SIZE"]["mean_kib"] * 1024 + sc["WRITE_SIZE"]["mean_kib"] * 1024
     summary["scan_kernel_hbm_bytes_per_launch_uncorrected"] = (sc["FETCH_SIZE"]["mean_kib"] + sc["WRITE_SIZE"]["mean_kib"]) * 1024
