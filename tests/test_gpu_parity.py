@@ -456,3 +456,21 @@ def test_cli_pqscan_and_compressed_query_agree_through_vec_id(gpu, oracle, tmp_p
         assert abs(res["query"][1][i][-1] - kth) <= 2e-6 * kth
         strictly_inside = d32 < kth * (1 - 2e-6)
         assert set(np.flatnonzero(strictly_inside).tolist()) <= set(got_tree.tolist()) & set(got_plain.tolist())
+
+
+@pytest.mark.parametrize("K,Ds", [(64, 4), (200, 16), (1, 2), (256, 32)])
+def test_other_codebook_shapes(gpu, oracle, K, Ds):
+    """K < 256 (codes only use k < K) and other sub-space widths."""
+    from deltapq_amd import synth
+    n, nq, k = 5000, 9, 25
+    rng = np.random.default_rng(K)
+    cb = rng.normal(10, 4, size=(8, K, Ds)).astype(np.float32)
+    qs = rng.normal(10, 4, size=(nq, 8 * Ds)).astype(np.float32)
+    tree = synth.synth_tree(n, 8, seed=K + 1)
+    tree["deltas"] = (tree["deltas"].astype(np.int64) % K).astype(np.uint8)
+    tree["root"] = (tree["root"].astype(np.int64) % K).astype(np.uint8)
+    payload, _ = synth.encode_dtc(tree)
+    with gpu.DeltaPQIndex.open_memory(payload, n, 8, K) as idx:
+        idx.set_codebook(cb)
+        ids, dists = idx.query_batch(qs, k)
+    assert_parity(ids, dists, oracle_topk(oracle, payload, n, cb, qs, k), n)
