@@ -474,3 +474,26 @@ def test_other_codebook_shapes(gpu, oracle, K, Ds):
         idx.set_codebook(cb)
         ids, dists = idx.query_batch(qs, k)
     assert_parity(ids, dists, oracle_topk(oracle, payload, n, cb, qs, k), n)
+
+
+def test_adversarial_table_magnitudes(gpu, oracle):
+    """`fp64 sum of the fp32 entries` equals the reference's incremental fp64 stack
+    bit for bit while partial sums are exact in fp64 (entries within ~2^29 of each other).  Here sub-spaces
+    differ by 1e5 in scale (1e10 in squared distance): the two summation orders may round differently, and
+    the contract falls back to the north-star tolerance: 1e-5 relative on distances, same ids where the
+    distances are separated by more than that."""
+    from deltapq_amd import synth
+    rng = np.random.default_rng(0)
+    n, nq, k = 30000, 12, 50
+    scale = np.array([1e5, 1e-2, 3.0, 1e2, 1e-3, 7.0, 1e4, 1.0], dtype=np.float64)
+    cb = (rng.normal(0, 1, size=(8, 256, 16)) * scale[:, None, None]).astype(np.float32)
+    qs = (rng.normal(0, 1, size=(nq, 8, 16)) * scale[None, :, None]).reshape(nq, 128).astype(np.float32)
+    tree, payload, _ = make_case(n, seed=3)
+    ids, dists, _, _ = run(gpu, payload, n, cb, qs, k)
+    exact_rows = 0
+    for i, (oi, od, alld) in enumerate(oracle_topk(oracle, payload, n, cb, qs, k)):
+        assert np.allclose(dists[i], od, rtol=1e-5, atol=0.0), i
+        pos = np.where(ids[i] == n, n - 1, ids[i])
+        assert np.allclose(alld[pos], dists[i], rtol=1e-5, atol=0.0)        # every returned id carries its distance
+        exact_rows += int(np.array_equal(dists[i].view(np.uint32), od.view(np.uint32)) and set(ids[i]) == set(oi))
+    assert exact_rows >= nq - 2          # in practice still bit-identical almost always
