@@ -16,7 +16,10 @@
 // index once into HBM (the reference re-opens the file per query for `query`).
 // Extensions: -gpus G shards the index over G GPUs of this node and merges the
 // partial top-k lists on the host; -out writes all results (the reference
-// only prints top-1 under -debug).
+// only prints top-1 under -debug); -task pqscan is the reference's uncompressed
+// comparator (main:496-556); -task encode is the encode step of the reference's
+// other binary, pqtree (main.cpp:314-425), so that base vectors -> codes ->
+// index -> query runs from this one tool.
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -64,6 +67,47 @@ int main(int argc, char* argv[]) {
     }
     (void)diff_argument; (void)method; (void)queryset;
 
+    if (task == "encode") {
+        // The other binary's `pqtree -task encode` (main.cpp:314-425): base.{ext} -> PQ codes (nearest
+        // codeword per sub-space, PQTree::EncodePlain pq_tree.cpp:215-237) -> codes.bin.plain.M{M}K{K}N{N}.
+        if (PQ_M <= 0 || PQ_K <= 0 || dataset.empty()) {
+            std::cout << "usage: deltapq -dataset DIR -task encode -m M -k K [-N N] [-ext fvecs|bvecs]" << std::endl;
+            return 2;
+        }
+        const std::string cw_path =
+            dataset + "/M" + std::to_string(PQ_M) + "K" + std::to_string(PQ_K) + "codewords.txt";
+        int32_t cM = 0, cK = 0, cDs = 0;
+        int rc = dpq_read_codewords(cw_path.c_str(), &cM, &cK, &cDs, nullptr);
+        if (rc) return die("ReadCodewords", rc);
+        std::vector<float> codewords((size_t)cM * cK * cDs);
+        rc = dpq_read_codewords(cw_path.c_str(), &cM, &cK, &cDs, codewords.data());
+        if (rc) return die("ReadCodewords", rc);
+        if (cM != PQ_M || cK != PQ_K) {
+            std::cout << "codewords file is M=" << cM << " K=" << cK << std::endl;
+            return 1;
+        }
+        const std::string base_path = dataset + "/base." + ext;  // main.cpp:354
+        int64_t n_file = 0;
+        int32_t D = 0;
+        rc = dpq_read_vecs(base_path.c_str(), ext == "bvecs", &n_file, &D, nullptr, 0);
+        if (rc) return die("ItrReader", rc);
+        int64_t n = n_file;
+        if (N != -1 && N < n) n = N;  // main.cpp:339-340: -N caps the number of vectors
+        std::vector<float> base((size_t)n * D);
+        rc = dpq_read_vecs(base_path.c_str(), ext == "bvecs", &n_file, &D, base.data(), n);
+        if (rc) return die("ItrReader", rc);
+        const double t0 = Elapsed();
+        std::vector<uint8_t> codes((size_t)n * PQ_M);
+        rc = dpq_encode_pq(base.data(), n, D, codewords.data(), PQ_M, PQ_K, cDs, 0, codes.data());
+        if (rc) return die("encode", rc);
+        const std::string out = dataset + "/codes.bin.plain.M" + std::to_string(PQ_M) + "K" + std::to_string(PQ_K) +
+                                "N" + std::to_string(n);  // main.cpp:409-411
+        rc = dpq_write_codes_plain(out.c_str(), codes.data(), n, PQ_M);
+        if (rc) return die("PQTree::Write", rc);
+        std::cout << "N = " << n << std::endl;                                         // pq_tree.cpp:1021
+        std::cout << "encoded " << n << " vectors in " << (Elapsed() - t0) << " [sec] -> " << out << std::endl;
+        return 0;
+    }
     if (task == "approx_tree") {
         // main:72-149: codes.bin.plain -> DeltaTree -> the three index artefacts
         if (PQ_M <= 0 || PQ_K <= 0 || dataset.empty() || N < 0) {
@@ -112,7 +156,7 @@ int main(int argc, char* argv[]) {
     }
     const bool pqscan = task == "pqscan";  // main:496-556: uncompressed comparator over codes.bin.plain
     if (task != "query" && task != "query_im" && !pqscan) {
-        std::cout << "deltapq (MI355X build): -task query, query_im, pqscan and approx_tree are implemented; got '" << task
+        std::cout << "deltapq (MI355X build): -task query, query_im, pqscan, approx_tree and encode are implemented; got '" << task
                   << "'" << std::endl;
         return 2;
     }

@@ -431,10 +431,13 @@ def test_cli_pqscan_and_compressed_query_agree_through_vec_id(gpu, oracle, tmp_p
     synth.write_codewords_txt(os.path.join(d, "M8K256codewords.txt"), cb)
     cb = synth.read_codewords_txt(os.path.join(d, "M8K256codewords.txt"))
     synth.write_fvecs(os.path.join(d, "query.fvecs"), queries)
-    codes = api.encode_pq(base, cb)
-    api.write_codes_plain(os.path.join(d, "codes.bin.plain.M8K256N%d" % n), codes)
+    synth.write_fvecs(os.path.join(d, "base.fvecs"), base)
     exe = os.path.join(ROOT, "deltapq_amd", "csrc", "deltapq")
     common = ["-dataset", d, "-m", "8", "-k", "256", "-N", str(n), "-topk", str(k), "-query_size", str(nq)]
+    r = subprocess.run([exe, "-task", "encode"] + common, capture_output=True, text=True, timeout=300)   # base.fvecs -> codes
+    assert r.returncode == 0, r.stdout + r.stderr
+    codes = api.read_codes_plain(os.path.join(d, "codes.bin.plain.M8K256N%d" % n), 8)
+    assert np.array_equal(codes, synth.encode_pq_numpy(base, cb))
     r = subprocess.run([exe, "-task", "approx_tree"] + common, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout
     res = {}
