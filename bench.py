@@ -59,7 +59,7 @@ def build_workload(args, device):
         cb = synth.kmeans_codebook(base, args.m, 256, iters=6, seed=102)
         codes = api.encode_pq(base, cb, device=device)
         del base
-        tree = api.DeltaTree(codes, codebook=cb)
+        tree = api.DeltaTree(codes, codebook=cb, device=device)      # edge search on the GPU, layout on the host
         payload = tree.payload()
         n_bytes = len(payload)
         uniq = len(np.unique(codes.view("V%d" % args.m))) / args.n

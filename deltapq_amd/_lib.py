@@ -61,6 +61,8 @@ SYMBOLS = [
     ("dpq_soa_free", None, [_VP]),
     ("dpq_dtc_encode", ctypes.c_int, [_VP, _VP, _VP, _VP, c_i64, ctypes.c_int, _VP, P(c_i64)]),
     ("dpq_tree_build", ctypes.c_int, [_VP, c_i64, ctypes.c_int, ctypes.c_int, ctypes.c_int, _VP, ctypes.c_int, P(_VP)]),
+    ("dpq_tree_build_gpu", ctypes.c_int,
+     [_VP, c_i64, ctypes.c_int, ctypes.c_int, ctypes.c_int, _VP, ctypes.c_int, ctypes.c_int, P(_VP)]),
     ("dpq_tree_stats", ctypes.c_int, [_VP, P(DtcStats)]),
     ("dpq_tree_array", ctypes.c_int, [_VP, ctypes.c_int, P(_VP), P(c_i64)]),
     ("dpq_tree_encode", ctypes.c_int, [_VP, _VP, P(c_i64)]),

@@ -107,7 +107,9 @@ class DeltaTree:
     _ARRAYS = [("vec_id", np.uint32), ("parent_pos", np.uint32), ("depth", np.uint8), ("mask", np.uint16),
                ("deltas", np.uint8), ("root", np.uint8), ("edges", np.uint32)]
 
-    def __init__(self, codes, K=256, max_height_folds=1, codebook=None):
+    def __init__(self, codes, K=256, max_height_folds=1, codebook=None, device=None):
+        """device=None: everything on the host; device=i: the edge search runs on GPU i
+        (dpq_tree_build_gpu) and yields the same tree."""
         lib = _lib.load()
         self._lib = lib
         c = np.ascontiguousarray(codes, dtype=np.uint8)
@@ -115,8 +117,12 @@ class DeltaTree:
         n, M = c.shape
         cb = None if codebook is None else np.ascontiguousarray(codebook, dtype=np.float32)
         h = ctypes.c_void_p()
-        check(lib.dpq_tree_build(_np_ptr(c), n, M, K, max_height_folds, None if cb is None else _np_ptr(cb),
-                                 0 if cb is None else cb.shape[2], h), "dpq_tree_build")
+        cbp, ds = (None, 0) if cb is None else (_np_ptr(cb), cb.shape[2])
+        if device is None:
+            check(lib.dpq_tree_build(_np_ptr(c), n, M, K, max_height_folds, cbp, ds, h), "dpq_tree_build")
+        else:
+            check(lib.dpq_tree_build_gpu(_np_ptr(c), n, M, K, max_height_folds, cbp, ds, device, h),
+                  "dpq_tree_build_gpu")
         self._h = h
         self.M, self.K, self.n = M, K, n
         st = _lib.DtcStats()

@@ -45,12 +45,13 @@ void combinations(int n, int k, std::vector<std::vector<int>>* out) {  // lexico
     }
 }
 
-// stable sort of ids by the bytes at `kept` positions (most significant first)
+// stable sort of ids by the bytes at `kept` positions; the HIGHEST position is the most significant
+// digit, i.e. the order of the masked code read as a little-endian integer (what the GPU edge finder sorts)
 void radix_by_positions(const uint8_t* codes, int M, const std::vector<int>& kept, std::vector<uint32_t>* ids,
                         std::vector<uint32_t>* tmp) {
     const size_t n = ids->size();
     tmp->resize(n);
-    for (int p = (int)kept.size() - 1; p >= 0; --p) {
+    for (int p = 0; p < (int)kept.size(); ++p) {
         const int pos = kept[p];
         size_t count[257] = {0};
         for (size_t i = 0; i < n; ++i) count[codes[(size_t)(*ids)[i] * M + pos] + 1]++;
@@ -71,8 +72,8 @@ inline bool same_key(const uint8_t* codes, int M, const std::vector<int>& kept, 
 
 }  // namespace
 
-int build_tree(const uint8_t* codes, int64_t n, int M, int K, int max_height_folds, const float* codewords, int Ds,
-               Tree* out, std::string* err) {
+static int check_build_args(const uint8_t* codes, int64_t n, int M, int K, int max_height_folds, Tree* out,
+                            std::string* err) {
     if (!codes || n < 1 || M < 1 || M > 16 || K < 1 || K > 256 || max_height_folds < 1 || !out) {
         if (err) *err = "bad argument to build_tree";
         return DPQ_ERR_ARG;
@@ -81,21 +82,24 @@ int build_tree(const uint8_t* codes, int64_t n, int M, int K, int max_height_fol
         if (err) *err = "number of codes is too large";
         return DPQ_ERR_ARG;
     }
-    Tree& t = *out;
-    t = Tree();
-    t.M = M;
-    t.K = K;
-    t.max_height_folds = max_height_folds;
-    t.n = n;
-    const int MAXH = M * max_height_folds;  // h:1262
-    const int levels = levels_for(M);
+    return DPQ_OK;
+}
 
-    // ---- edges (find_edges_by_diff_approx, h:1207-1313) ----
-    std::vector<uint32_t> cur((size_t)n), next, act, tmp, finalists;
+void position_subsets(int M, int keep, std::vector<std::vector<int>>* out) { combinations(M, keep, out); }
+
+// ---- edges (find_edges_by_diff_approx, h:1207-1313), host version ----
+int find_edges_host(const uint8_t* codes, int64_t n, int M, int max_height_folds, std::vector<uint32_t>* finalists_out,
+                    std::vector<std::pair<uint32_t, uint32_t>>* edges, std::string* err) {
+    (void)err;
+    const int MAXH = M * max_height_folds;  // h:1262
+    std::vector<uint32_t> cur((size_t)n), next, act, tmp;
+    std::vector<uint32_t>& finalists = *finalists_out;
+    finalists.clear();
     std::iota(cur.begin(), cur.end(), 0u);
     std::vector<uint8_t> heights((size_t)n, 0), merged((size_t)n, 0);
     std::vector<std::vector<int>> combos;
-    t.edges.reserve((size_t)n);
+    edges->clear();
+    edges->reserve((size_t)n);
     for (int diff = 0; diff <= M; ++diff) {
         combinations(M, M - diff, &combos);
         for (const auto& kept : combos) {
@@ -126,7 +130,7 @@ int build_tree(const uint8_t* codes, int64_t n, int M, int K, int max_height_fol
                     for (size_t j = i; j < end; ++j)
                         if (act[j] != parent) {
                             merged[act[j]] = 1;
-                            t.edges.emplace_back(parent, act[j]);
+                            edges->emplace_back(parent, act[j]);
                         }
                 }
                 i = end;
@@ -139,6 +143,34 @@ int build_tree(const uint8_t* codes, int64_t n, int M, int K, int max_height_fol
         if (cur.size() <= 1) break;  // h:1288
     }
     for (uint32_t id : cur) finalists.push_back(id);  // h:1292-1294
+    return DPQ_OK;
+}
+
+int build_tree(const uint8_t* codes, int64_t n, int M, int K, int max_height_folds, const float* codewords, int Ds,
+               Tree* out, std::string* err) {
+    int rc = check_build_args(codes, n, M, K, max_height_folds, out, err);
+    if (rc) return rc;
+    std::vector<uint32_t> finalists;
+    std::vector<std::pair<uint32_t, uint32_t>> edges;
+    rc = find_edges_host(codes, n, M, max_height_folds, &finalists, &edges, err);
+    if (rc) return rc;
+    return layout_tree(codes, n, M, K, max_height_folds, codewords, Ds, finalists, &edges, out, err);
+}
+
+// Everything after the edge search: root, adjacency, sibling order, DFS numbering, per-node diffs.
+int layout_tree(const uint8_t* codes, int64_t n, int M, int K, int max_height_folds, const float* codewords, int Ds,
+                const std::vector<uint32_t>& finalists, std::vector<std::pair<uint32_t, uint32_t>>* edges_in, Tree* out,
+                std::string* err) {
+    int rc = check_build_args(codes, n, M, K, max_height_folds, out, err);
+    if (rc) return rc;
+    Tree& t = *out;
+    t = Tree();
+    t.M = M;
+    t.K = K;
+    t.max_height_folds = max_height_folds;
+    t.n = n;
+    t.edges.swap(*edges_in);
+    const int levels = levels_for(M);
     if (finalists.empty()) {
         if (err) *err = "internal: no root found";
         return DPQ_ERR_FORMAT;

@@ -33,6 +33,18 @@ struct Tree {
 // codewords ([M][K][Ds], may be NULL) only orders siblings (by max_dist2p, h:1420-1426).
 int build_tree(const uint8_t* codes, int64_t n, int M, int K, int max_height_folds, const float* codewords, int Ds,
                Tree* out, std::string* err);
+// The two halves of build_tree, shared with the GPU edge finder (dpq_build_gpu.hip):
+// the edge search (find_edges_by_diff_approx, h:1207-1313) and everything after it.
+int find_edges_host(const uint8_t* codes, int64_t n, int M, int max_height_folds, std::vector<uint32_t>* finalists,
+                    std::vector<std::pair<uint32_t, uint32_t>>* edges, std::string* err);
+int layout_tree(const uint8_t* codes, int64_t n, int M, int K, int max_height_folds, const float* codewords, int Ds,
+                const std::vector<uint32_t>& finalists, std::vector<std::pair<uint32_t, uint32_t>>* edges, Tree* out,
+                std::string* err);
+void position_subsets(int M, int keep, std::vector<std::vector<int>>* out);  // lexicographic, create_tree.h:75-95
+// Edge search on the GPU (same groups, same parents, same edge order as find_edges_host).
+int find_edges_gpu(const uint8_t* codes, int64_t n, int M, int max_height_folds, int device,
+                   std::vector<uint32_t>* finalists, std::vector<std::pair<uint32_t, uint32_t>>* edges,
+                   std::string* err);
 // DTC payload of the tree (qnodes_to_compressed_codes_opt, h:1765-1826).
 int tree_encode(const Tree& t, std::vector<uint8_t>* payload, std::string* err);
 // The reference's artefacts in `dir`: M{M}K{K}H{h}_Approx_Edges_N{N} (h:1326-1327),

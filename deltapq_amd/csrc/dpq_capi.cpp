@@ -726,6 +726,28 @@ int dpq_tree_build(const uint8_t* codes, int64_t n_codes, int M, int K, int max_
     return DPQ_OK;
 }
 
+int dpq_tree_build_gpu(const uint8_t* codes, int64_t n_codes, int M, int K, int max_height_folds,
+                       const float* codewords, int Ds, int device, dpq_tree** out) {
+    if (!out) return fail(DPQ_ERR_ARG, "out is NULL");
+    *out = nullptr;
+    if (!codes || n_codes < 1 || n_codes >= (int64_t)INT32_MAX || M < 1 || M > 16 || K < 1 || K > 256 ||
+        max_height_folds < 1)
+        return fail(DPQ_ERR_ARG, "bad argument to dpq_tree_build_gpu");
+    std::string err;
+    std::vector<uint32_t> finalists;
+    std::vector<std::pair<uint32_t, uint32_t>> edges;
+    int rc = dpq::find_edges_gpu(codes, n_codes, M, max_height_folds, device, &finalists, &edges, &err);
+    if (rc) return fail(rc, err);
+    dpq_tree* t = new dpq_tree();
+    rc = dpq::layout_tree(codes, n_codes, M, K, max_height_folds, codewords, Ds, finalists, &edges, &t->tree, &err);
+    if (rc) {
+        delete t;
+        return fail(rc, err);
+    }
+    *out = t;
+    return DPQ_OK;
+}
+
 int dpq_tree_stats(const dpq_tree* t, dpq_dtc_stats* stats) {
     if (!t || !stats) return fail(DPQ_ERR_ARG, "NULL argument");
     const dpq::Tree& tr = t->tree;

@@ -139,7 +139,14 @@ int main(int argc, char* argv[]) {
         std::cout << "K = " << PQ_K << std::endl << "N = " << NN << std::endl << dataset << std::endl;
         const double t0 = Elapsed();  // main:98
         dpq_tree* tree = nullptr;
-        rc = dpq_tree_build(vecs.data(), NN, PQ_M, PQ_K, max_height_folds, codewords.data(), cDs, &tree);
+        // the sort/group passes run on GPU 0 when there is one (same tree either way); -cpu_build forces the host
+        bool cpu_build = dpq_device_count() < 1;
+        for (int i = 0; i < argc; i++)
+            if (std::string(argv[i]) == "-cpu_build") cpu_build = true;
+        std::cout << "edge search on " << (cpu_build ? "the host" : "GPU 0") << std::endl;
+        rc = cpu_build ? dpq_tree_build(vecs.data(), NN, PQ_M, PQ_K, max_height_folds, codewords.data(), cDs, &tree)
+                       : dpq_tree_build_gpu(vecs.data(), NN, PQ_M, PQ_K, max_height_folds, codewords.data(), cDs, 0,
+                                            &tree);
         if (rc) return die("create_approx_tree", rc);
         dpq_dtc_stats st;
         dpq_tree_stats(tree, &st);

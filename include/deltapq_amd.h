@@ -163,6 +163,10 @@ int dpq_dtc_encode(const uint8_t* root_code, const uint8_t* depths, const uint16
  * codes[n][M] raw PQ codes; codewords [M][K][Ds] may be NULL (it only orders siblings). */
 int dpq_tree_build(const uint8_t* codes, int64_t n_codes, int M, int K, int max_height_folds, const float* codewords,
                    int Ds, dpq_tree** out);
+/* Same tree, with the edge search (the sort/group passes over all position subsets) on GPU `device`;
+ * the result is identical to dpq_tree_build's, node for node. */
+int dpq_tree_build_gpu(const uint8_t* codes, int64_t n_codes, int M, int K, int max_height_folds,
+                       const float* codewords, int Ds, int device, dpq_tree** out);
 int dpq_tree_stats(const dpq_tree* t, dpq_dtc_stats* stats);
 /* Borrowed arrays: which = 0 vec_id u32[n] (DFS position -> original id, QNode.vec_id h:80), 1 parent_pos u32[n],
  * 2 depth u8[n], 3 mask u16[n], 4 changed bytes, 5 root code u8[M], 6 edges (parent id, child id) u32[n-1][2]. */

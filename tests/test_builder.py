@@ -148,3 +148,35 @@ def test_end_to_end_vectors_to_query(lib, oracle):
         alld = sum(lut[m, codes[:, m]].astype(np.float64) for m in range(8)).astype(np.float32)
         assert np.array_equal(alld[orig[i]].view(np.uint32), dists[i].view(np.uint32))
         assert np.sort(alld)[k - 1] == dists[i][-1]                     # really the k best of the raw codes
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,M", [(1, 8), (2, 8), (777, 8), (50000, 8), (20000, 16)])
+def test_gpu_edge_search_builds_the_identical_tree(lib, n, M):
+    """SURVEY.md 8f row 1 on the GPU: the sort/group passes over every position subset run on the device
+    (hipCUB stable radix sort + grouping kernels) and must reproduce the host builder exactly."""
+    from deltapq_amd import api
+    if api.device_count() < 1:
+        pytest.fail("no GPU")
+    codes = clustered_codes(n, M, seed=n + 1)
+    host = api.DeltaTree(codes)
+    dev = api.DeltaTree(codes, device=0)
+    assert np.array_equal(host.edges, dev.edges)
+    assert np.array_equal(host.vec_id, dev.vec_id) and np.array_equal(host.payload(), dev.payload())
+    assert host.stats == dev.stats
+
+
+@pytest.mark.gpu
+def test_gpu_edge_search_speed_and_structure_1m(lib):
+    import time
+    from deltapq_amd import api, synth
+    n = 1_000_000
+    tree = synth.synth_tree(n, 8, seed=102, mean_diffs=3.0)
+    codes = synth.decode_tree_codes(tree)[np.random.default_rng(0).permutation(n)]
+    t0 = time.time()
+    dev = api.DeltaTree(codes, device=0)
+    t_gpu = time.time() - t0
+    assert dev.stats["n_diffs"] < 3.4 * n and dev.stats["max_depth"] <= 7
+    assert np.array_equal(tree_decode(dev), codes[dev.vec_id])
+    print("GPU-assisted build of 1M codes: %.2f s, %.2f diffs/node" % (t_gpu, dev.stats["n_diffs"] / n))
+    assert t_gpu < 20
