@@ -81,6 +81,6 @@ hipError_t launch_merge(const int32_t* d_ids, const float* d_dists, int n_lists,
 hipError_t launch_encode_pq(const float* d_vectors, int64_t n, int D, const float* d_codebook, int M, int K, int Ds,
                             uint8_t* d_codes, hipStream_t stream);
 size_t scan_lds_bytes(int M);
-size_t select_lds_bytes(int M);
+size_t select_lds_bytes(int M, int top_k);
 
 }  // namespace dpq

@@ -543,19 +543,57 @@ __device__ __forceinline__ void block_bitonic_sort(uint64_t* v, int n_pow2, int 
 }
 
 // k-th smallest (1-based rank `rank`) of keys[0..n) -- LDS or HBM -- by MSB-first
-// 8-bit radix select.  Histogram with LDS atomics, bin scan by one wavefront
-// (no barriers inside), 3 barriers per pass.
+// 8-bit radix select.  Distances of one query share their sign/exponent bits, so
+// raw keys would put every element into one bin for the first passes (thousands
+// of serialised LDS atomics): the passes run on (key - min) and start at the
+// first byte in which (max - min) is non-zero.  Histogram with LDS atomics, bin
+// scan by one wavefront (no barriers inside), 3 barriers per pass.
+// `ignore` (= ~0) marks padding entries; they sort last and are never selected
+// because rank <= number of valid keys.
 __device__ uint64_t block_radix_select(const uint64_t* keys, int n, int rank, uint32_t* hist, uint32_t* bcast,
                                        int tid, int nthreads) {
+    // block min / max of the valid keys (padding = ~0 is excluded from max)
+    uint64_t lo = ~0ull, hi = 0ull;
+    for (int i = tid; i < n; i += nthreads) {
+        const uint64_t k = keys[i];
+        if (k != ~0ull) {
+            lo = k < lo ? k : lo;
+            hi = k > hi ? k : hi;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const uint64_t olo = ((uint64_t)(uint32_t)__shfl_xor((int)(lo >> 32), off, 64) << 32) |
+                             (uint32_t)__shfl_xor((int)(uint32_t)lo, off, 64);
+        const uint64_t ohi = ((uint64_t)(uint32_t)__shfl_xor((int)(hi >> 32), off, 64) << 32) |
+                             (uint32_t)__shfl_xor((int)(uint32_t)hi, off, 64);
+        lo = olo < lo ? olo : lo;
+        hi = ohi > hi ? ohi : hi;
+    }
+    uint64_t* mm = reinterpret_cast<uint64_t*>(hist);  // [2 * waves] scratch, hist is free until the first pass
+    if ((tid & 63) == 0) {
+        mm[2 * (tid >> 6)] = lo;
+        mm[2 * (tid >> 6) + 1] = hi;
+    }
+    __syncthreads();
+    for (int w = 0; w < nthreads / 64; ++w) {
+        lo = mm[2 * w] < lo ? mm[2 * w] : lo;
+        hi = mm[2 * w + 1] > hi ? mm[2 * w + 1] : hi;
+    }
+    __syncthreads();
+    const uint64_t span = hi - lo;                                   // valid keys live in [0, span] after the shift
+    const int top = span ? (63 - __clzll((long long)span)) >> 3 : 0;  // most significant non-zero byte
     uint64_t prefix = 0;
     uint32_t rem = (uint32_t)rank;
-    for (int pass = 7; pass >= 0; --pass) {
+    for (int pass = top; pass >= 0; --pass) {
         if (tid < 256) hist[tid] = 0;
         __syncthreads();
         const int shift = 8 * pass;
         for (int i = tid; i < n; i += nthreads) {
-            const uint64_t key = keys[i];
-            const bool match = pass == 7 ? true : ((key >> (shift + 8)) == (prefix >> (shift + 8)));
+            const uint64_t raw = keys[i];
+            if (raw == ~0ull) continue;
+            const uint64_t key = raw - lo;
+            const bool match = pass == top ? true : ((key >> (shift + 8)) == (prefix >> (shift + 8)));
             if (match) atomicAdd(&hist[(uint32_t)(key >> shift) & 255u], 1u);
         }
         __syncthreads();
@@ -581,7 +619,7 @@ __device__ uint64_t block_radix_select(const uint64_t* keys, int n, int rank, ui
         prefix |= (uint64_t)bcast[0] << shift;
         rem = bcast[1];
     }
-    return prefix;
+    return prefix + lo;
 }
 
 __device__ __forceinline__ int32_t report_id(uint32_t pos, int64_t n_total) {
@@ -595,11 +633,15 @@ __global__ __launch_bounds__(kSelectThreads) void select_kernel(const SelectArgs
     constexpr int W = Cfg<M>::W;
     constexpr int TE = M * 256;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // winner arrays are sized by top_k (rounded up to a power of two for the final sort), not by the
+    // 2048 maximum: at top_k = 100 a block needs 35 KB instead of 66 KB and four blocks share a CU
+    int KP = 1;
+    while (KP < a.top_k) KP <<= 1;
     uint64_t* skeys = reinterpret_cast<uint64_t*>(smem);                              // [kSortMax] candidate keys
-    uint64_t* wkeys = skeys + kSortMax;                                               // [kMaxTopK] winner keys
-    uint32_t* win_id = reinterpret_cast<uint32_t*>(wkeys + kMaxTopK);                 // [kMaxTopK]
-    uint32_t* win_code = win_id + kMaxTopK;                                           // [kMaxTopK][W]
-    uint32_t* hist = win_code + W * kMaxTopK;                                         // [256]
+    uint64_t* wkeys = skeys + kSortMax;                                               // [KP] winner keys
+    uint32_t* win_id = reinterpret_cast<uint32_t*>(wkeys + KP);                       // [KP]
+    uint32_t* win_code = win_id + KP;                                                 // [KP][W]
+    uint32_t* hist = win_code + W * KP;                                               // [256]
     uint32_t* bcast = hist + 256;                                                     // [2]
     uint32_t* counters = bcast + 2;                                                   // [2]: winners, padding nodes
 
@@ -653,7 +695,7 @@ __global__ __launch_bounds__(kSelectThreads) void select_kernel(const SelectArgs
         const uint64_t key = keys[i];
         if (kk > 0 && key <= kth) {
             const uint32_t pos = atomicAdd(&counters[0], 1u);
-            if (pos < (uint32_t)kMaxTopK) {
+            if (pos < (uint32_t)KP) {
                 wkeys[pos] = key;
                 win_id[pos] = src_id[i];
 #pragma unroll
@@ -797,8 +839,10 @@ size_t scan_lds_bytes(int M) {
            QG * kStage * (1 + W) * sizeof(uint32_t);
 }
 
-size_t select_lds_bytes(int M) {
-    return (size_t)kSortMax * 8 + (size_t)kMaxTopK * 8 + (size_t)kMaxTopK * (1 + M / 4) * 4 + (256 + 2 + 2) * 4;
+size_t select_lds_bytes(int M, int top_k) {
+    size_t kp = 1;
+    while (kp < (size_t)top_k) kp <<= 1;
+    return (size_t)kSortMax * 8 + kp * 8 + kp * (1 + M / 4) * 4 + (256 + 2 + 2) * 4;
 }
 
 // hipFuncSetAttribute is per device; handles may live on several GPUs
@@ -859,10 +903,11 @@ hipError_t launch_scan(const ScanArgs& a, int n_slot_groups, int splits, hipStre
 template <int M>
 static hipError_t launch_select_m(const SelectArgs& a, int n_slots, hipStream_t stream) {
     static bool done[64] = {};
-    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&select_kernel<M>), select_lds_bytes(M), done);
+    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&select_kernel<M>),
+                                      select_lds_bytes(M, kMaxTopK), done);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(select_kernel<M>, dim3((unsigned)n_slots), dim3(kSelectThreads), select_lds_bytes(M), stream,
-                       a);
+    hipLaunchKernelGGL(select_kernel<M>, dim3((unsigned)n_slots), dim3(kSelectThreads),
+                       select_lds_bytes(M, a.top_k), stream, a);
     return hipGetLastError();
 }
 
