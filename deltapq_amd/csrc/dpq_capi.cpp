@@ -87,7 +87,7 @@ struct dpq_index {
     float* d_dists_stage = nullptr;
     size_t q_stage_floats = 0, out_stage_elems = 0;
     // cascade plan: visiting order of the segments, level bounds, decoded level 0
-    int plan_top_k = -1, plan_cap = -1;
+    int plan_top_k = -1, plan_cap = -1, plan_coarse = -1;
     std::vector<int> level_off, level_cnt;
     uint32_t* d_order = nullptr;
     uint32_t *d_l0_id = nullptr, *d_l0_code = nullptr;
@@ -156,8 +156,10 @@ int auto_cap(int top_k) { return std::max(4096, 32 * top_k); }
 // cascade.  Level 0 (<= 4096 nodes) is query independent: its segments are
 // decoded once here and every query evaluates that list exactly.  Later levels
 // are filter scans; expected survivors of level l = top_k * (bound[l]/bound[l-1] - 1).
-int ensure_plan(dpq_index* x, int top_k, int cap) {
-    if (x->plan_top_k == top_k && x->plan_cap == cap) return DPQ_OK;
+// Small batches (coarse == 1) are bound by the fixed cost per level (a launch + a select), not by survivor
+// handling, so they use steps of 16 and end up with three levels instead of five.
+int ensure_plan(dpq_index* x, int top_k, int cap, int coarse) {
+    if (x->plan_top_k == top_k && x->plan_cap == cap && x->plan_coarse == coarse) return DPQ_OK;
     const int64_t S = (int64_t)dpq::kChunk * x->img.chunks_per_segment;
     const int64_t nseg = x->img.n_segments;
     const int64_t s0 = std::min<int64_t>(nseg, std::max<int64_t>(1, dpq::kSortMax / S));
@@ -166,10 +168,12 @@ int ensure_plan(dpq_index* x, int top_k, int cap) {
         bounds.push_back(nseg);
     } else {
         bounds.push_back(nseg);
-        const int ratios[] = {2, 4, 8};
+        const int fine[] = {2, 4, 8};
+        // expected survivors of a level = top_k * (ratio - 1) must stay well inside the candidate buffer
+        const int wide = (int)std::max<int64_t>(2, std::min<int64_t>(16, cap / (2 * (int64_t)top_k)));
         int64_t b = nseg;
         for (int i = 0;; ++i) {
-            const int64_t nb = b / ratios[std::min(i, 2)];
+            const int64_t nb = b / (coarse ? wide : fine[std::min(i, 2)]);
             if (nb < 2 * s0) break;
             bounds.push_back(nb);
             b = nb;
@@ -209,6 +213,7 @@ int ensure_plan(dpq_index* x, int top_k, int cap) {
     }
     x->plan_top_k = top_k;
     x->plan_cap = cap;
+    x->plan_coarse = coarse;
     return DPQ_OK;
 }
 
@@ -252,7 +257,7 @@ int run_batch(dpq_index* x, const float* d_queries, int nq, int top_k, int32_t* 
     const int cap = x->cap_auto ? auto_cap(top_k) : std::max(x->cap, top_k);
     int rc;
     if ((rc = ensure_workspace(x, nqp, cap))) return rc;
-    if ((rc = ensure_plan(x, top_k, cap))) return rc;
+    if ((rc = ensure_plan(x, top_k, cap, nq <= 128 ? 1 : 0))) return rc;
 
     {
         Timer t(x, stream, 0);
