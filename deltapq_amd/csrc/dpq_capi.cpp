@@ -168,7 +168,12 @@ int ensure_plan(dpq_index* x, int top_k, int cap, int coarse) {
         bounds.push_back(nseg);
     } else {
         bounds.push_back(nseg);
-        const int fine[] = {2, 4, 8};
+        // large batches: level sizes shrink by 4, 8, 8 from the full index down (three filter levels at 1 M
+        // codes); measured best trade between per-level fixed cost and survivor handling.
+        // DPQ_PLAN_RATIOS=a,b,c overrides it for experiments.
+        int fine[] = {4, 8, 8};
+        if (const char* ev = getenv("DPQ_PLAN_RATIOS")) sscanf(ev, "%d,%d,%d", &fine[0], &fine[1], &fine[2]);
+        for (int& f : fine) f = std::max(2, f);
         // expected survivors of a level = top_k * (ratio - 1) must stay well inside the candidate buffer
         const int wide = (int)std::max<int64_t>(2, std::min<int64_t>(16, cap / (2 * (int64_t)top_k)));
         int64_t b = nseg;
