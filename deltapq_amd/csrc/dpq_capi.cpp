@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <type_traits>
@@ -1068,6 +1069,7 @@ int dpq_debug_scan_time(dpq_index* x, int nq, int pass_all, int reps, int splits
     sa.debug_pass = pass_all ? 2 : 1;
     sa.seg_list = nullptr;
     sa.n_seg_pass = x->img.n_segments;
+    if (const char* e = getenv("DPQ_DEBUG_NSEG")) sa.n_seg_pass = std::min(x->img.n_segments, atoi(e));
     sa.cand_count = x->d_cand_count;
     sa.cand_id = x->d_cand_id;
     sa.cand_code = x->d_cand_code;

@@ -644,12 +644,17 @@ __global__ __launch_bounds__(kSelectThreads) void select_kernel(const SelectArgs
     uint32_t* hist = win_code + W * KP;                                               // [256]
     uint32_t* bcast = hist + 256;                                                     // [2]
     uint32_t* counters = bcast + 2;                                                   // [2]: winners, padding nodes
+    float* T = reinterpret_cast<float*>(counters + 2);                                // [M][256] this query's exact tables
 
     const int slot = blockIdx.x;
     const int tid = threadIdx.x;
     const int q = a.slot_query ? a.slot_query[slot] : slot;
     if (q < 0) return;  // unused slot of a rerun group
-    const float* T = a.lut32 + (size_t)q * TE;
+    {   // stage the query's exact tables in LDS: every candidate gathers M entries, and scattered gathers
+        // from global memory are bound by the vector-memory address rate (~4 lanes per clock per CU)
+        const float4* src = reinterpret_cast<const float4*>(a.lut32 + (size_t)q * TE);
+        for (int i = tid; i < TE / 4; i += kSelectThreads) reinterpret_cast<float4*>(T)[i] = src[i];
+    }
     const bool shared = a.shared_id != nullptr;
     const uint32_t cnt = shared ? (uint32_t)a.shared_n : a.cand_count[slot];
     const int n = shared ? a.shared_n : (int)min(cnt, (uint32_t)a.cap);
@@ -842,7 +847,7 @@ size_t scan_lds_bytes(int M) {
 size_t select_lds_bytes(int M, int top_k) {
     size_t kp = 1;
     while (kp < (size_t)top_k) kp <<= 1;
-    return (size_t)kSortMax * 8 + kp * 8 + kp * (1 + M / 4) * 4 + (256 + 2 + 2) * 4;
+    return (size_t)kSortMax * 8 + kp * 8 + kp * (1 + M / 4) * 4 + (256 + 2 + 2) * 4 + (size_t)M * 256 * 4;
 }
 
 // hipFuncSetAttribute is per device; handles may live on several GPUs
