@@ -82,6 +82,8 @@ struct dpq_index {
     uint32_t *d_cand_count = nullptr, *d_cand_id = nullptr, *d_cand_code = nullptr, *d_overflow = nullptr;
     uint64_t *d_keys = nullptr, *d_thr_key = nullptr;
     uint32_t* h_overflow = nullptr;  // pinned
+    uint32_t* h_any = nullptr;       // pinned + mapped: set by select_kernel when any query overflowed
+    uint32_t* d_any = nullptr;       // device address of h_any
     // staging for the host-pointer entry point
     float* d_q_stage = nullptr;
     int32_t* d_ids_stage = nullptr;
@@ -95,6 +97,7 @@ struct dpq_index {
     int l0_segments = 0;
     // profiling
     bool prof = false;
+    bool prof_scan_only = false;     // events around the scan launches only (each event pair costs ~4 us of stream time)
     std::vector<EventPair> events;
     std::vector<hipEvent_t> ev_pool;
     dpq_profile prof_acc{};
@@ -105,7 +108,8 @@ struct dpq_index {
             return e;
         }
         hipEvent_t e;
-        hipEventCreate(&e);
+        // timing events between kernels of one stream: no system-scope fence needed (saves ~2 us per record)
+        hipEventCreateWithFlags(&e, hipEventDisableSystemFence);
         return e;
     }
 };
@@ -144,6 +148,10 @@ int ensure_workspace(dpq_index* x, int slots, int cap) {
     if ((rc = dev_alloc(&x->d_keys, (size_t)slots * cap))) return rc;
     if ((rc = dev_alloc(&x->d_thr_key, (size_t)slots))) return rc;
     if (!x->h_overflow) DPQ_HIP(hipHostMalloc(reinterpret_cast<void**>(&x->h_overflow), sizeof(uint32_t) * 4096));
+    if (!x->h_any) {
+        DPQ_HIP(hipHostMalloc(reinterpret_cast<void**>(&x->h_any), sizeof(uint32_t), hipHostMallocMapped));
+        DPQ_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&x->d_any), x->h_any, 0));
+    }
     x->ws_slots = slots;
     x->ws_cap = cap;
     return DPQ_OK;
@@ -229,7 +237,8 @@ struct Timer {
     int kind;
     bool on;
     EventPair ep{};
-    Timer(dpq_index* x_, hipStream_t s_, int kind_) : x(x_), s(s_), kind(kind_), on(x_->prof) {
+    Timer(dpq_index* x_, hipStream_t s_, int kind_)
+        : x(x_), s(s_), kind(kind_), on(x_->prof && (kind_ == 1 || !x_->prof_scan_only)) {
         if (on) {
             ep.kind = kind;
             ep.a = x->get_event();
@@ -267,12 +276,12 @@ int run_batch(dpq_index* x, const float* d_queries, int nq, int top_k, int32_t* 
 
     {
         Timer t(x, stream, 0);
-        DPQ_HIP(dpq::launch_lut_build(x->d_codebook, d_queries, nq, x->M, x->K, x->Ds, x->d_lut32, x->d_lut_min,
-                                      stream));
+        // also clears the candidate counters and overflow flags of the nqp slots
+        DPQ_HIP(dpq::launch_lut_build(x->d_codebook, d_queries, nq, nqp, x->M, x->K, x->Ds, x->d_lut32, x->d_lut_min,
+                                      x->d_cand_count, x->d_overflow, stream));
     }
     if (x->prof) x->prof_acc.lut_launches++;
-    DPQ_HIP(hipMemsetAsync(x->d_cand_count, 0, sizeof(uint32_t) * nqp, stream));
-    DPQ_HIP(hipMemsetAsync(x->d_overflow, 0, sizeof(uint32_t) * nqp, stream));
+    *x->h_any = 0;  // no batch of this index is in flight here (run_batch ends synchronised)
 
     dpq::ScanArgs sa{};
     sa.img = x->img;
@@ -297,6 +306,7 @@ int run_batch(dpq_index* x, const float* d_queries, int nq, int top_k, int32_t* 
     se.top_k = top_k;
     se.thr_key = x->d_thr_key;
     se.overflow = x->d_overflow;
+    se.any_overflow = x->d_any;
     se.out_ids = d_ids;
     se.out_dists = d_dists;
     se.n_codes_total = x->plain ? -1 : x->img.n_codes_total;
@@ -344,6 +354,8 @@ int run_batch(dpq_index* x, const float* d_queries, int nq, int top_k, int32_t* 
 
     // The only host synchronisation of the batch: did any query drop candidates
     // at some level (buffer overflow)?  Then its list may miss entries.
+    DPQ_HIP(hipStreamSynchronize(stream));
+    if (*reinterpret_cast<volatile uint32_t*>(x->h_any) == 0) return DPQ_OK;
     std::vector<int> over;
     for (int base = 0; base < nq; base += 4096) {
         const int n = std::min(4096, nq - base);
@@ -425,6 +437,7 @@ int run_batch(dpq_index* x, const float* d_queries, int nq, int top_k, int32_t* 
         se.keys = c_keys;
         se.thr_key = c_tk;
         se.overflow = c_over;
+        se.any_overflow = nullptr;
         se.final_pass = 1;
         chk(dpq::launch_select(se, x->M, slots2, stream));
         chk(hipStreamSynchronize(stream));
@@ -945,6 +958,7 @@ int dpq_close(dpq_index* x) {
     hipFree(x->d_ids_stage);
     hipFree(x->d_dists_stage);
     if (x->h_overflow) hipHostFree(x->h_overflow);
+    if (x->h_any) hipHostFree(x->h_any);
     delete x;
     return DPQ_OK;
 }
@@ -1066,7 +1080,7 @@ int dpq_debug_scan_time(dpq_index* x, int nq, int pass_all, int reps, int splits
     sa.thr_key = x->d_thr_key;
     sa.slot_query = nullptr;
     sa.n_queries = nq;
-    sa.debug_pass = pass_all ? 2 : 1;
+    sa.debug_pass = pass_all == 2 ? 0 : (pass_all ? 2 : 1);  // 2: the thresholds the last batch left behind
     sa.seg_list = nullptr;
     sa.n_seg_pass = x->img.n_segments;
     if (const char* e = getenv("DPQ_DEBUG_NSEG")) sa.n_seg_pass = std::min(x->img.n_segments, atoi(e));
@@ -1134,6 +1148,7 @@ int dpq_debug_select_time(dpq_index* x, int nq, int top_k, int flags, int reps, 
 int dpq_profile_enable(dpq_index* x, int on) {
     if (!x) return fail(DPQ_ERR_ARG, "NULL index");
     x->prof = on != 0;
+    x->prof_scan_only = on == 2;
     return DPQ_OK;
 }
 

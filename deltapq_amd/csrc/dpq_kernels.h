@@ -63,14 +63,18 @@ struct SelectArgs {
     int32_t final_pass;            // 1: write ids/dists; 0: carry winners to the next level
     uint64_t* thr_key;             // out [slots]: k-th smallest key seen so far (upper bound of the final one)
     uint32_t* overflow;            // out [slots]: set to 1 when a level dropped candidates (sticky)
+    uint32_t* any_overflow;        // out (may be NULL): one word in pinned host memory, set to 1 with any overflow[slot]
     int32_t* out_ids;              // [nq][top_k]
     float* out_dists;              // [nq][top_k]
     int64_t n_codes_total;         // N for the even-N id quirk of the DTC scan; odd (-1) for the plain scan
     int32_t fp32_accum;            // 1: plain-scan rule, distance accumulated in fp32 (h:2658-2662)
 };
 
-hipError_t launch_lut_build(const float* d_codebook, const float* d_queries, int nq, int M, int K, int Ds,
-                            float* d_lut32, float* d_lut_min, hipStream_t stream);
+// Builds the exact tables of queries [0, nq) and clears the candidate counters / overflow flags of
+// slots [0, n_slots) (either may be NULL).
+hipError_t launch_lut_build(const float* d_codebook, const float* d_queries, int nq, int n_slots, int M, int K, int Ds,
+                            float* d_lut32, float* d_lut_min, uint32_t* d_cand_count, uint32_t* d_overflow,
+                            hipStream_t stream);
 hipError_t launch_decode_segments(const DeviceImage& img, const uint32_t* seg_list, int n_seg, uint32_t* out_id,
                                   uint32_t* out_code, hipStream_t stream);
 hipError_t launch_scan(const ScanArgs& a, int n_slot_groups, int splits, hipStream_t stream);

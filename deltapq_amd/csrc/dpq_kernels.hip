@@ -62,45 +62,77 @@ __device__ __forceinline__ uint64_t make_key(float d, uint32_t id) {
 }
 
 // ---------------------------------------------------------------------------
-// a3: LUT build.  grid = (nq, M), block = 256 (one thread per centroid).
-// Output layout [query][m][256] fp32 (exact tables, read by select_kernel).
+// a3: LUT build.  grid = (slots / kLutQueries, M), block = 256 (one thread per
+// centroid; its codebook row is loaded once and reused for kLutQueries queries,
+// whose sub-vectors are wave-uniform scalar loads).
+// Output layout [query][m][256] fp32 (exact tables, read by select_kernel and
+// by the scan prologue) + the per-(query, m) minima that anchor the filter
+// quantisation.  Also clears the per-slot candidate counters and overflow
+// flags of the batch (saves two fill launches per batch).
 // ---------------------------------------------------------------------------
+constexpr int kLutQueries = 8;
+
 __global__ __launch_bounds__(256) void lut_build_kernel(const float* __restrict__ codebook,
-                                                         const float* __restrict__ queries, int M, int K, int Ds,
-                                                         float* __restrict__ lut, float* __restrict__ lut_min) {
-    __shared__ uint32_t minbits;
-    const int q = blockIdx.x, m = blockIdx.y, k = threadIdx.x;
-    if (k == 0) minbits = 0x7f800000u;
-    __syncthreads();
-    float acc = 0.0f;
+                                                         const float* __restrict__ queries, int nq, int n_slots, int M,
+                                                         int K, int Ds, float* __restrict__ lut,
+                                                         float* __restrict__ lut_min, uint32_t* __restrict__ cand_count,
+                                                         uint32_t* __restrict__ overflow) {
+    __shared__ uint32_t wave_min[4][kLutQueries];
+    const int q0 = blockIdx.x * kLutQueries, m = blockIdx.y, k = threadIdx.x;
+    if (m == 0 && k < kLutQueries && q0 + k < n_slots) {
+        if (cand_count) cand_count[q0 + k] = 0;
+        if (overflow) overflow[q0 + k] = 0;
+    }
+    if (q0 >= nq) return;  // padding slots only
+    float acc[kLutQueries];
+#pragma unroll
+    for (int j = 0; j < kLutQueries; ++j) acc[j] = 0.0f;
     if (k < K) {
         const float* c = codebook + ((size_t)m * K + k) * Ds;
-        const float* qv = queries + (size_t)q * M * Ds + (size_t)m * Ds;
+        const float* qv = queries + (size_t)q0 * M * Ds + (size_t)m * Ds;  // query j: qv + j * M * Ds (clamped to nq - 1)
+        const size_t qstride = (size_t)M * Ds;
         // h:2845-2846: `float += pow(float - float, 2)`, d ascending
-        auto step = [&](float cv, float qd) {
+        auto step = [&](float& a, float cv, float qd) {
             const float diff = __fsub_rn(cv, qd);                      // fp32 subtract
             const double sq = __dmul_rn((double)diff, (double)diff);   // pow(.,2): exact in fp64
-            acc = (float)__dadd_rn((double)acc, sq);                   // float += double
+            a = (float)__dadd_rn((double)a, sq);                       // float += double
         };
         if ((Ds & 3) == 0) {  // rows are 16-byte aligned: one dwordx4 load per 4 dimensions
             const float4* c4 = reinterpret_cast<const float4*>(c);
             for (int d = 0; d < Ds; d += 4) {
                 const float4 v = c4[d >> 2];
-                step(v.x, qv[d]);
-                step(v.y, qv[d + 1]);
-                step(v.z, qv[d + 2]);
-                step(v.w, qv[d + 3]);
+#pragma unroll
+                for (int j = 0; j < kLutQueries; ++j) {
+                    const float* qj = qv + (size_t)min(j, nq - 1 - q0) * qstride + d;
+                    step(acc[j], v.x, qj[0]);
+                    step(acc[j], v.y, qj[1]);
+                    step(acc[j], v.z, qj[2]);
+                    step(acc[j], v.w, qj[3]);
+                }
             }
         } else {
-            for (int d = 0; d < Ds; ++d) step(c[d], qv[d]);
+            for (int d = 0; d < Ds; ++d) {
+                const float cv = c[d];
+#pragma unroll
+                for (int j = 0; j < kLutQueries; ++j) step(acc[j], cv, qv[(size_t)min(j, nq - 1 - q0) * qstride + d]);
+            }
         }
-        atomicMin(&minbits, __float_as_uint(acc));                     // acc >= 0: uint order == float order
     } else {
-        acc = INFINITY;  // centroids beyond K do not exist; no valid code points at them
+#pragma unroll
+        for (int j = 0; j < kLutQueries; ++j) acc[j] = INFINITY;  // centroids beyond K do not exist; no valid code points at them
     }
-    lut[((size_t)q * M + m) * 256 + k] = acc;
+#pragma unroll
+    for (int j = 0; j < kLutQueries; ++j) {
+        if (q0 + j < nq) lut[((size_t)(q0 + j) * M + m) * 256 + k] = acc[j];
+        uint32_t v = __float_as_uint(acc[j]);  // acc >= 0: uint order == float order
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v = min(v, (uint32_t)__shfl_xor((int)v, o));
+        if ((k & 63) == 0) wave_min[k >> 6][j] = v;
+    }
     __syncthreads();
-    if (k == 0) lut_min[(size_t)q * M + m] = __uint_as_float(minbits);  // feeds the filter quantisation
+    if (k < kLutQueries && q0 + k < nq)  // feeds the filter quantisation
+        lut_min[(size_t)(q0 + k) * M + m] =
+            __uint_as_float(min(min(wave_min[0][k], wave_min[1][k]), min(wave_min[2][k], wave_min[3][k])));
 }
 
 // ---------------------------------------------------------------------------
@@ -666,7 +698,10 @@ __global__ __launch_bounds__(kSelectThreads) void select_kernel(const SelectArgs
         counters[0] = 0;
         counters[1] = 0;
         // candidates were dropped at this level: the final list may miss entries -> host reruns this query
-        if (!shared && cnt > (uint32_t)a.cap) a.overflow[slot] = 1u;
+        if (!shared && cnt > (uint32_t)a.cap) {
+            a.overflow[slot] = 1u;
+            if (a.any_overflow) *reinterpret_cast<volatile uint32_t*>(a.any_overflow) = 1u;  // host-visible summary
+        }
     }
     __syncthreads();
 
@@ -863,11 +898,14 @@ static hipError_t ensure_dynamic_lds(const void* fn, size_t bytes, bool* done) {
     return hipSuccess;
 }
 
-hipError_t launch_lut_build(const float* d_codebook, const float* d_queries, int nq, int M, int K, int Ds,
-                            float* d_lut32, float* d_lut_min, hipStream_t stream) {
+hipError_t launch_lut_build(const float* d_codebook, const float* d_queries, int nq, int n_slots, int M, int K, int Ds,
+                            float* d_lut32, float* d_lut_min, uint32_t* d_cand_count, uint32_t* d_overflow,
+                            hipStream_t stream) {
     if (nq <= 0) return hipSuccess;
-    hipLaunchKernelGGL(lut_build_kernel, dim3((unsigned)nq, (unsigned)M), dim3(256), 0, stream, d_codebook,
-                       d_queries, M, K, Ds, d_lut32, d_lut_min);
+    n_slots = std::max(n_slots, nq);
+    hipLaunchKernelGGL(lut_build_kernel, dim3((unsigned)((n_slots + kLutQueries - 1) / kLutQueries), (unsigned)M),
+                       dim3(256), 0, stream, d_codebook, d_queries, nq, n_slots, M, K, Ds, d_lut32, d_lut_min,
+                       d_cand_count, d_overflow);
     return hipGetLastError();
 }
 

@@ -228,7 +228,7 @@ int dpq_merge_topk_device(const int32_t* d_ids, const float* d_dists, int n_list
                           int32_t* d_out_ids, float* d_out_dists, int device, void* hip_stream);
 
 /* ---- measurement -------------------------------------------------------- */
-int dpq_profile_enable(dpq_index* idx, int on);
+int dpq_profile_enable(dpq_index* idx, int on);  /* 0 off, 1 every kernel, 2 scan launches only (less event overhead) */
 int dpq_profile_reset(dpq_index* idx);
 int dpq_profile_read(dpq_index* idx, dpq_profile* out);
 

@@ -15,8 +15,8 @@ with api.DeltaPQIndex.open_memory(payload, n, 8, 256) as idx:
     idx.query_batch(qs, 100)
     for nseg in (0, 16, 106, 856, 2930, 3907):
         os.environ["DPQ_DEBUG_NSEG"] = str(nseg)
-        for splits in (0, 2, 4, 8):
+        for mode in (0, 2):
             ms = ctypes.c_float()
-            rc = lib.dpq_debug_scan_time(idx._h, nq, 0, 20, splits, ms)
+            rc = lib.dpq_debug_scan_time(idx._h, nq, mode, 20, 0, ms)
             assert rc == 0, lib.dpq_last_error()
-            print("nseg=%d splits=%d: %.1f us" % (nseg, splits, ms.value * 1e3), flush=True)
+            print("nseg=%d mode=%d: %.1f us" % (nseg, mode, ms.value * 1e3), flush=True)
