@@ -254,7 +254,7 @@ def main():
                             "%.2f B/code, %.2f diffs/node" % (wl["desc"], args.n, args.m, k, nq, wl["n_bytes"] / args.n,
                                                               (wl["n_bytes"] - args.m) / args.n - (1.5 if args.m <= 8 else 2.5)),
                 "n_codes": args.n, "queries_per_step": nq, "topk": k, "n_bytes": int(wl["n_bytes"]),
-                "sharding": "dfs-range x%d" % world, "queries_per_decode_pass": 32 if args.m <= 8 else 16,
+                "sharding": "dfs-range x%d" % world, "queries_per_decode_pass": 64 if args.m <= 8 else 16,
             },
             "roofline": {
                 "bound": "hbm",

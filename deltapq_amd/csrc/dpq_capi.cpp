@@ -79,8 +79,9 @@ struct dpq_index {
     int ws_slots = 0, ws_cap = 0;
     float* d_lut32 = nullptr;       // exact tables [query][8][256]
     float* d_lut_min = nullptr;     // [query][8] minima (filter quantisation in the scan prologue)
-    uint32_t *d_cand_count = nullptr, *d_cand_id = nullptr, *d_cand_code = nullptr, *d_overflow = nullptr;
-    uint64_t *d_keys = nullptr, *d_thr_key = nullptr;
+    uint32_t *d_cand_count = nullptr, *d_overflow = nullptr;
+    uint64_t *d_cand_key = nullptr, *d_thr_key = nullptr;  // candidate keys [slots][ws_cap], threshold keys [slots]
+    uint64_t* d_scratch = nullptr;   // [slots][ws_cap] contiguous copy of a slot's keys when they exceed the select's LDS list
     uint32_t* h_overflow = nullptr;  // pinned
     uint32_t* h_any = nullptr;       // pinned + mapped: set by select_kernel when any query overflowed
     uint32_t* d_any = nullptr;       // device address of h_any
@@ -120,15 +121,14 @@ void free_workspace(dpq_index* x) {
     hipFree(x->d_lut32);
     hipFree(x->d_lut_min);
     hipFree(x->d_cand_count);
-    hipFree(x->d_cand_id);
-    hipFree(x->d_cand_code);
+    hipFree(x->d_cand_key);
+    hipFree(x->d_scratch);
     hipFree(x->d_overflow);
-    hipFree(x->d_keys);
     hipFree(x->d_thr_key);
     x->d_lut32 = nullptr;
     x->d_lut_min = nullptr;
-    x->d_cand_count = x->d_cand_id = x->d_cand_code = x->d_overflow = nullptr;
-    x->d_keys = x->d_thr_key = nullptr;
+    x->d_cand_count = x->d_overflow = nullptr;
+    x->d_cand_key = x->d_thr_key = x->d_scratch = nullptr;
     x->ws_slots = x->ws_cap = 0;
 }
 
@@ -138,14 +138,12 @@ int ensure_workspace(dpq_index* x, int slots, int cap) {
     cap = std::max(cap, x->ws_cap);
     free_workspace(x);
     int rc;
-    const size_t W = (size_t)x->M / 4;
     if ((rc = dev_alloc(&x->d_lut32, (size_t)slots * x->M * 256))) return rc;
     if ((rc = dev_alloc(&x->d_lut_min, (size_t)slots * x->M))) return rc;
-    if ((rc = dev_alloc(&x->d_cand_count, (size_t)slots))) return rc;
-    if ((rc = dev_alloc(&x->d_cand_id, (size_t)slots * cap))) return rc;
-    if ((rc = dev_alloc(&x->d_cand_code, (size_t)slots * cap * W))) return rc;
+    if ((rc = dev_alloc(&x->d_cand_count, (size_t)slots * dpq::kRegionStride))) return rc;
+    if ((rc = dev_alloc(&x->d_cand_key, (size_t)slots * cap))) return rc;
+    if ((rc = dev_alloc(&x->d_scratch, (size_t)slots * cap))) return rc;
     if ((rc = dev_alloc(&x->d_overflow, (size_t)slots))) return rc;
-    if ((rc = dev_alloc(&x->d_keys, (size_t)slots * cap))) return rc;
     if ((rc = dev_alloc(&x->d_thr_key, (size_t)slots))) return rc;
     if (!x->h_overflow) DPQ_HIP(hipHostMalloc(reinterpret_cast<void**>(&x->h_overflow), sizeof(uint32_t) * 4096));
     if (!x->h_any) {
@@ -263,6 +261,27 @@ int splits_for(int n_seg_pass, int n_groups) {
     return std::max(1, std::min(by_work, want));
 }
 
+// Candidate-buffer geometry of one scan launch: region 0 (top_k keys) carries the winners of the
+// previous level, then one region per scan workgroup of a query group (no global atomics: a
+// workgroup appends to its own region).
+struct Regions {
+    int splits;
+    int region_cap;
+    int64_t stride;  // keys per slot
+};
+
+Regions regions_for(const dpq_index* x, int n_seg_pass, int n_groups, int top_k, int cap) {
+    Regions r;
+    r.splits = splits_for(n_seg_pass, n_groups);
+    r.region_cap = (cap - top_k) / r.splits;
+    // automatic sizing: a query's candidates cluster in few segments (DFS neighbours are similar codes), so a
+    // region must absorb a few dense segments; 16 K keys per slot, at least one segment's worth per region
+    if (x->cap_auto) r.region_cap = std::max(r.region_cap, std::max(256, 16384 / r.splits));
+    r.region_cap = std::max(r.region_cap, 1);
+    r.stride = (int64_t)top_k + (int64_t)r.splits * r.region_cap;
+    return r;
+}
+
 // One sub-batch (nq <= kMaxBatchQueries) end to end on `stream`.
 int run_batch(dpq_index* x, const float* d_queries, int nq, int top_k, int32_t* d_ids, float* d_dists,
               hipStream_t stream) {
@@ -271,14 +290,19 @@ int run_batch(dpq_index* x, const float* d_queries, int nq, int top_k, int32_t* 
     const int ngroups = nqp / QG;
     const int cap = x->cap_auto ? auto_cap(top_k) : std::max(x->cap, top_k);
     int rc;
-    if ((rc = ensure_workspace(x, nqp, cap))) return rc;
     if ((rc = ensure_plan(x, top_k, cap, nq <= 128 ? 1 : 0))) return rc;
+    int64_t stride = top_k;
+    for (size_t l = 1; l < x->level_cnt.size(); ++l)
+        stride = std::max(stride, regions_for(x, x->level_cnt[l], ngroups, top_k, cap).stride);
+    if (stride > INT32_MAX) return fail(DPQ_ERR_NOMEM, "candidate buffer too large");
+    if ((rc = ensure_workspace(x, nqp, (int)stride))) return rc;
+    stride = x->ws_cap;
 
     {
         Timer t(x, stream, 0);
-        // also clears the candidate counters and overflow flags of the nqp slots
+        // also clears the overflow flags of the nqp slots
         DPQ_HIP(dpq::launch_lut_build(x->d_codebook, d_queries, nq, nqp, x->M, x->K, x->Ds, x->d_lut32, x->d_lut_min,
-                                      x->d_cand_count, x->d_overflow, stream));
+                                      nullptr, x->d_overflow, stream));
     }
     if (x->prof) x->prof_acc.lut_launches++;
     *x->h_any = 0;  // no batch of this index is in flight here (run_batch ends synchronised)
@@ -291,18 +315,18 @@ int run_batch(dpq_index* x, const float* d_queries, int nq, int top_k, int32_t* 
     sa.slot_query = nullptr;
     sa.n_queries = nq;
     sa.cand_count = x->d_cand_count;
-    sa.cand_id = x->d_cand_id;
-    sa.cand_code = x->d_cand_code;
-    sa.cap = cap;
+    sa.cand_key = x->d_cand_key;
+    sa.cand_stride = stride;
+    sa.region_off = top_k;
 
     dpq::SelectArgs se{};
     se.cand_count = x->d_cand_count;
-    se.cand_id = x->d_cand_id;
-    se.cand_code = x->d_cand_code;
-    se.cap = cap;
+    se.cand_key = x->d_cand_key;
+    se.cand_stride = stride;
+    se.region_off = top_k;
+    se.scratch = x->d_scratch;
     se.lut32 = x->d_lut32;
     se.slot_query = nullptr;
-    se.keys = x->d_keys;
     se.top_k = top_k;
     se.thr_key = x->d_thr_key;
     se.overflow = x->d_overflow;
@@ -333,9 +357,28 @@ int run_batch(dpq_index* x, const float* d_queries, int nq, int top_k, int32_t* 
             // filter scan of the next slice of segments; appends behind the carried winners
             sa.seg_list = x->d_order + x->level_off[l];
             sa.n_seg_pass = x->level_cnt[l];
+            static const bool dbg_counts = getenv("DPQ_DEBUG_COUNTS") != nullptr;
+            unsigned long long* d_cnt = nullptr;
+            if (dbg_counts) {
+                hipMalloc(reinterpret_cast<void**>(&d_cnt), 16);
+                hipMemsetAsync(d_cnt, 0, 16, stream);
+                sa.counters = d_cnt;
+            }
+            const Regions rg = regions_for(x, sa.n_seg_pass, ngroups, top_k, cap);
+            sa.region_cap = se.region_cap = rg.region_cap;
+            se.n_regions = 1 + rg.splits;
             {
                 Timer t(x, stream, 1);
-                DPQ_HIP(dpq::launch_scan(sa, ngroups, splits_for(sa.n_seg_pass, ngroups), stream));
+                DPQ_HIP(dpq::launch_scan(sa, ngroups, rg.splits, stream));
+            }
+            if (dbg_counts) {
+                unsigned long long h[2];
+                hipMemcpyAsync(h, d_cnt, 16, hipMemcpyDeviceToHost, stream);
+                hipStreamSynchronize(stream);
+                hipFree(d_cnt);
+                sa.counters = nullptr;
+                fprintf(stderr, "level %zu: %d segments, %llu pairs checked exactly (%.0f/query), %llu candidates (%.0f/query)\n", l,
+                        sa.n_seg_pass, h[0], (double)h[0] / nq, h[1], (double)h[1] / nq);
             }
             if (x->prof) {
                 x->prof_acc.scan_launches++;
@@ -366,6 +409,13 @@ int run_batch(dpq_index* x, const float* d_queries, int nq, int top_k, int32_t* 
             if (x->h_overflow[i]) over.push_back(base + i);
     }
     if (over.empty()) return DPQ_OK;
+    if (getenv("DPQ_DEBUG_COUNTS")) {
+        std::vector<uint32_t> hc((size_t)nqp * dpq::kRegionStride);
+        hipMemcpy(hc.data(), x->d_cand_count, hc.size() * 4, hipMemcpyDeviceToHost);
+        fprintf(stderr, "%zu queries overflowed; last level region counts of query %d:", over.size(), over[0]);
+        for (int r = 0; r < 18; ++r) fprintf(stderr, " %u", hc[(size_t)over[0] * dpq::kRegionStride + r]);
+        fprintf(stderr, "\n");
+    }
 
     // Rerun the affected queries over the whole shard in ONE filter level.  The
     // k-th key of the incomplete list is still a valid upper bound (its entries
@@ -380,21 +430,23 @@ int run_batch(dpq_index* x, const float* d_queries, int nq, int top_k, int32_t* 
         slot_query[i] = over[i];
         k2[i] = h_key[(size_t)over[i]];
     }
-    int64_t cap2 = std::max(cap, 8 * top_k);
+    // few, large regions: with a tight threshold the candidates of a query may all sit in one workgroup's share
+    const int splits2 = std::min(16, splits_for(x->img.n_segments, ng2));
+    int64_t rcap2 = std::max<int64_t>(2 * (int64_t)top_k, 1024);
     for (int attempt = 0;; ++attempt) {
+        const int64_t stride2 = (int64_t)top_k + (int64_t)splits2 * rcap2;
         int32_t* d_slot_query = nullptr;
-        uint32_t *c_count = nullptr, *c_id = nullptr, *c_code = nullptr, *c_over = nullptr;
-        uint64_t *c_keys = nullptr, *c_tk = nullptr;
+        uint32_t *c_count = nullptr, *c_over = nullptr;
+        uint64_t *c_keys = nullptr, *c_scratch = nullptr, *c_tk = nullptr;
         auto cleanup = [&]() {
-            hipFree(d_slot_query); hipFree(c_count); hipFree(c_id);
-            hipFree(c_code); hipFree(c_over); hipFree(c_keys); hipFree(c_tk);
+            hipFree(d_slot_query); hipFree(c_count); hipFree(c_over); hipFree(c_keys); hipFree(c_scratch); hipFree(c_tk);
         };
-        rc = dev_alloc(&d_slot_query, (size_t)slots2);
-        if (!rc) rc = dev_alloc(&c_count, (size_t)slots2);
-        if (!rc) rc = dev_alloc(&c_id, (size_t)slots2 * cap2);
-        if (!rc) rc = dev_alloc(&c_code, (size_t)slots2 * cap2 * (x->M / 4));
+        rc = stride2 > INT32_MAX ? fail(DPQ_ERR_NOMEM, "candidate buffer too large") : DPQ_OK;
+        if (!rc) rc = dev_alloc(&d_slot_query, (size_t)slots2);
+        if (!rc) rc = dev_alloc(&c_count, (size_t)slots2 * dpq::kRegionStride);
         if (!rc) rc = dev_alloc(&c_over, (size_t)slots2);
-        if (!rc) rc = dev_alloc(&c_keys, (size_t)slots2 * cap2);
+        if (!rc) rc = dev_alloc(&c_keys, (size_t)slots2 * stride2);
+        if (!rc) rc = dev_alloc(&c_scratch, (size_t)slots2 * stride2);
         if (!rc) rc = dev_alloc(&c_tk, (size_t)slots2);
         if (rc) {
             cleanup();
@@ -404,7 +456,7 @@ int run_batch(dpq_index* x, const float* d_queries, int nq, int top_k, int32_t* 
         auto chk = [&](hipError_t r) { if (e == hipSuccess) e = r; };
         chk(hipMemcpy(d_slot_query, slot_query.data(), sizeof(int32_t) * slots2, hipMemcpyHostToDevice));
         chk(hipMemcpy(c_tk, k2.data(), sizeof(uint64_t) * slots2, hipMemcpyHostToDevice));
-        chk(hipMemsetAsync(c_count, 0, sizeof(uint32_t) * slots2, stream));
+        chk(hipMemsetAsync(c_count, 0, sizeof(uint32_t) * slots2 * dpq::kRegionStride, stream));  // region 0: no carried winners
         chk(hipMemsetAsync(c_over, 0, sizeof(uint32_t) * slots2, stream));
         sa.seg_list = nullptr;
         sa.n_seg_pass = x->img.n_segments;
@@ -412,29 +464,30 @@ int run_batch(dpq_index* x, const float* d_queries, int nq, int top_k, int32_t* 
         sa.slot_query = d_slot_query;
         sa.n_queries = slots2;
         sa.cand_count = c_count;
-        sa.cand_id = c_id;
-        sa.cand_code = c_code;
-        sa.cap = (int32_t)cap2;
-        chk(dpq::launch_scan(sa, ng2, splits_for(sa.n_seg_pass, ng2), stream));
-        std::vector<uint32_t> h_cnt((size_t)slots2, 0);
-        chk(hipMemcpyAsync(h_cnt.data(), c_count, sizeof(uint32_t) * slots2, hipMemcpyDeviceToHost, stream));
+        sa.cand_key = c_keys;
+        sa.cand_stride = stride2;
+        sa.region_cap = (int32_t)rcap2;
+        chk(dpq::launch_scan(sa, ng2, splits2, stream));
+        std::vector<uint32_t> h_cnt((size_t)slots2 * dpq::kRegionStride, 0);
+        chk(hipMemcpyAsync(h_cnt.data(), c_count, sizeof(uint32_t) * h_cnt.size(), hipMemcpyDeviceToHost, stream));
         chk(hipStreamSynchronize(stream));
         uint32_t max_cnt = 0;
         for (uint32_t c : h_cnt) max_cnt = std::max(max_cnt, c);
-        if (e == hipSuccess && (int64_t)max_cnt > cap2 && attempt < 4) {
+        if (e == hipSuccess && (int64_t)max_cnt > rcap2 && attempt < 4) {
             cleanup();
-            cap2 = (int64_t)max_cnt + 64;
+            rcap2 = (int64_t)max_cnt + 64;
             continue;
         }
         se.shared_id = nullptr;
         se.shared_code = nullptr;
         se.shared_n = 0;
         se.cand_count = c_count;
-        se.cand_id = c_id;
-        se.cand_code = c_code;
-        se.cap = (int32_t)cap2;
+        se.cand_key = c_keys;
+        se.cand_stride = stride2;
+        se.region_cap = (int32_t)rcap2;
+        se.n_regions = 1 + splits2;
+        se.scratch = c_scratch;
         se.slot_query = d_slot_query;
-        se.keys = c_keys;
         se.thr_key = c_tk;
         se.overflow = c_over;
         se.any_overflow = nullptr;
@@ -443,7 +496,7 @@ int run_batch(dpq_index* x, const float* d_queries, int nq, int top_k, int32_t* 
         chk(hipStreamSynchronize(stream));
         cleanup();
         if (e != hipSuccess) return fail(DPQ_ERR_HIP, std::string("overflow rerun: ") + hipGetErrorString(e));
-        if ((int64_t)max_cnt > cap2) return fail(DPQ_ERR_NOMEM, "candidate overflow persisted after reruns");
+        if ((int64_t)max_cnt > rcap2) return fail(DPQ_ERR_NOMEM, "candidate overflow persisted after reruns");
         break;
     }
     if (x->prof) x->prof_acc.overflow_reruns += (int64_t)over.size();
@@ -1084,21 +1137,18 @@ int dpq_debug_scan_time(dpq_index* x, int nq, int pass_all, int reps, int splits
     sa.seg_list = nullptr;
     sa.n_seg_pass = x->img.n_segments;
     if (const char* e = getenv("DPQ_DEBUG_NSEG")) sa.n_seg_pass = std::min(x->img.n_segments, atoi(e));
-    sa.cand_count = x->d_cand_count;
-    sa.cand_id = x->d_cand_id;
-    sa.cand_code = x->d_cand_code;
-    sa.cap = x->ws_cap;
     if (splits <= 0) splits = splits_for(sa.n_seg_pass, nqp / QG);
+    sa.cand_count = x->d_cand_count;
+    sa.cand_key = x->d_cand_key;
+    sa.cand_stride = x->ws_cap;
+    sa.region_off = 0;
+    sa.region_cap = std::max(1, x->ws_cap / splits);
     hipEvent_t a, b;
     DPQ_HIP(hipEventCreate(&a));
     DPQ_HIP(hipEventCreate(&b));
-    DPQ_HIP(hipMemset(x->d_cand_count, 0, sizeof(uint32_t) * nqp));
     DPQ_HIP(dpq::launch_scan(sa, nqp / QG, splits, nullptr));
     DPQ_HIP(hipEventRecord(a, nullptr));
-    for (int r = 0; r < reps; ++r) {
-        DPQ_HIP(hipMemsetAsync(x->d_cand_count, 0, sizeof(uint32_t) * nqp, nullptr));
-        DPQ_HIP(dpq::launch_scan(sa, nqp / QG, splits, nullptr));
-    }
+    for (int r = 0; r < reps; ++r) DPQ_HIP(dpq::launch_scan(sa, nqp / QG, splits, nullptr));
     DPQ_HIP(hipEventRecord(b, nullptr));
     DPQ_HIP(hipEventSynchronize(b));
     float ms = 0;
@@ -1118,11 +1168,11 @@ int dpq_debug_select_time(dpq_index* x, int nq, int top_k, int flags, int reps, 
     se.shared_code = x->d_l0_code;
     se.shared_n = x->l0_segments * dpq::kChunk * x->img.chunks_per_segment;
     se.cand_count = x->d_cand_count;
-    se.cand_id = x->d_cand_id;
-    se.cand_code = x->d_cand_code;
-    se.cap = x->ws_cap;
+    se.cand_key = x->d_cand_key;
+    se.cand_stride = x->ws_cap;
+    se.region_off = top_k;
+    se.scratch = x->d_scratch;
     se.lut32 = x->d_lut32;
-    se.keys = x->d_keys;
     se.top_k = top_k;
     se.final_pass = 0;
     se.thr_key = x->d_thr_key;

@@ -10,9 +10,11 @@ constexpr int kScanThreads = 1024;  // 16 wavefronts, one workgroup per CU (LDS-
 constexpr int kScanWaves = kScanThreads / 64;
 constexpr int kMaxTopK = 2048;
 constexpr int kSelectThreads = 512;
-constexpr int kSortMax = 4096;  // candidates the select kernel sorts in LDS; more -> radix select in HBM scratch
-inline int queries_per_group(int M) { return M <= 8 ? 32 : 16; }  // 128 KB of 16-bit filter tables per workgroup
-constexpr int kStage = 64;      // LDS-staged candidates per query per scan workgroup
+constexpr int kMaxSplits = 256;                  // scan workgroups per query group
+constexpr int kRegionStride = 1 + kMaxSplits;    // candidate-count words per slot
+constexpr int kSortMax = 4096;  // candidate keys the select kernel holds in LDS; more -> radix select on the HBM list
+// queries per scan workgroup = what 128 KB of filter tables hold: 8-bit entries for M = 8, 16-bit for M = 16
+inline int queries_per_group(int M) { return M <= 8 ? 64 : 16; }
 
 // The SoA image of one shard in HBM (see DESIGN.md "Data layout").
 struct DeviceImage {
@@ -41,10 +43,13 @@ struct ScanArgs {
     const int32_t* slot_query;  // slot -> query of the batch, NULL = identity, -1 = unused slot (nothing passes)
     int32_t n_queries;          // slots >= n_queries are padding when slot_query == NULL
     int32_t debug_pass;         // developer experiments: 0 normal, 1 nothing passes, 2 everything passes
-    uint32_t* cand_count;       // [slots]
-    uint32_t* cand_id;          // [slots][cap]
-    uint32_t* cand_code;        // [slots][cap][M/4] dwords
-    int32_t cap;
+    // candidate buffer of a slot: [region 0: winners carried from the previous level, region_off keys]
+    // [region 1 + s: what workgroup (split) s of this launch found, region_cap keys each]
+    uint32_t* cand_count;       // [slots][kRegionStride] keys per region (region 1 + s written here, may exceed region_cap)
+    uint64_t* cand_key;         // [slots][cand_stride] exact keys (distance bits << 32 | DFS position)
+    int64_t cand_stride;
+    int32_t region_off, region_cap;
+    unsigned long long* counters;  // developer statistics (may be NULL): [0] pairs checked exactly, [1] candidates
 };
 
 struct SelectArgs {
@@ -52,13 +57,14 @@ struct SelectArgs {
     const uint32_t* shared_id;     // non-NULL: level 0 (0xffffffff = padding node)
     const uint32_t* shared_code;
     int32_t shared_n;
-    uint32_t* cand_count;          // in: candidates per slot; out (non-final): winners carried to the next level
-    uint32_t* cand_id;
-    uint32_t* cand_code;
-    int32_t cap;
+    uint32_t* cand_count;          // [slots][kRegionStride] in: keys per region; out (non-final): region 0 = carried winners
+    uint64_t* cand_key;            // [slots][cand_stride], regions as in ScanArgs
+    int64_t cand_stride;
+    int32_t region_off, region_cap;
+    int32_t n_regions;             // regions to read: 1 + splits of the level's scan launch (0 with shared_id)
+    uint64_t* scratch;             // [slots][cand_stride] contiguous copy when a slot holds more than kSortMax keys
     const float* lut32;            // exact tables [query][m][256] fp32
     const int32_t* slot_query;     // slot -> query index in the batch (LUT + output row), NULL = identity, -1 = skip
-    uint64_t* keys;                // scratch [slots][cap] for the radix path
     int32_t top_k;
     int32_t final_pass;            // 1: write ids/dists; 0: carry winners to the next level
     uint64_t* thr_key;             // out [slots]: k-th smallest key seen so far (upper bound of the final one)
@@ -85,6 +91,6 @@ hipError_t launch_merge(const int32_t* d_ids, const float* d_dists, int n_lists,
 hipError_t launch_encode_pq(const float* d_vectors, int64_t n, int D, const float* d_codebook, int M, int K, int Ds,
                             uint8_t* d_codes, hipStream_t stream);
 size_t scan_lds_bytes(int M);
-size_t select_lds_bytes(int M, int top_k);
+size_t select_lds_bytes(int M, int top_k, bool level0);
 
 }  // namespace dpq

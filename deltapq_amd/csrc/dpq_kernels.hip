@@ -148,11 +148,23 @@ struct Cfg {
     static constexpr int LEVELS = M <= 8 ? 8 : 16;    // ancestor stack entries (h:2858-2864: M of them)
     static constexpr int JUMPS = M <= 8 ? 3 : 4;      // pointer-jumping rounds: 2^JUMPS > deepest in-chunk chain
     static constexpr int PLANES = M <= 8 ? 4 : 5;     // bits of popcount(mask)
-    static constexpr int QG = M <= 8 ? 32 : 16;       // queries per scan workgroup (128 KB of filter tables)
-    static constexpr int NG = QG / 8;                 // 16-byte table entries hold 8 queries
-    static constexpr int NA = QG / 2;                 // packed accumulators (two queries per dword)
-    static constexpr int SAT = 65535 / M;             // entry saturation: M entries cannot overflow 16 bits
-    static constexpr int QTARGET = M <= 8 ? 7500 : 3700;  // accept bound in filter units (< SAT)
+    // ---- filter tables of the scan ----
+    static constexpr int EB = M <= 8 ? 8 : 16;        // bits per table entry
+    static constexpr int F = 32 / EB;                 // entries (= queries) per dword
+    static constexpr int NG = M <= 8 ? 4 : 2;         // 16-byte entries per (m, code): NG * M * 256 * 16 B = 128 KB
+    static constexpr int NA = NG * 4;                 // accumulator dwords per node
+    static constexpr int QG = NA * F;                 // queries per scan workgroup: 64 (M = 8), 16 (M = 16)
+    static constexpr int J = NA < EB ? NA : EB;       // accumulator dwords folded into one survivor-mask dword
+    static constexpr int MD = (NA + EB - 1) / EB;     // survivor-mask dwords per lane
+    static constexpr int QT = M <= 8 ? 80 : 3700;     // filter units that span (tau - sum of minima)
+    static constexpr int SAT = M <= 8 ? 26 : 2279;    // entry saturation
+    // added to every m = 0 entry: field sum >= 2^(EB-1) (its top bit) <=> sum of entries > QT + 1
+    static constexpr int BIAS = (1 << (EB - 1)) - 1 - (QT + 1);
+    static constexpr int FIELD_MAX = (1 << EB) - 1;
+    static_assert(M * SAT + BIAS <= FIELD_MAX, "a field sum must not carry into its neighbour");
+    static constexpr uint32_t LOW = EB == 8 ? 0x01010101u : 0x00010001u;  // bit 0 of every field
+    // local slot of field f of accumulator dword acc: survivor-mask dword acc / EB, bit EB * f + acc % EB
+    __host__ __device__ static constexpr int slot_of(int acc, int f) { return (acc / EB) * (J * F) + f * J + acc % EB; }
 };
 
 // a7: the reference's decoder[256] (main:312-325) as byte-permute selectors.
@@ -313,58 +325,103 @@ __global__ __launch_bounds__(64) void decode_segments_kernel(const DeviceImage i
 }
 
 // ---------------------------------------------------------------------------
-// scan: decode + ADC filter for QG queries per workgroup
+// scan: decode + ADC filter + exact check for QG queries per workgroup
 // ---------------------------------------------------------------------------
+// exact distance: fp64 sum of the M fp32 entries, rounded to fp32 == the
+// reference's incremental fp64 stack (h:2889-2907), see DESIGN.md section 3
+template <int M>
+__device__ __forceinline__ float exact_dist(const float* __restrict__ T, const uint32_t* __restrict__ c, bool fp32_accum) {
+    if (fp32_accum) {  // plain scan (h:2658-2662): `float dist += lut[m][code]`, m ascending
+        float fsum = 0.0f;
+#pragma unroll
+        for (int m = 0; m < M; ++m) fsum = __fadd_rn(fsum, T[m * 256 + ((c[m >> 2] >> (8 * (m & 3))) & 0xffu)]);
+        return fsum;
+    }
+    double dsum = 0.0;
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+        const uint32_t byte = (c[m >> 2] >> (8 * (m & 3))) & 0xffu;
+        dsum = __dadd_rn(dsum, (double)T[m * 256 + byte]);
+    }
+    return (float)dsum;
+}
+
+// LDS map of the scan workgroup
+template <int M>
+struct ScanLds {
+    static constexpr size_t kTables = (size_t)Cfg<M>::NG * M * 256 * 16;          // filter tables
+    static constexpr size_t kDtab = kTables;                                        // decode table [256] x 16 B
+    static constexpr size_t kThr = kDtab + 4096;                                    // [QG] u64 threshold keys
+    static constexpr size_t kBase = kThr + (size_t)Cfg<M>::QG * 8;                  // [QG] i32 row of the exact tables
+    static constexpr size_t kCount = kBase + (size_t)Cfg<M>::QG * 4;                // [QG] candidates of this workgroup
+    // per-wave queue of (node, query) pairs that passed the filter and await the exact check
+    static constexpr size_t kQCode = kCount + (size_t)Cfg<M>::QG * 4;               // [waves][64][W] dwords
+    static constexpr size_t kQId = kQCode + (size_t)kScanWaves * 64 * M;            // [waves][64] u32
+    static constexpr size_t kQSlot = kQId + (size_t)kScanWaves * 64 * 4;            // [waves][64] u8
+    static constexpr size_t kBytes = kQSlot + (size_t)kScanWaves * 64;
+    static_assert(kBytes <= 160 * 1024, "one workgroup per CU: 160 KB of LDS");
+};
+
 template <int M, bool PLAIN>
 __global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanArgs a) {
-    constexpr int W = Cfg<M>::W;
-    constexpr int QG = Cfg<M>::QG;
-    constexpr int NG = Cfg<M>::NG;
-    constexpr int NA = Cfg<M>::NA;
+    using C = Cfg<M>;
+    constexpr int W = C::W, QG = C::QG, NG = C::NG, NA = C::NA, EB = C::EB, F = C::F, MD = C::MD;
     constexpr int TE = M * 256;  // table entries per query
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint4* lut = reinterpret_cast<uint4*>(smem);                                   // [NG][M][256] x 16 B = 128 KB
-    uint4* dtab = reinterpret_cast<uint4*>(smem + (size_t)NG * TE * 16);           // [256]
-    // candidate staging: survivors are appended with LDS atomics and flushed to
-    // HBM once per workgroup (one global atomic per query), see the epilogue
-    uint32_t* stg_count = reinterpret_cast<uint32_t*>(smem + (size_t)NG * TE * 16 + 4096);  // [QG]
-    uint32_t* stg_id = stg_count + 32;                                                        // [QG][kStage]
-    uint32_t* stg_code = stg_id + QG * kStage;                                                // [QG][kStage][W]
+    uint4* lut = reinterpret_cast<uint4*>(smem);                                        // [NG][M][256] x 16 B = 128 KB
+    uint4* dtab = reinterpret_cast<uint4*>(smem + ScanLds<M>::kDtab);                   // [256]
+    uint64_t* s_thr = reinterpret_cast<uint64_t*>(smem + ScanLds<M>::kThr);             // [QG]
+    int32_t* s_base = reinterpret_cast<int32_t*>(smem + ScanLds<M>::kBase);             // [QG], -1 = unused slot
+    // candidates found by this workgroup per query; their keys go straight to the workgroup's own region
+    // of the query's candidate buffer (plain stores, no global atomics), the counts in the epilogue
+    uint32_t* wg_count = reinterpret_cast<uint32_t*>(smem + ScanLds<M>::kCount);        // [QG]
+    // refine queue of this wavefront: filter survivors wait here until 64 of them can be checked at once
+    uint32_t* rq_code = reinterpret_cast<uint32_t*>(smem + ScanLds<M>::kQCode) + (size_t)(threadIdx.x >> 6) * 64 * C::W;
+    uint32_t* rq_id = reinterpret_cast<uint32_t*>(smem + ScanLds<M>::kQId) + (size_t)(threadIdx.x >> 6) * 64;
+    uint8_t* rq_slot = smem + ScanLds<M>::kQSlot + (size_t)(threadIdx.x >> 6) * 64;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int group = blockIdx.y;
+    // Workgroups are dealt to the 8 XCDs round-robin in launch order.  All workgroups of a query group
+    // read the same exact tables (QG * M KB, prologue and exact checks), so give each XCD whole groups:
+    // its L2 then holds 1/8 of the batch's tables instead of all of them.
+    int group = blockIdx.y, split = blockIdx.x;
+    if ((gridDim.y & 7) == 0) {
+        const int linear = blockIdx.x + gridDim.x * blockIdx.y;
+        const int r = linear >> 3;
+        group = (linear & 7) * (gridDim.y >> 3) + r / gridDim.x;
+        split = r % gridDim.x;
+    }
     const int slot0 = group * QG;
 
     // ---- prologue: quantise the QG queries' exact tables into conservative
-    // lower-bound tables (two per dword), straight into LDS.  For slot q with threshold tau:
-    //   entry[m][k] = floor((T[m][k] - min_m) * s)   rounded DOWN, saturated at SAT = 65535 / M
-    //   node passes iff sum_m entry[m][c_m] <= Q = ceil((tau' - sum_m min_m) * s)
-    //   s = QTARGET / (tau' - sum_m min_m),  tau' = tau * (1 + 2^-20): covers the fp32 rounding of the exact
-    //   distance and, for the plain scan, the M fp32 roundings of its accumulated distance (<= M * 2^-24 relative)
-    // A node with exact distance <= tau has sum entry <= (d - sum min) * s <= Q;
-    // a saturated entry (SAT > Q) can only belong to a node with d > tau; and
-    // M entries <= SAT cannot overflow 16 bits, so packed pairs are summed with
-    // plain 32-bit adds (v_add3_u32) without carries crossing the halves.
-    // Computed as fma(T, s32, -off) in fp32: off >= min * s32 (rounded up), one
-    // rounding of the result, and s32 carries a (1 - 2^-20) factor, so every
-    // entry is <= the exact real value (conservative).
-    float* q_scale = reinterpret_cast<float*>(stg_id);               // [QG]      (staging area is free until the scan loop)
+    // lower-bound tables, F per dword, straight into LDS.  For slot q with threshold tau:
+    //   entry[m][k] = min(floor((T[m][k] - min_m) * s), SAT) (+ BIAS for m = 0),  s = QT / (tau' - sum_m min_m)
+    //   tau' = tau * (1 + 2^-20): covers the fp32 rounding of the exact distance and, for the plain
+    //   scan, the M fp32 roundings of its accumulated distance (<= M * 2^-24 relative)
+    // floor and min only lower an entry, so sum_m entry <= (d - sum min) * s, which is <= QT for a node
+    // with exact distance d <= tau: its field sum stays <= QT + BIAS < 2^(EB-1).  The top bit of a field
+    // is therefore a safe reject flag (no per-query compare in the loop), M * SAT + BIAS <= 2^EB - 1
+    // keeps the fields of a dword from carrying into each other, and what the filter lets through is
+    // checked exactly before it becomes a candidate.
+    // Computed as fma(T, s32, -off) in fp32: off >= min * s32 (rounded up), one rounding of the
+    // result, and s32 carries a (1 - 2^-20) factor, so every entry is <= the exact real value.
+    float* q_scale = reinterpret_cast<float*>(smem + ScanLds<M>::kQCode);  // [QG]  (the refine queues are idle until the scan loop)
     float* q_off = q_scale + QG;                                      // [M][QG]   min_m * scale, rounded UP
-    int32_t* q_base = reinterpret_cast<int32_t*>(q_off + M * QG);     // [QG]      row offset of the query's tables, -1 = unused
-    uint16_t* q_thr = reinterpret_cast<uint16_t*>(q_base + QG);       // [QG]      accept bound + 1
+    uint32_t* q_bias = reinterpret_cast<uint32_t*>(q_off + M * QG);   // [QG]      added to the m = 0 entries
     if (tid < 256) dtab[tid] = make_decode_entry((uint32_t)tid);
     if (tid < QG) {
         const int slot = slot0 + tid;
         int qq = a.slot_query ? a.slot_query[slot] : (slot < a.n_queries ? slot : -1);
-        float s32 = 0.0f;
-        uint32_t qb = 0;  // accept bound + 1; 0 = nothing passes
+        float s32 = 0.0f;   // 0: all entries 0, everything passes the filter
+        uint32_t bias = 0;
+        uint64_t key = ~0ull;
         float mn[M];
 #pragma unroll
         for (int m = 0; m < M; ++m) mn[m] = 0.0f;
         if (qq >= 0 && a.debug_pass != 1) {
-            const uint64_t key = a.thr_key[slot];
+            if (a.debug_pass != 2) key = a.thr_key[slot];
             double B = 0.0;
 #pragma unroll
             for (int m = 0; m < M; ++m) {
@@ -373,18 +430,15 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanArgs a) {
             }
             const double taup = (double)__uint_as_float((uint32_t)(key >> 32)) * (1.0 + 0x1p-20);
             const double R = taup - B;
-            if (key != ~0ull && a.debug_pass != 2 && R > 0.0 && R < 1e300) {
-                const double s = (double)Cfg<M>::QTARGET / R;
-                s32 = (float)(s * (1.0 - 0x1p-20));
-                qb = (uint32_t)ceil(R * s * (1.0 + 0x1p-40)) + 1u;
-            } else {
-                s32 = 0.0f;  // no threshold yet (or degenerate): all entries 0, everything passes
-                qb = 1u;
+            if (key != ~0ull && R > 0.0 && R < 1e300) {  // else: no threshold yet (or degenerate), keep everything
+                s32 = (float)((double)C::QT / R * (1.0 - 0x1p-20));
+                bias = (uint32_t)C::BIAS;
             }
         } else {
             qq = -1;
         }
         q_scale[tid] = s32;
+        q_bias[tid] = bias;
 #pragma unroll
         for (int m = 0; m < M; ++m) {
             // entry = fma(T, s32, -off) with off >= min*s32 (rounded up): never above (T - min) * s32
@@ -393,49 +447,75 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanArgs a) {
             if ((double)of < od) of = __uint_as_float(__float_as_uint(of) + 1u);  // od >= 0: next float up
             q_off[m * QG + tid] = of;
         }
-        q_base[tid] = qq >= 0 ? qq * TE : -1;
-        q_thr[tid] = (uint16_t)qb;
+        s_base[tid] = qq >= 0 ? qq * TE : -1;
+        s_thr[tid] = key;
+        wg_count[tid] = 0;
     }
-    if (tid < 32) stg_count[tid] = 0;
     __syncthreads();
-    // one (g, m, k) tuple = one 16-byte LDS entry = 8 queries; global reads are coalesced over k,
-    // the per-(query, m) constants come from broadcast ds_read_b128
-    for (int e = tid; e < NG * TE; e += kScanThreads) {
-        const int g = e / TE, mk = e % TE, m = mk >> 8;
-        const int4 b0 = *reinterpret_cast<const int4*>(q_base + g * 8), b1 = *reinterpret_cast<const int4*>(q_base + g * 8 + 4);
-        const float4 s0 = *reinterpret_cast<const float4*>(q_scale + g * 8), s1 = *reinterpret_cast<const float4*>(q_scale + g * 8 + 4);
-        const float4 o0 = *reinterpret_cast<const float4*>(q_off + m * QG + g * 8),
-                     o1 = *reinterpret_cast<const float4*>(q_off + m * QG + g * 8 + 4);
-        const int base[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
-        const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
-        const float of[8] = {o0.x, o0.y, o0.z, o0.w, o1.x, o1.y, o1.z, o1.w};
-        float t[8];
+    // one iteration = one dword column (F slots) of 4 consecutive codes of one (g, m): per slot one
+    // 16-byte global read (coalesced over the codes), one dword of each of the four LDS entries written
+    uint32_t* lut_dw = reinterpret_cast<uint32_t*>(lut);
+    for (int it = tid; it < NG * TE; it += kScanThreads) {
+        const int c = it & 3, e4 = it >> 2;
+        const int g = e4 / (TE / 4), mk = (e4 % (TE / 4)) * 4, m = mk >> 8;
+        uint32_t out[4] = {0, 0, 0, 0};
 #pragma unroll
-        for (int j = 0; j < 8; ++j) t[j] = base[j] >= 0 ? a.lut32[(size_t)base[j] + mk] : INFINITY;
-        uint32_t v[8];
+        for (int f = 0; f < F; ++f) {
+            const int ls = C::slot_of(4 * g + c, f);
+            const int base = s_base[ls];
+            const float sc = q_scale[ls], of = q_off[m * QG + ls];
+            const uint32_t bias = m == 0 ? q_bias[ls] : 0u;
+            float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (base >= 0) t = *reinterpret_cast<const float4*>(a.lut32 + (size_t)base + mk);
+            const float tv[4] = {t.x, t.y, t.z, t.w};
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float f = __fmaf_rn(t[j], sc[j], -of[j]);
-            // f < 0 only by the round-up of `of` (true value 0); NaN/inf (unused slot, k >= K) saturate
-            v[j] = f < (float)Cfg<M>::SAT ? (f > 0.0f ? (uint32_t)f : 0u) : (uint32_t)Cfg<M>::SAT;
-            if (base[j] < 0) v[j] = (uint32_t)Cfg<M>::SAT;
+            for (int k = 0; k < 4; ++k) {
+                const float fv = __fmaf_rn(tv[k], sc, -of);
+                // fv < 0 only by the round-up of `of` (true value 0); NaN/inf (k >= K) saturate
+                uint32_t v = fv < (float)C::SAT ? (fv > 0.0f ? (uint32_t)fv : 0u) : (uint32_t)C::SAT;
+                v += bias;
+                if (base < 0) v = m == 0 ? (uint32_t)C::FIELD_MAX : 0u;  // unused slot: top bit always set
+                out[k] |= v << (EB * f);
+            }
         }
-        lut[e] = make_uint4(v[0] | (v[1] << 16), v[2] | (v[3] << 16), v[4] | (v[5] << 16), v[6] | (v[7] << 16));
-    }
-    // accept bounds (+1), two queries per dword, wave-uniform
-    uint32_t qp1[NA];
-    {
-        const uint32_t* qt = reinterpret_cast<const uint32_t*>(q_thr);
 #pragma unroll
-        for (int j = 0; j < NA; ++j) qp1[j] = qt[j];
+        for (int k = 0; k < 4; ++k) lut_dw[((size_t)g * TE + mk + k) * 4 + c] = out[k];
     }
-    __syncthreads();  // tables complete; the staging area (q_* scratch) may be reused from here on
+    __syncthreads();  // tables complete; the queue area (q_* scratch) may be reused from here on
 
     const uint64_t lt_mask = (1ull << lane) - 1ull;
     const int cps = a.img.chunks_per_segment;
     WaveDecoder<M> dec;
+    // bits of a survivor-mask dword that stand for a slot of this configuration
+    uint32_t live = 0;
+#pragma unroll
+    for (int f = 0; f < F; ++f) live |= ((1u << C::J) - 1u) << (EB * f);
 
-    for (int s = blockIdx.x * kScanWaves + wave; s < a.n_seg_pass; s += gridDim.x * kScanWaves) {
+    // exact check of the first n queued pairs (same distance rule and key order as the select kernel);
+    // what passes is a candidate
+    int rq_n = 0;  // wave-uniform
+    const size_t region0 = (size_t)a.region_off + (size_t)split * a.region_cap;  // this workgroup's region in a slot's buffer
+    auto refine = [&](int n) {
+        __builtin_amdgcn_wave_barrier();  // queue entries were written by other lanes of this wavefront
+        if (a.counters && lane == 0) atomicAdd(&a.counters[0], (unsigned long long)n);
+        if (lane < n) {
+            uint32_t c[W];
+#pragma unroll
+            for (int w = 0; w < W; ++w) c[w] = rq_code[lane * W + w];
+            const int ls = rq_slot[lane];
+            const float d = exact_dist<M>(a.lut32 + s_base[ls], c, PLAIN);
+            const uint64_t key = make_key(d, rq_id[lane]);
+            if (key <= s_thr[ls]) {
+                if (a.counters) atomicAdd(&a.counters[1], 1ull);
+                const uint32_t li = atomicAdd(&wg_count[ls], 1u);
+                if (li < (uint32_t)a.region_cap)
+                    a.cand_key[(size_t)(slot0 + ls) * a.cand_stride + region0 + li] = key;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    };
+
+    for (int s = split * kScanWaves + wave; s < a.n_seg_pass; s += gridDim.x * kScanWaves) {
         const uint32_t seg = (uint32_t)__builtin_amdgcn_readfirstlane(a.seg_list ? (int)a.seg_list[s] : s);
         if (!PLAIN) dec.begin_segment(a.img, seg, lane);
         for (int c = 0; c < cps; ++c) {
@@ -449,8 +529,8 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanArgs a) {
                 dec.step(a.img, node, lane, lt_mask, dtab, c + 1 < cps, code);
             }
 
-            // ---- ADC lower bound: M LDS gathers per 8 queries; entries two per dword,
-            // summed with 3-input integer adds (no carry can cross the halves) ----
+            // ---- ADC lower bound: M LDS gathers per 4 * F queries; the fields of a dword are
+            // summed with 3-input integer adds (no carry can cross a field) ----
             uint32_t acc[NA];
 #pragma unroll
             for (int g = 0; g < NG; ++g) {
@@ -474,86 +554,67 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanArgs a) {
                 acc[4 * g + 2] = sz;
                 acc[4 * g + 3] = sw;
             }
-            // ---- filter (replaces the heap test h:2909-2914): keep iff bound <= accept bound ----
+            // ---- filter (replaces the heap test h:2909-2914): the top bit of a field rejects.
+            // Fold the top bits of the NA accumulators into MD mask dwords per lane. ----
+            uint32_t pass[MD];
             const bool valid = node < a.img.n_local;
             uint32_t any = 0;
 #pragma unroll
-            for (int j = 0; j < NA; ++j) any |= pk_sub_sat_u16(qp1[j], acc[j]);  // half != 0 <=> acc <= Q
-            if (!valid) any = 0;
+            for (int h = 0; h < MD; ++h) {
+                uint32_t fail = 0;
+#pragma unroll
+                for (int j = 0; j < C::J; ++j) fail |= (acc[EB * h + j] >> (EB - 1 - j)) & (C::LOW << j);
+                pass[h] = valid ? (~fail & live) : 0u;
+                any |= pass[h];
+            }
             if (__any(any != 0)) {
+                // ---- queue what the filter let through: one (node, query) pair per lane and round;
+                // a full queue is checked exactly by all 64 lanes at once ----
                 const uint32_t id = a.img.id_base + (uint32_t)node;
+                for (;;) {
+                    int ls = -1, hsel = 0;
+                    uint32_t bit = 0;
 #pragma unroll
-                for (int j = 0; j < NA; ++j) {
-                    const uint32_t t = valid ? pk_sub_sat_u16(qp1[j], acc[j]) : 0u;
-                    if (__any(t != 0)) {
-#pragma unroll
-                        for (int h = 0; h < 2; ++h) {
-                            if ((t >> (16 * h)) & 0xffffu) {
-                                const int q = 2 * j + h;
-                                const uint32_t li = atomicAdd(&stg_count[q], 1u);
-                                if (li < (uint32_t)kStage) {
-                                    stg_id[q * kStage + li] = id;
-#pragma unroll
-                                    for (int w = 0; w < W; ++w) stg_code[W * (q * kStage + li) + w] = code[w];
-                                } else {  // staging full: straight to HBM
-                                    const uint32_t idx = atomicAdd(&a.cand_count[slot0 + q], 1u);
-                                    if (idx < (uint32_t)a.cap) {
-                                        const size_t o = (size_t)(slot0 + q) * a.cap + idx;
-                                        a.cand_id[o] = id;
-#pragma unroll
-                                        for (int w = 0; w < W; ++w) a.cand_code[W * o + w] = code[w];
-                                    }
-                                }
-                            }
+                    for (int h = 0; h < MD; ++h) {
+                        if (ls < 0 && pass[h] != 0) {
+                            const int p = __ffs((int)pass[h]) - 1;
+                            bit = 1u << p;
+                            hsel = h;
+                            ls = h * (C::J * F) + (p / EB) * C::J + (p % EB);
                         }
+                    }
+                    const uint64_t pushing = __ballot(ls >= 0);
+                    if (pushing == 0) break;
+                    const int pos = rq_n + (int)mbcnt64(pushing, 0);
+                    if (ls >= 0 && pos < 64) {
+#pragma unroll
+                        for (int h = 0; h < MD; ++h)
+                            if (h == hsel) pass[h] &= ~bit;
+#pragma unroll
+                        for (int w = 0; w < W; ++w) rq_code[pos * W + w] = code[w];
+                        rq_id[pos] = id;
+                        rq_slot[pos] = (uint8_t)ls;
+                    }
+                    rq_n = min(64, rq_n + (int)__popcll(pushing));
+                    if (rq_n == 64) {
+                        refine(64);
+                        rq_n = 0;
                     }
                 }
             }
         }
     }
+    if (rq_n > 0) refine(rq_n);
 
-    // ---- epilogue: flush the staged candidates, wave w serves queries w, w+16 ----
+    // ---- epilogue: this workgroup's candidate counts (a count above region_cap tells the select
+    // kernel that candidates were dropped) ----
     __syncthreads();
-    for (int q = wave; q < QG; q += kScanWaves) {
-        const uint32_t n = min(stg_count[q], (uint32_t)kStage);
-        if (n == 0) continue;
-        uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(&a.cand_count[slot0 + q], n);
-        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-        for (uint32_t i = lane; i < n; i += 64) {
-            const uint32_t idx = base + i;
-            if (idx < (uint32_t)a.cap) {
-                const size_t o = (size_t)(slot0 + q) * a.cap + idx;
-                a.cand_id[o] = stg_id[q * kStage + i];
-#pragma unroll
-                for (int w = 0; w < W; ++w) a.cand_code[W * o + w] = stg_code[W * (q * kStage + i) + w];
-            }
-        }
-    }
+    if (tid < QG) a.cand_count[(size_t)(slot0 + tid) * kRegionStride + 1 + split] = wg_count[tid];
 }
 
 // ---------------------------------------------------------------------------
 // a6: select.  grid = slots, block = kSelectThreads, dynamic LDS
 // ---------------------------------------------------------------------------
-
-// exact distance: fp64 sum of the M fp32 entries, rounded to fp32 == the
-// reference's incremental fp64 stack (h:2889-2907), see DESIGN.md section 3
-template <int M>
-__device__ __forceinline__ float exact_dist(const float* __restrict__ T, const uint32_t* __restrict__ c, bool fp32_accum) {
-    if (fp32_accum) {  // plain scan (h:2658-2662): `float dist += lut[m][code]`, m ascending
-        float fsum = 0.0f;
-#pragma unroll
-        for (int m = 0; m < M; ++m) fsum = __fadd_rn(fsum, T[m * 256 + ((c[m >> 2] >> (8 * (m & 3))) & 0xffu)]);
-        return fsum;
-    }
-    double dsum = 0.0;
-#pragma unroll
-    for (int m = 0; m < M; ++m) {
-        const uint32_t byte = (c[m >> 2] >> (8 * (m & 3))) & 0xffu;
-        dsum = __dadd_rn(dsum, (double)T[m * 256 + byte]);
-    }
-    return (float)dsum;
-}
 
 __device__ __forceinline__ void block_bitonic_sort(uint64_t* v, int n_pow2, int tid, int nthreads) {
     for (int k = 2; k <= n_pow2; k <<= 1) {
@@ -665,55 +726,87 @@ __global__ __launch_bounds__(kSelectThreads) void select_kernel(const SelectArgs
     constexpr int W = Cfg<M>::W;
     constexpr int TE = M * 256;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    // winner arrays are sized by top_k (rounded up to a power of two for the final sort), not by the
-    // 2048 maximum: at top_k = 100 a block needs 35 KB instead of 66 KB and four blocks share a CU
+    // the winner array is sized by top_k (rounded up to a power of two for the final sort), not by the
+    // 2048 maximum: at top_k = 100 a block needs 35 KB and four blocks share a CU
     int KP = 1;
     while (KP < a.top_k) KP <<= 1;
     uint64_t* skeys = reinterpret_cast<uint64_t*>(smem);                              // [kSortMax] candidate keys
     uint64_t* wkeys = skeys + kSortMax;                                               // [KP] winner keys
-    uint32_t* win_id = reinterpret_cast<uint32_t*>(wkeys + KP);                       // [KP]
-    uint32_t* win_code = win_id + KP;                                                 // [KP][W]
-    uint32_t* hist = win_code + W * KP;                                               // [256]
-    uint32_t* bcast = hist + 256;                                                     // [2]
+    uint32_t* hist = reinterpret_cast<uint32_t*>(wkeys + KP);                         // [kRegionStride + 1 <= 264]
+    uint32_t* bcast = hist + 264;                                                     // [2]
     uint32_t* counters = bcast + 2;                                                   // [2]: winners, padding nodes
-    float* T = reinterpret_cast<float*>(counters + 2);                                // [M][256] this query's exact tables
+    float* T = reinterpret_cast<float*>(counters + 2);                                // [M][256], level 0 only
 
     const int slot = blockIdx.x;
     const int tid = threadIdx.x;
     const int q = a.slot_query ? a.slot_query[slot] : slot;
     if (q < 0) return;  // unused slot of a rerun group
-    {   // stage the query's exact tables in LDS: every candidate gathers M entries, and scattered gathers
-        // from global memory are bound by the vector-memory address rate (~4 lanes per clock per CU)
-        const float4* src = reinterpret_cast<const float4*>(a.lut32 + (size_t)q * TE);
-        for (int i = tid; i < TE / 4; i += kSelectThreads) reinterpret_cast<float4*>(T)[i] = src[i];
-    }
     const bool shared = a.shared_id != nullptr;
-    const uint32_t cnt = shared ? (uint32_t)a.shared_n : a.cand_count[slot];
-    const int n = shared ? a.shared_n : (int)min(cnt, (uint32_t)a.cap);
-    const uint32_t* src_id = shared ? a.shared_id : a.cand_id + (size_t)slot * a.cap;
-    const uint32_t* src_code = shared ? a.shared_code : a.cand_code + (size_t)slot * a.cap * W;
-    // keys live in LDS for the usual list sizes, in HBM scratch for huge ones (overflow reruns)
-    uint64_t* keys = n <= kSortMax ? skeys : a.keys + (size_t)slot * a.cap;
+    uint64_t* cand = a.cand_key + (size_t)slot * a.cand_stride;
+    uint32_t* region_n = a.cand_count + (size_t)slot * kRegionStride;
+    uint64_t* keys = skeys;
+    int n = 0;
     if (tid == 0) {
         counters[0] = 0;
         counters[1] = 0;
-        // candidates were dropped at this level: the final list may miss entries -> host reruns this query
-        if (!shared && cnt > (uint32_t)a.cap) {
-            a.overflow[slot] = 1u;
-            if (a.any_overflow) *reinterpret_cast<volatile uint32_t*>(a.any_overflow) = 1u;  // host-visible summary
-        }
     }
-    __syncthreads();
-
-    // exact keys of every candidate
-    for (int i = tid; i < n; i += kSelectThreads) {
-        const uint32_t id = src_id[i];
-        uint64_t key = ~0ull;
-        if (id != 0xffffffffu)
-            key = make_key(exact_dist<M>(T, src_code + (size_t)W * i, a.fp32_accum != 0), id);
-        else
-            atomicAdd(&counters[1], 1u);  // padding node of the shared level-0 list
-        keys[i] = key;
+    if (shared) {
+        // level 0: the query-independent list of decoded nodes, evaluated exactly here.  The query's
+        // exact tables are staged in LDS first: every node gathers M entries, and scattered gathers
+        // from global memory are bound by the vector-memory address rate.
+        n = a.shared_n;
+        if (n > kSortMax) keys = a.scratch + (size_t)slot * a.cand_stride;
+        const float4* src = reinterpret_cast<const float4*>(a.lut32 + (size_t)q * TE);
+        for (int i = tid; i < TE / 4; i += kSelectThreads) reinterpret_cast<float4*>(T)[i] = src[i];
+        __syncthreads();
+        for (int i = tid; i < n; i += kSelectThreads) {
+            const uint32_t id = a.shared_id[i];
+            uint64_t key = ~0ull;
+            if (id != 0xffffffffu)
+                key = make_key(exact_dist<M>(T, a.shared_code + (size_t)W * i, a.fp32_accum != 0), id);
+            else
+                atomicAdd(&counters[1], 1u);  // padding node
+            keys[i] = key;
+        }
+    } else {
+        // later levels: the scan already evaluated its survivors exactly.  Gather the regions of the
+        // slot's buffer (carried winners + one per scan workgroup) into one list.
+        uint32_t* rstart = hist;  // [n_regions + 1] exclusive prefix of the region sizes (hist is free until the select)
+        const int R = a.n_regions;
+        if (tid < 64) {  // wave 0: R <= 257
+            uint32_t carry = 0;
+            bool dropped = false;
+            for (int r0 = 0; r0 < R; r0 += 64) {
+                const int r = r0 + tid;
+                const uint32_t capr = r == 0 ? (uint32_t)a.region_off : (uint32_t)a.region_cap;
+                const uint32_t raw = r < R ? region_n[r] : 0u;
+                dropped |= raw > capr;
+                const uint32_t mine = min(raw, capr);
+                uint32_t incl = mine;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const uint32_t up = (uint32_t)__shfl_up((int)incl, off, 64);
+                    if (tid >= off) incl += up;
+                }
+                if (r < R) rstart[r] = carry + incl - mine;
+                carry += (uint32_t)__shfl((int)incl, 63, 64);
+            }
+            if (tid == 0) rstart[R] = carry;
+            // candidates were dropped at this level: the final list may miss entries -> host reruns this query
+            if (__any(dropped) && tid == 0) {
+                a.overflow[slot] = 1u;
+                if (a.any_overflow) *reinterpret_cast<volatile uint32_t*>(a.any_overflow) = 1u;  // host-visible summary
+            }
+        }
+        __syncthreads();
+        n = (int)rstart[R];
+        // keys live in LDS for the usual list sizes, in HBM scratch for huge ones (overflow reruns)
+        if (n > kSortMax) keys = a.scratch + (size_t)slot * a.cand_stride;
+        for (int r = tid >> 6; r < R; r += kSelectThreads / 64) {  // one wavefront per region
+            const uint32_t lo = rstart[r], cnt = rstart[r + 1] - lo;
+            const uint64_t* src = cand + (r == 0 ? (size_t)0 : (size_t)a.region_off + (size_t)(r - 1) * a.region_cap);
+            for (uint32_t li = tid & 63; li < cnt; li += 64) keys[lo + li] = src[li];
+        }
     }
     __syncthreads();
     const int n_valid = n - (int)counters[1];
@@ -735,25 +828,15 @@ __global__ __launch_bounds__(kSelectThreads) void select_kernel(const SelectArgs
         const uint64_t key = keys[i];
         if (kk > 0 && key <= kth) {
             const uint32_t pos = atomicAdd(&counters[0], 1u);
-            if (pos < (uint32_t)KP) {
-                wkeys[pos] = key;
-                win_id[pos] = src_id[i];
-#pragma unroll
-                for (int w = 0; w < W; ++w) win_code[W * pos + w] = src_code[(size_t)W * i + w];
-            }
+            if (pos < (uint32_t)KP) wkeys[pos] = key;
         }
     }
     __syncthreads();
 
     if (!a.final_pass) {
         // carry the winners: compact them to the front; the next level appends behind
-        for (int i = tid; i < kk; i += kSelectThreads) {
-            const size_t o = (size_t)slot * a.cap + i;
-            a.cand_id[o] = win_id[i];
-#pragma unroll
-            for (int w = 0; w < W; ++w) a.cand_code[W * o + w] = win_code[W * i + w];
-        }
-        if (tid == 0) a.cand_count[slot] = (uint32_t)kk;
+        for (int i = tid; i < kk; i += kSelectThreads) cand[i] = wkeys[i];
+        if (tid == 0) region_n[0] = (uint32_t)kk;
         return;
     }
 
@@ -873,16 +956,13 @@ hipError_t launch_encode_pq(const float* d_vectors, int64_t n, int D, const floa
     return hipGetLastError();
 }
 
-size_t scan_lds_bytes(int M) {
-    const size_t QG = M <= 8 ? 32 : 16, W = (size_t)M / 4;
-    return (QG / 8) * (size_t)M * 256 * 16 + 256 * sizeof(uint4) + 32 * sizeof(uint32_t) +
-           QG * kStage * (1 + W) * sizeof(uint32_t);
-}
+size_t scan_lds_bytes(int M) { return M <= 8 ? ScanLds<8>::kBytes : ScanLds<16>::kBytes; }
 
-size_t select_lds_bytes(int M, int top_k) {
+// `level0`: the block also stages the query's exact tables (M KB)
+size_t select_lds_bytes(int M, int top_k, bool level0) {
     size_t kp = 1;
     while (kp < (size_t)top_k) kp <<= 1;
-    return (size_t)kSortMax * 8 + kp * 8 + kp * (1 + M / 4) * 4 + (256 + 2 + 2) * 4 + (size_t)M * 256 * 4;
+    return (size_t)kSortMax * 8 + kp * 8 + (264 + 2 + 2) * 4 + (level0 ? (size_t)M * 256 * 4 : 0);
 }
 
 // hipFuncSetAttribute is per device; handles may live on several GPUs
@@ -947,10 +1027,10 @@ template <int M>
 static hipError_t launch_select_m(const SelectArgs& a, int n_slots, hipStream_t stream) {
     static bool done[64] = {};
     hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&select_kernel<M>),
-                                      select_lds_bytes(M, kMaxTopK), done);
+                                      select_lds_bytes(M, kMaxTopK, true), done);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(select_kernel<M>, dim3((unsigned)n_slots), dim3(kSelectThreads),
-                       select_lds_bytes(M, a.top_k), stream, a);
+                       select_lds_bytes(M, a.top_k, a.shared_id != nullptr), stream, a);
     return hipGetLastError();
 }
 

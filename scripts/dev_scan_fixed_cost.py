@@ -12,11 +12,12 @@ lib = _lib.load()
 lib.dpq_debug_scan_time.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_float)]
 with api.DeltaPQIndex.open_memory(payload, n, 8, 256) as idx:
     idx.set_codebook(cb)
-    idx.query_batch(qs, 100)
-    for nseg in (0, 16, 106, 856, 2930, 3907):
-        os.environ["DPQ_DEBUG_NSEG"] = str(nseg)
-        for mode in (0, 2):
-            ms = ctypes.c_float()
-            rc = lib.dpq_debug_scan_time(idx._h, nq, mode, 20, 0, ms)
-            assert rc == 0, lib.dpq_last_error()
-            print("nseg=%d mode=%d: %.1f us" % (nseg, mode, ms.value * 1e3), flush=True)
+    for topk in (100, 400, 1600):
+        idx.query_batch(qs, topk)   # leaves the final thresholds of a top-`topk` search behind
+        for nseg in (16, 106, 856, 3907):
+            os.environ["DPQ_DEBUG_NSEG"] = str(nseg)
+            for mode in (0, 2):
+                ms = ctypes.c_float()
+                rc = lib.dpq_debug_scan_time(idx._h, nq, mode, 20, 0, ms)
+                assert rc == 0, lib.dpq_last_error()
+                print("thresholds of top-%d, nseg=%d mode=%d: %.1f us" % (topk, nseg, mode, ms.value * 1e3), flush=True)

@@ -357,9 +357,10 @@ def test_m16_sift1m_shape_top1000(gpu, oracle):
 
 def test_tie_explosion_thousands_of_duplicates_of_the_nearest_code(gpu, oracle, codebook):
     """Pathological ties: 9000 exact copies of the code nearest to the query.  The
-    filter cannot separate equal distances, so every copy is a candidate and the
-    per-query buffer (4096) overflows; the rerun loop must grow it and still return
-    the canonical answer (lowest ids of the tie group)."""
+    lower-bound filter cannot separate equal distances, so every copy reaches the
+    scan's exact check; that check compares whole (distance, id) keys, so only
+    copies below the threshold id become candidates and the canonical answer
+    (lowest ids of the tie group) comes out without a rerun."""
     from deltapq_amd import api, synth
     rng = np.random.default_rng(5)
     n = 40000
@@ -372,7 +373,7 @@ def test_tie_explosion_thousands_of_duplicates_of_the_nearest_code(gpu, oracle, 
     tree = api.DeltaTree(codes)
     payload = tree.payload()
     ids, dists, prof, _ = run(gpu, payload, n, codebook, q, 100)
-    assert prof["overflow_reruns"] >= 1
+    assert prof["overflow_reruns"] == 0
     assert_parity(ids, dists, oracle_topk(oracle, payload, n, codebook, q, 100), n)
     # query 0: all 100 results are copies of `best`, and they are the 100 lowest DFS positions holding it
     pos_of_best = np.flatnonzero((codes[tree.vec_id] == best).all(1))
