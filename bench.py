@@ -209,6 +209,8 @@ def main():
     sync()
     prof_aux = idx.profile_read()
     idx.profile_enable(0)
+    prof["exact_checks_per_query"] = prof_aux["exact_checks"] / max(1, aux_steps * args.queries)
+    prof["candidates_per_query"] = prof_aux["candidates"] / max(1, aux_steps * args.queries)
     prof["select_ms"] = prof_aux["select_ms"] * args.steps / aux_steps
     prof["lut_ms"] = prof_aux["lut_ms"] * args.steps / aux_steps
 
@@ -274,10 +276,12 @@ def main():
                 "scan_ms_per_step": scan_ms_step,
                 "select_ms_per_step": float(all_stats[:, 4].max()) / steps,
                 "lut_ms_per_step": float(all_stats[:, 5].max()) / steps,
+                "filter_survivors_per_query": prof["exact_checks_per_query"],
+                "candidates_per_query": prof["candidates_per_query"],
                 "event_note": "timed region: HIP events around the scan launches only; select/lut figures from %d "
                               "untimed steps run afterwards with events around every kernel" % aux_steps,
                 "note": "achieved = queries x DTC payload bytes / scan-kernel time (HIP events on the launch "
-                        "stream, all cascade levels of a step summed); each decoded chunk serves 32 queries, so "
+                        "stream, all cascade levels of a step summed); each decoded chunk serves 64 queries (16 at m=16), so "
                         "physical traffic is a small fraction of this figure and frac can exceed 1 (see DESIGN.md)",
             },
             "parity_checked_queries": min(args.check, nq) if parity else 0,

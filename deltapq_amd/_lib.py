@@ -32,7 +32,7 @@ class Profile(ctypes.Structure):
     _fields_ = [("lut_ms", ctypes.c_double), ("scan_ms", ctypes.c_double), ("select_ms", ctypes.c_double),
                 ("lut_launches", c_i64), ("scan_launches", c_i64), ("select_launches", c_i64),
                 ("scan_node_query_pairs", c_i64), ("scan_stream_bytes", c_i64), ("query_batches", c_i64),
-                ("queries", c_i64), ("overflow_reruns", c_i64)]
+                ("queries", c_i64), ("overflow_reruns", c_i64), ("exact_checks", c_i64), ("candidates", c_i64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

@@ -81,6 +81,7 @@ struct dpq_index {
     float* d_lut_min = nullptr;     // [query][8] minima (filter quantisation in the scan prologue)
     uint32_t *d_cand_count = nullptr, *d_overflow = nullptr;
     uint64_t *d_cand_key = nullptr, *d_thr_key = nullptr;  // candidate keys [slots][ws_cap], threshold keys [slots]
+    unsigned long long* d_counters = nullptr;  // [2] scan statistics (dpq_profile.exact_checks / candidates)
     uint64_t* d_scratch = nullptr;   // [slots][ws_cap] contiguous copy of a slot's keys when they exceed the select's LDS list
     uint32_t* h_overflow = nullptr;  // pinned
     uint32_t* h_any = nullptr;       // pinned + mapped: set by select_kernel when any query overflowed
@@ -146,6 +147,10 @@ int ensure_workspace(dpq_index* x, int slots, int cap) {
     if ((rc = dev_alloc(&x->d_overflow, (size_t)slots))) return rc;
     if ((rc = dev_alloc(&x->d_thr_key, (size_t)slots))) return rc;
     if (!x->h_overflow) DPQ_HIP(hipHostMalloc(reinterpret_cast<void**>(&x->h_overflow), sizeof(uint32_t) * 4096));
+    if (!x->d_counters) {
+        if ((rc = dev_alloc(&x->d_counters, 2))) return rc;
+        DPQ_HIP(hipMemset(x->d_counters, 0, 16));
+    }
     if (!x->h_any) {
         DPQ_HIP(hipHostMalloc(reinterpret_cast<void**>(&x->h_any), sizeof(uint32_t), hipHostMallocMapped));
         DPQ_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&x->d_any), x->h_any, 0));
@@ -253,12 +258,11 @@ struct Timer {
 };
 
 int splits_for(int n_seg_pass, int n_groups) {
-    // One workgroup per CU is resident (LDS) and each pays a table-building
-    // prologue, so aim at ONE chip-wave: <= 256 workgroups, and no more waves
-    // than segments.
-    const int by_work = (n_seg_pass + dpq::kScanWaves - 1) / dpq::kScanWaves;
-    const int want = std::max(1, 256 / std::max(1, n_groups));
-    return std::max(1, std::min(by_work, want));
+    // One workgroup per CU is resident (LDS), so aim at ONE chip-wave: <= 256 workgroups.  Small levels
+    // still spread over as many CUs as they have segments: the exact checks of the filter survivors
+    // are bound by each CU's vector-memory address rate, not by its wavefront count.
+    const int want = std::max(1, dpq::kMaxSplits / std::max(1, n_groups));
+    return std::max(1, std::min(n_seg_pass, want));
 }
 
 // Candidate-buffer geometry of one scan launch: region 0 (top_k keys) carries the winners of the
@@ -318,6 +322,7 @@ int run_batch(dpq_index* x, const float* d_queries, int nq, int top_k, int32_t* 
     sa.cand_key = x->d_cand_key;
     sa.cand_stride = stride;
     sa.region_off = top_k;
+    sa.counters = x->prof && !x->prof_scan_only ? x->d_counters : nullptr;
 
     dpq::SelectArgs se{};
     se.cand_count = x->d_cand_count;
@@ -357,28 +362,12 @@ int run_batch(dpq_index* x, const float* d_queries, int nq, int top_k, int32_t* 
             // filter scan of the next slice of segments; appends behind the carried winners
             sa.seg_list = x->d_order + x->level_off[l];
             sa.n_seg_pass = x->level_cnt[l];
-            static const bool dbg_counts = getenv("DPQ_DEBUG_COUNTS") != nullptr;
-            unsigned long long* d_cnt = nullptr;
-            if (dbg_counts) {
-                hipMalloc(reinterpret_cast<void**>(&d_cnt), 16);
-                hipMemsetAsync(d_cnt, 0, 16, stream);
-                sa.counters = d_cnt;
-            }
             const Regions rg = regions_for(x, sa.n_seg_pass, ngroups, top_k, cap);
             sa.region_cap = se.region_cap = rg.region_cap;
             se.n_regions = 1 + rg.splits;
             {
                 Timer t(x, stream, 1);
                 DPQ_HIP(dpq::launch_scan(sa, ngroups, rg.splits, stream));
-            }
-            if (dbg_counts) {
-                unsigned long long h[2];
-                hipMemcpyAsync(h, d_cnt, 16, hipMemcpyDeviceToHost, stream);
-                hipStreamSynchronize(stream);
-                hipFree(d_cnt);
-                sa.counters = nullptr;
-                fprintf(stderr, "level %zu: %d segments, %llu pairs checked exactly (%.0f/query), %llu candidates (%.0f/query)\n", l,
-                        sa.n_seg_pass, h[0], (double)h[0] / nq, h[1], (double)h[1] / nq);
             }
             if (x->prof) {
                 x->prof_acc.scan_launches++;
@@ -409,13 +398,6 @@ int run_batch(dpq_index* x, const float* d_queries, int nq, int top_k, int32_t* 
             if (x->h_overflow[i]) over.push_back(base + i);
     }
     if (over.empty()) return DPQ_OK;
-    if (getenv("DPQ_DEBUG_COUNTS")) {
-        std::vector<uint32_t> hc((size_t)nqp * dpq::kRegionStride);
-        hipMemcpy(hc.data(), x->d_cand_count, hc.size() * 4, hipMemcpyDeviceToHost);
-        fprintf(stderr, "%zu queries overflowed; last level region counts of query %d:", over.size(), over[0]);
-        for (int r = 0; r < 18; ++r) fprintf(stderr, " %u", hc[(size_t)over[0] * dpq::kRegionStride + r]);
-        fprintf(stderr, "\n");
-    }
 
     // Rerun the affected queries over the whole shard in ONE filter level.  The
     // k-th key of the incomplete list is still a valid upper bound (its entries
@@ -1012,6 +994,7 @@ int dpq_close(dpq_index* x) {
     hipFree(x->d_dists_stage);
     if (x->h_overflow) hipHostFree(x->h_overflow);
     if (x->h_any) hipHostFree(x->h_any);
+    hipFree(x->d_counters);
     delete x;
     return DPQ_OK;
 }
@@ -1211,6 +1194,7 @@ int dpq_profile_reset(dpq_index* x) {
     }
     x->events.clear();
     memset(&x->prof_acc, 0, sizeof x->prof_acc);
+    if (x->d_counters) hipMemset(x->d_counters, 0, 16);
     return DPQ_OK;
 }
 
@@ -1228,6 +1212,12 @@ int dpq_profile_read(dpq_index* x, dpq_profile* out) {
         x->ev_pool.push_back(ep.b);
     }
     x->events.clear();
+    if (x->d_counters) {
+        unsigned long long h[2] = {0, 0};
+        DPQ_HIP(hipMemcpy(h, x->d_counters, 16, hipMemcpyDeviceToHost));
+        x->prof_acc.exact_checks = (int64_t)h[0];
+        x->prof_acc.candidates = (int64_t)h[1];
+    }
     *out = x->prof_acc;
     return DPQ_OK;
 }

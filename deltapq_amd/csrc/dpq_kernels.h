@@ -49,7 +49,7 @@ struct ScanArgs {
     uint64_t* cand_key;         // [slots][cand_stride] exact keys (distance bits << 32 | DFS position)
     int64_t cand_stride;
     int32_t region_off, region_cap;
-    unsigned long long* counters;  // developer statistics (may be NULL): [0] pairs checked exactly, [1] candidates
+    unsigned long long* counters;  // statistics (may be NULL): [0] += pairs checked exactly, [1] += candidates
 };
 
 struct SelectArgs {

@@ -163,6 +163,7 @@ struct Cfg {
     static constexpr int FIELD_MAX = (1 << EB) - 1;
     static_assert(M * SAT + BIAS <= FIELD_MAX, "a field sum must not carry into its neighbour");
     static constexpr uint32_t LOW = EB == 8 ? 0x01010101u : 0x00010001u;  // bit 0 of every field
+    static constexpr int RQ = M <= 8 ? 128 : 64;      // (node, query) pairs a wavefront queues before their exact check
     // local slot of field f of accumulator dword acc: survivor-mask dword acc / EB, bit EB * f + acc % EB
     __host__ __device__ static constexpr int slot_of(int acc, int f) { return (acc / EB) * (J * F) + f * J + acc % EB; }
 };
@@ -355,10 +356,10 @@ struct ScanLds {
     static constexpr size_t kBase = kThr + (size_t)Cfg<M>::QG * 8;                  // [QG] i32 row of the exact tables
     static constexpr size_t kCount = kBase + (size_t)Cfg<M>::QG * 4;                // [QG] candidates of this workgroup
     // per-wave queue of (node, query) pairs that passed the filter and await the exact check
-    static constexpr size_t kQCode = kCount + (size_t)Cfg<M>::QG * 4;               // [waves][64][W] dwords
-    static constexpr size_t kQId = kQCode + (size_t)kScanWaves * 64 * M;            // [waves][64] u32
-    static constexpr size_t kQSlot = kQId + (size_t)kScanWaves * 64 * 4;            // [waves][64] u8
-    static constexpr size_t kBytes = kQSlot + (size_t)kScanWaves * 64;
+    static constexpr size_t kQCode = kCount + (size_t)Cfg<M>::QG * 4;               // [waves][RQ][W] dwords
+    static constexpr size_t kQId = kQCode + (size_t)kScanWaves * Cfg<M>::RQ * M;    // [waves][RQ] u32
+    static constexpr size_t kQSlot = kQId + (size_t)kScanWaves * Cfg<M>::RQ * 4;    // [waves][RQ] u8
+    static constexpr size_t kBytes = kQSlot + (size_t)kScanWaves * Cfg<M>::RQ;
     static_assert(kBytes <= 160 * 1024, "one workgroup per CU: 160 KB of LDS");
 };
 
@@ -376,9 +377,9 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanArgs a) {
     // of the query's candidate buffer (plain stores, no global atomics), the counts in the epilogue
     uint32_t* wg_count = reinterpret_cast<uint32_t*>(smem + ScanLds<M>::kCount);        // [QG]
     // refine queue of this wavefront: filter survivors wait here until 64 of them can be checked at once
-    uint32_t* rq_code = reinterpret_cast<uint32_t*>(smem + ScanLds<M>::kQCode) + (size_t)(threadIdx.x >> 6) * 64 * C::W;
-    uint32_t* rq_id = reinterpret_cast<uint32_t*>(smem + ScanLds<M>::kQId) + (size_t)(threadIdx.x >> 6) * 64;
-    uint8_t* rq_slot = smem + ScanLds<M>::kQSlot + (size_t)(threadIdx.x >> 6) * 64;
+    uint32_t* rq_code = reinterpret_cast<uint32_t*>(smem + ScanLds<M>::kQCode) + (size_t)(threadIdx.x >> 6) * C::RQ * C::W;
+    uint32_t* rq_id = reinterpret_cast<uint32_t*>(smem + ScanLds<M>::kQId) + (size_t)(threadIdx.x >> 6) * C::RQ;
+    uint8_t* rq_slot = smem + ScanLds<M>::kQSlot + (size_t)(threadIdx.x >> 6) * C::RQ;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -498,18 +499,29 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanArgs a) {
     auto refine = [&](int n) {
         __builtin_amdgcn_wave_barrier();  // queue entries were written by other lanes of this wavefront
         if (a.counters && lane == 0) atomicAdd(&a.counters[0], (unsigned long long)n);
-        if (lane < n) {
-            uint32_t c[W];
+        constexpr int E = C::RQ / 64;  // entries per lane: their table gathers are in flight together
+        uint32_t c[E][W];
+        int ls[E];
+        uint32_t eid[E];
+        float d[E];
 #pragma unroll
-            for (int w = 0; w < W; ++w) c[w] = rq_code[lane * W + w];
-            const int ls = rq_slot[lane];
-            const float d = exact_dist<M>(a.lut32 + s_base[ls], c, PLAIN);
-            const uint64_t key = make_key(d, rq_id[lane]);
-            if (key <= s_thr[ls]) {
+        for (int e = 0; e < E; ++e) {
+            const int i = min(lane + 64 * e, n - 1);
+#pragma unroll
+            for (int w = 0; w < W; ++w) c[e][w] = rq_code[i * W + w];
+            ls[e] = rq_slot[i];
+            eid[e] = rq_id[i];
+        }
+#pragma unroll
+        for (int e = 0; e < E; ++e) d[e] = exact_dist<M>(a.lut32 + s_base[ls[e]], c[e], PLAIN);
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const uint64_t key = make_key(d[e], eid[e]);
+            if (lane + 64 * e < n && key <= s_thr[ls[e]]) {
                 if (a.counters) atomicAdd(&a.counters[1], 1ull);
-                const uint32_t li = atomicAdd(&wg_count[ls], 1u);
+                const uint32_t li = atomicAdd(&wg_count[ls[e]], 1u);
                 if (li < (uint32_t)a.region_cap)
-                    a.cand_key[(size_t)(slot0 + ls) * a.cand_stride + region0 + li] = key;
+                    a.cand_key[(size_t)(slot0 + ls[e]) * a.cand_stride + region0 + li] = key;
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -586,7 +598,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanArgs a) {
                     const uint64_t pushing = __ballot(ls >= 0);
                     if (pushing == 0) break;
                     const int pos = rq_n + (int)mbcnt64(pushing, 0);
-                    if (ls >= 0 && pos < 64) {
+                    if (ls >= 0 && pos < C::RQ) {
 #pragma unroll
                         for (int h = 0; h < MD; ++h)
                             if (h == hsel) pass[h] &= ~bit;
@@ -595,9 +607,9 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanArgs a) {
                         rq_id[pos] = id;
                         rq_slot[pos] = (uint8_t)ls;
                     }
-                    rq_n = min(64, rq_n + (int)__popcll(pushing));
-                    if (rq_n == 64) {
-                        refine(64);
+                    rq_n = min(C::RQ, rq_n + (int)__popcll(pushing));
+                    if (rq_n == C::RQ) {
+                        refine(C::RQ);
                         rq_n = 0;
                     }
                 }

@@ -109,6 +109,8 @@ typedef struct dpq_profile {
     int64_t scan_stream_bytes;         /* SoA bytes the scan launches had to read at least once */
     int64_t query_batches, queries;
     int64_t overflow_reruns;           /* queries that needed a second final pass (candidate overflow) */
+    int64_t exact_checks;              /* (code, query) pairs the filter let through, checked exactly in the scan */
+    int64_t candidates;                /* pairs that passed the exact check (counted with dpq_profile_enable(idx, 1) only) */
 } dpq_profile;
 
 typedef struct dpq_dtc_stats {
