@@ -174,7 +174,7 @@ int ensure_plan(dpq_index* x, int top_k, int cap, int coarse) {
     if (x->plan_top_k == top_k && x->plan_cap == cap && x->plan_coarse == coarse) return DPQ_OK;
     const int64_t S = (int64_t)dpq::kChunk * x->img.chunks_per_segment;
     const int64_t nseg = x->img.n_segments;
-    const int64_t s0 = std::min<int64_t>(nseg, std::max<int64_t>(1, dpq::kSortMax / S));
+    const int64_t s0 = std::min<int64_t>(nseg, std::max<int64_t>(1, dpq::kLevel0Nodes / S));
     std::vector<int64_t> bounds;
     if (s0 >= nseg) {
         bounds.push_back(nseg);

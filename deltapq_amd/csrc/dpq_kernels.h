@@ -12,6 +12,7 @@ constexpr int kMaxTopK = 2048;
 constexpr int kSelectThreads = 512;
 constexpr int kMaxSplits = 256;                  // scan workgroups per query group
 constexpr int kRegionStride = 1 + kMaxSplits;    // candidate-count words per slot
+constexpr int kLevel0Nodes = 3840;               // level-0 list: its select block (keys + exact tables) stays under 40 KB of LDS
 constexpr int kSortMax = 4096;  // candidate keys the select kernel holds in LDS; more -> radix select on the HBM list
 // queries per scan workgroup = what 128 KB of filter tables hold: 8-bit entries for M = 8, 16-bit for M = 16
 inline int queries_per_group(int M) { return M <= 8 ? 64 : 16; }
@@ -91,6 +92,6 @@ hipError_t launch_merge(const int32_t* d_ids, const float* d_dists, int n_lists,
 hipError_t launch_encode_pq(const float* d_vectors, int64_t n, int D, const float* d_codebook, int M, int K, int Ds,
                             uint8_t* d_codes, hipStream_t stream);
 size_t scan_lds_bytes(int M);
-size_t select_lds_bytes(int M, int top_k, bool level0);
+size_t select_lds_bytes(int M, int top_k, int n_shared);
 
 }  // namespace dpq

@@ -648,11 +648,12 @@ __device__ __forceinline__ void block_bitonic_sort(uint64_t* v, int n_pow2, int 
 }
 
 // k-th smallest (1-based rank `rank`) of keys[0..n) -- LDS or HBM -- by MSB-first
-// 8-bit radix select.  Distances of one query share their sign/exponent bits, so
-// raw keys would put every element into one bin for the first passes (thousands
-// of serialised LDS atomics): the passes run on (key - min) and start at the
-// first byte in which (max - min) is non-zero.  Histogram with LDS atomics, bin
-// scan by one wavefront (no barriers inside), 3 barriers per pass.
+// radix select with digits of up to 8 bits.  Distances of one query share their
+// sign/exponent bits, so raw keys would put every element into one bin for the
+// first passes (thousands of serialised LDS atomics): the passes run on
+// (key - min) and the first digit starts at the top set bit of (max - min).
+// Histogram with LDS atomics, bin scan by one wavefront (no barriers inside),
+// 3 barriers per pass; the walk stops as soon as the chosen bin holds one key.
 // `ignore` (= ~0) marks padding entries; they sort last and are never selected
 // because rank <= number of valid keys.
 __device__ uint64_t block_radix_select(const uint64_t* keys, int n, int rank, uint32_t* hist, uint32_t* bcast,
@@ -687,19 +688,24 @@ __device__ uint64_t block_radix_select(const uint64_t* keys, int n, int rank, ui
     }
     __syncthreads();
     const uint64_t span = hi - lo;                                   // valid keys live in [0, span] after the shift
-    const int top = span ? (63 - __clzll((long long)span)) >> 3 : 0;  // most significant non-zero byte
+    // digits are cut from the most significant set bit of span downwards, so the first pass already
+    // spreads the keys over >= 128 bins (a byte-aligned first digit may hold only a few values)
+    const int hi_bit = span ? 63 - __clzll((long long)span) : 0;
+    int shift = hi_bit > 7 ? hi_bit - 7 : 0;
+    int width = hi_bit - shift + 1;  // <= 8
+    bool first = true;
     uint64_t prefix = 0;
     uint32_t rem = (uint32_t)rank;
-    for (int pass = top; pass >= 0; --pass) {
+    for (;;) {
         if (tid < 256) hist[tid] = 0;
         __syncthreads();
-        const int shift = 8 * pass;
+        const uint32_t dmask = (1u << width) - 1u;
         for (int i = tid; i < n; i += nthreads) {
             const uint64_t raw = keys[i];
             if (raw == ~0ull) continue;
             const uint64_t key = raw - lo;
-            const bool match = pass == top ? true : ((key >> (shift + 8)) == (prefix >> (shift + 8)));
-            if (match) atomicAdd(&hist[(uint32_t)(key >> shift) & 255u], 1u);
+            const bool match = first ? true : ((key >> (shift + width)) == (prefix >> (shift + width)));
+            if (match) atomicAdd(&hist[(uint32_t)(key >> shift) & dmask], 1u);
         }
         __syncthreads();
         if (tid < 64) {  // wave 0: lane l owns bins 4l..4l+3
@@ -716,13 +722,30 @@ __device__ uint64_t block_radix_select(const uint64_t* keys, int n, int rank, ui
                 uint32_t r = rem - before;
                 int bin = 4 * tid;
                 if (r > h0) { r -= h0; ++bin; if (r > h1) { r -= h1; ++bin; if (r > h2) { r -= h2; ++bin; } } }
-                bcast[0] = (uint32_t)bin;
+                const uint32_t hb = bin == 4 * tid ? h0 : bin == 4 * tid + 1 ? h1 : bin == 4 * tid + 2 ? h2 : h3;
+                bcast[0] = (uint32_t)bin | (hb == 1u ? 0x100u : 0u);  // bit 8: the bin holds exactly one key
                 bcast[1] = r;
             }
         }
         __syncthreads();
-        prefix |= (uint64_t)bcast[0] << shift;
+        prefix |= (uint64_t)(bcast[0] & 0xffu) << shift;
         rem = bcast[1];
+        if (shift == 0) break;
+        if (bcast[0] & 0x100u) {
+            // one key left under this prefix: fetch it instead of walking the remaining digits
+            uint64_t* found = reinterpret_cast<uint64_t*>(hist);  // the histogram is no longer needed
+            for (int i = tid; i < n; i += nthreads) {
+                const uint64_t raw = keys[i];
+                if (raw != ~0ull && ((raw - lo) >> shift) == (prefix >> shift)) *found = raw;
+            }
+            __syncthreads();
+            const uint64_t r = *found;
+            __syncthreads();  // callers reuse hist
+            return r;
+        }
+        width = shift < 8 ? shift : 8;
+        shift -= width;
+        first = false;
     }
     return prefix + lo;
 }
@@ -742,12 +765,18 @@ __global__ __launch_bounds__(kSelectThreads) void select_kernel(const SelectArgs
     // 2048 maximum: at top_k = 100 a block needs 35 KB and four blocks share a CU
     int KP = 1;
     while (KP < a.top_k) KP <<= 1;
-    uint64_t* skeys = reinterpret_cast<uint64_t*>(smem);                              // [kSortMax] candidate keys
-    uint64_t* wkeys = skeys + kSortMax;                                               // [KP] winner keys
+    // LDS: [candidate keys][winner keys, histogram | level 0: the query's exact tables][counters].
+    // The tables are dead once the level-0 list is evaluated, so they share their space with what the
+    // selection needs afterwards: a level-0 block stays under 40 KB and four of them fit a CU.
+    const int n_lds_keys = a.shared_id ? min(a.shared_n, kSortMax) : kSortMax;
+    uint64_t* skeys = reinterpret_cast<uint64_t*>(smem);                              // [n_lds_keys] candidate keys
+    unsigned char* shared_area = smem + (size_t)n_lds_keys * 8;
+    float* T = reinterpret_cast<float*>(shared_area);                                 // [M][256], level 0 only
+    uint64_t* wkeys = reinterpret_cast<uint64_t*>(shared_area);                       // [KP] winner keys
     uint32_t* hist = reinterpret_cast<uint32_t*>(wkeys + KP);                         // [kRegionStride + 1 <= 264]
     uint32_t* bcast = hist + 264;                                                     // [2]
-    uint32_t* counters = bcast + 2;                                                   // [2]: winners, padding nodes
-    float* T = reinterpret_cast<float*>(counters + 2);                                // [M][256], level 0 only
+    const size_t select_bytes = (size_t)KP * 8 + 266 * 4, table_bytes = a.shared_id ? (size_t)TE * 4 : 0;
+    uint32_t* counters = reinterpret_cast<uint32_t*>(shared_area + (select_bytes > table_bytes ? select_bytes : table_bytes));  // [2]: winners, padding nodes
 
     const int slot = blockIdx.x;
     const int tid = threadIdx.x;
@@ -970,11 +999,13 @@ hipError_t launch_encode_pq(const float* d_vectors, int64_t n, int D, const floa
 
 size_t scan_lds_bytes(int M) { return M <= 8 ? ScanLds<8>::kBytes : ScanLds<16>::kBytes; }
 
-// `level0`: the block also stages the query's exact tables (M KB)
-size_t select_lds_bytes(int M, int top_k, bool level0) {
+// level 0 (n_shared > 0): the block holds n_shared keys and stages the query's exact tables (M KB)
+size_t select_lds_bytes(int M, int top_k, int n_shared) {
     size_t kp = 1;
     while (kp < (size_t)top_k) kp <<= 1;
-    return (size_t)kSortMax * 8 + kp * 8 + (264 + 2 + 2) * 4 + (level0 ? (size_t)M * 256 * 4 : 0);
+    const size_t n_keys = n_shared > 0 ? (size_t)std::min(n_shared, kSortMax) : (size_t)kSortMax;
+    const size_t select_bytes = kp * 8 + 266 * 4, table_bytes = n_shared > 0 ? (size_t)M * 256 * 4 : 0;
+    return n_keys * 8 + std::max(select_bytes, table_bytes) + 16;
 }
 
 // hipFuncSetAttribute is per device; handles may live on several GPUs
@@ -1039,10 +1070,10 @@ template <int M>
 static hipError_t launch_select_m(const SelectArgs& a, int n_slots, hipStream_t stream) {
     static bool done[64] = {};
     hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&select_kernel<M>),
-                                      select_lds_bytes(M, kMaxTopK, true), done);
+                                      select_lds_bytes(M, kMaxTopK, kSortMax), done);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(select_kernel<M>, dim3((unsigned)n_slots), dim3(kSelectThreads),
-                       select_lds_bytes(M, a.top_k, a.shared_id != nullptr), stream, a);
+                       select_lds_bytes(M, a.top_k, a.shared_id ? a.shared_n : 0), stream, a);
     return hipGetLastError();
 }
 
