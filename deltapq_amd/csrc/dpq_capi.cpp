@@ -294,7 +294,8 @@ int run_batch(dpq_index* x, const float* d_queries, int nq, int top_k, int32_t* 
     const int ngroups = nqp / QG;
     const int cap = x->cap_auto ? auto_cap(top_k) : std::max(x->cap, top_k);
     int rc;
-    if ((rc = ensure_plan(x, top_k, cap, nq <= 128 ? 1 : 0))) return rc;
+    static const int coarse_below = getenv("DPQ_COARSE_BELOW") ? atoi(getenv("DPQ_COARSE_BELOW")) : 128;
+    if ((rc = ensure_plan(x, top_k, cap, nq <= coarse_below ? 1 : 0))) return rc;
     int64_t stride = top_k;
     for (size_t l = 1; l < x->level_cnt.size(); ++l)
         stride = std::max(stride, regions_for(x, x->level_cnt[l], ngroups, top_k, cap).stride);

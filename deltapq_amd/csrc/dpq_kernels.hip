@@ -527,7 +527,8 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanArgs a) {
         __builtin_amdgcn_wave_barrier();
     };
 
-    for (int s = split * kScanWaves + wave; s < a.n_seg_pass; s += gridDim.x * kScanWaves) {
+    // list entry s -> workgroup s % splits, wavefront (s / splits) % 16: a short list still reaches every workgroup
+    for (int s = split + (int)gridDim.x * wave; s < a.n_seg_pass; s += gridDim.x * kScanWaves) {
         const uint32_t seg = (uint32_t)__builtin_amdgcn_readfirstlane(a.seg_list ? (int)a.seg_list[s] : s);
         if (!PLAIN) dec.begin_segment(a.img, seg, lane);
         for (int c = 0; c < cps; ++c) {
