@@ -356,7 +356,8 @@ struct ScanLds {
     static constexpr size_t kBase = kThr + (size_t)Cfg<M>::QG * 8;                  // [QG] i32 row of the exact tables
     static constexpr size_t kCount = kBase + (size_t)Cfg<M>::QG * 4;                // [QG] candidates of this workgroup
     // per-wave queue of (node, query) pairs that passed the filter and await the exact check
-    static constexpr size_t kQCode = kCount + (size_t)Cfg<M>::QG * 4;               // [waves][RQ][W] dwords
+    static constexpr size_t kChecks = kCount + (size_t)Cfg<M>::QG * 4;              // [4] statistics: pairs checked exactly
+    static constexpr size_t kQCode = kChecks + 16;                                  // [waves][RQ][W] dwords
     static constexpr size_t kQId = kQCode + (size_t)kScanWaves * Cfg<M>::RQ * M;    // [waves][RQ] u32
     static constexpr size_t kQSlot = kQId + (size_t)kScanWaves * Cfg<M>::RQ * 4;    // [waves][RQ] u8
     static constexpr size_t kBytes = kQSlot + (size_t)kScanWaves * Cfg<M>::RQ;
@@ -376,6 +377,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanArgs a) {
     // candidates found by this workgroup per query; their keys go straight to the workgroup's own region
     // of the query's candidate buffer (plain stores, no global atomics), the counts in the epilogue
     uint32_t* wg_count = reinterpret_cast<uint32_t*>(smem + ScanLds<M>::kCount);        // [QG]
+    uint32_t* wg_checks = reinterpret_cast<uint32_t*>(smem + ScanLds<M>::kChecks);      // [1]
     // refine queue of this wavefront: filter survivors wait here until 64 of them can be checked at once
     uint32_t* rq_code = reinterpret_cast<uint32_t*>(smem + ScanLds<M>::kQCode) + (size_t)(threadIdx.x >> 6) * C::RQ * C::W;
     uint32_t* rq_id = reinterpret_cast<uint32_t*>(smem + ScanLds<M>::kQId) + (size_t)(threadIdx.x >> 6) * C::RQ;
@@ -451,6 +453,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanArgs a) {
         s_base[tid] = qq >= 0 ? qq * TE : -1;
         s_thr[tid] = key;
         wg_count[tid] = 0;
+        if (tid == 0) *wg_checks = 0;
     }
     __syncthreads();
     // one iteration = one dword column (F slots) of 4 consecutive codes of one (g, m): per slot one
@@ -498,7 +501,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanArgs a) {
     const size_t region0 = (size_t)a.region_off + (size_t)split * a.region_cap;  // this workgroup's region in a slot's buffer
     auto refine = [&](int n) {
         __builtin_amdgcn_wave_barrier();  // queue entries were written by other lanes of this wavefront
-        if (a.counters && lane == 0) atomicAdd(&a.counters[0], (unsigned long long)n);
+        if (a.counters && lane == 0) atomicAdd(wg_checks, (uint32_t)n);
         constexpr int E = C::RQ / 64;  // entries per lane: their table gathers are in flight together
         uint32_t c[E][W];
         int ls[E];
@@ -518,7 +521,6 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanArgs a) {
         for (int e = 0; e < E; ++e) {
             const uint64_t key = make_key(d[e], eid[e]);
             if (lane + 64 * e < n && key <= s_thr[ls[e]]) {
-                if (a.counters) atomicAdd(&a.counters[1], 1ull);
                 const uint32_t li = atomicAdd(&wg_count[ls[e]], 1u);
                 if (li < (uint32_t)a.region_cap)
                     a.cand_key[(size_t)(slot0 + ls[e]) * a.cand_stride + region0 + li] = key;
@@ -623,6 +625,16 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanArgs a) {
     // kernel that candidates were dropped) ----
     __syncthreads();
     if (tid < QG) a.cand_count[(size_t)(slot0 + tid) * kRegionStride + 1 + split] = wg_count[tid];
+    if (a.counters && tid < 64) {  // statistics: one pair of global atomics per workgroup
+        uint32_t c = 0;
+        for (int q = tid; q < QG; q += 64) c += wg_count[q];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) c += (uint32_t)__shfl_xor((int)c, off, 64);
+        if (tid == 0) {
+            atomicAdd(&a.counters[0], (unsigned long long)*wg_checks);
+            atomicAdd(&a.counters[1], (unsigned long long)c);
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------
