@@ -46,7 +46,14 @@ def measured_traffic(args):
     return s.get("scan_kernel_hbm_bytes_per_launch"), s.get("tag")
 
 
-def build_workload(args, device):
+def make_queries(args, seed):
+    from deltapq_amd import synth
+    if args.data == "pipeline":
+        return synth.make_clustered_vectors(args.queries, args.dim, seed=seed, n_clusters=20000, spread=12.0, centre_seed=7)
+    return synth.make_queries(args.queries, args.dim, seed=seed)
+
+
+def build_workload(args, device, query_seed=101):
     """`pipeline` (default): SIFT-shaped vectors (mixture of 20 000 Gaussians, values 0..218) ->
     k-means codebook -> PQ codes (GPU encoder) -> DeltaTree (host builder, reference method 1) -> DTC.
     `stream`: random DeltaTree emitted directly as (depth, mask, bytes) triples."""
@@ -54,8 +61,7 @@ def build_workload(args, device):
     t0 = time.time()
     if args.data == "pipeline":
         base = synth.make_clustered_vectors(args.n, args.dim, seed=100, n_clusters=20000, spread=12.0, centre_seed=7)
-        queries = synth.make_clustered_vectors(args.queries, args.dim, seed=101, n_clusters=20000, spread=12.0,
-                                               centre_seed=7)
+        queries = make_queries(args, query_seed)
         cb = synth.kmeans_codebook(base, args.m, 256, iters=6, seed=102)
         codes = api.encode_pq(base, cb, device=device)
         del base
@@ -67,7 +73,7 @@ def build_workload(args, device):
         tree.close()
     else:
         cb = synth.make_codebook(args.m, 256, args.dim // args.m, seed=100)
-        queries = synth.make_queries(args.queries, args.dim, seed=101)
+        queries = make_queries(args, query_seed)
         tree = synth.synth_tree(args.n, args.m, seed=102, mean_diffs=args.mean_diffs)
         payload, n_bytes = synth.encode_dtc(tree)
         desc = "random (depth, mask, bytes) stream"
@@ -115,6 +121,11 @@ def main():
     ap.add_argument("--cpu-queries", type=int, default=700, help="queries timed on the CPU oracle (1 thread)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--check", type=int, default=4, help="queries verified against the oracle before timing")
+    ap.add_argument("--shard", choices=["auto", "query", "index"], default="auto",
+                    help="N > 1: 'query' = every GPU holds the whole index and answers its own batch of --queries "
+                         "(independent units, no data-path collective, weak scaling); 'index' = the index is cut into "
+                         "DFS ranges, every GPU answers the one batch on its range, one all-gather + merge (strong "
+                         "scaling; what an index beyond one GPU's HBM needs); auto = query while the index fits")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="gloo = rehearsal of the N > 1 path on a box with fewer GPUs than ranks (ranks share GPUs)")
     args = ap.parse_args()
@@ -147,9 +158,20 @@ def main():
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    wl = build_workload(args, local_rank)
-    idx = api.DeltaPQIndex.open_memory(wl["payload"], args.n, args.m, 256, device=local_rank, shard_rank=rank,
-                                       shard_count=world, chunks_per_segment=args.chunks_per_segment)
+    # N > 1 decomposition.  Queries are independent units: while the whole index fits one GPU (4.5 MB at
+    # 1 M codes, 4.5 GB at 1 B codes, of 288 GB) every GPU keeps a replica and answers its own batch --
+    # no data-path collective, per-GPU work fixed ("weak").  Index sharding (DFS ranges, one all-gather
+    # of the partial lists + merge, "strong") is what larger indexes need; it is measured beside it.
+    shard_mode = args.shard
+    if shard_mode == "auto":
+        shard_mode = "query" if (5 * args.n) < (64 << 30) else "index"
+    if world == 1:
+        shard_mode = "index"   # one shard == the whole index
+    by_query = shard_mode == "query"
+    wl = build_workload(args, local_rank, query_seed=101 + (rank if by_query else 0))
+    idx = api.DeltaPQIndex.open_memory(wl["payload"], args.n, args.m, 256, device=local_rank,
+                                       shard_rank=0 if by_query else rank, shard_count=1 if by_query else world,
+                                       chunks_per_segment=args.chunks_per_segment)
     idx.set_codebook(wl["codebook"])
     info = idx.info()
     q_dev = torch.from_numpy(wl["queries"]).to(dev)
@@ -160,7 +182,9 @@ def main():
 
     def step():
         idx.query_batch_torch(q_dev, k, ids, dists)
-        # N > 1: the path's one exchange step -- all-gather of the partial lists
+        if by_query:
+            return ids, dists   # this rank's batch is complete
+        # index shards: the path's one exchange step -- all-gather of the partial lists
         # (nq*k*8 B per rank) over RCCL, then the device merge
         return dpq_dist.gather_and_merge(ids, dists)
 
@@ -214,11 +238,35 @@ def main():
     prof["select_ms"] = prof_aux["select_ms"] * args.steps / aux_steps
     prof["lut_ms"] = prof_aux["lut_ms"] * args.steps / aux_steps
 
+    # N > 1 with replicas: also time the index-sharded decomposition of ONE batch (rank 0's queries), outside
+    # the timed region, so both ways of using the GPUs are on record
+    alt = None
+    if world > 1 and by_query:
+        q0 = torch.from_numpy(make_queries(args, 101)).to(dev)
+        sidx = api.DeltaPQIndex.open_memory(wl["payload"], args.n, args.m, 256, device=local_rank, shard_rank=rank,
+                                            shard_count=world, chunks_per_segment=args.chunks_per_segment)
+        sidx.set_codebook(wl["codebook"])
+
+        def sstep():
+            sidx.query_batch_torch(q0, k, ids, dists)
+            return dpq_dist.gather_and_merge(ids, dists)
+
+        m_ids, _ = sstep()
+        for _ in range(args.warmup):
+            sstep()
+        sync()
+        ta = time.perf_counter()
+        for _ in range(args.steps):
+            sstep()
+        sync()
+        alt = time.perf_counter() - ta
+        sidx.close()
+
     cdev = torch.device("cpu") if cpu_coll else dev
-    t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
+    t = torch.tensor([elapsed, alt or 0.0], dtype=torch.float64, device=cdev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+    elapsed, alt = float(t[0].item()), float(t[1].item())
     # per-rank scan figures -> rank 0 (sum of algorithmic bytes, max of kernel time)
     stats = torch.tensor([prof["scan_ms"], float(prof["scan_launches"]), float(info["algorithmic_bytes"]),
                           float(info["device_bytes"]), prof["select_ms"], prof["lut_ms"]], dtype=torch.float64,
@@ -234,20 +282,20 @@ def main():
         steps = max(1, args.steps)
         scan_ms_step = float(all_stats[:, 0].max()) / steps              # slowest rank
         launches_step = float(all_stats[0, 1]) / steps
-        alg_bytes_total = float(all_stats[:, 2].sum())                    # == n_bytes of the DTC payload
+        alg_bytes_total = float(all_stats[:, 2].sum())   # index shards: n_bytes of the payload; replicas: world x n_bytes
         achieved = (nq * alg_bytes_total) / (scan_ms_step * 1e-3) / 1e9 if scan_ms_step > 0 else 0.0
         peak = HBM_PEAK_GBPS * world
         traffic, traffic_tag = measured_traffic(args)
         result = {
             "metric": "queries/sec, SIFT1M-shaped m=%d k=256 topk=%d" % (args.m, k),
-            "value": nq * steps / elapsed,
+            "value": (world if by_query else 1) * nq * steps / elapsed,
             "unit": "queries/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / steps,
             "higher_is_better": True,
-            "scaling": "strong",
+            "scaling": "weak" if by_query else "strong",
             "vs_baseline": None,
             "dtype": "f64-sum-of-f32 (u8 code decode)",
             "data": "synthetic",
@@ -256,7 +304,10 @@ def main():
                             "%.2f B/code, %.2f diffs/node" % (wl["desc"], args.n, args.m, k, nq, wl["n_bytes"] / args.n,
                                                               (wl["n_bytes"] - args.m) / args.n - (1.5 if args.m <= 8 else 2.5)),
                 "n_codes": args.n, "queries_per_step": nq, "topk": k, "n_bytes": int(wl["n_bytes"]),
-                "sharding": "dfs-range x%d" % world, "queries_per_decode_pass": 64 if args.m <= 8 else 16,
+                "sharding": ("query replicas x%d: every GPU holds the whole index and answers its own %d-query batch"
+                             % (world, nq)) if by_query else "dfs-range index shards x%d, one batch" % world,
+                "global_queries_per_step": (world if by_query else 1) * nq,
+                "queries_per_decode_pass": 64 if args.m <= 8 else 16,
             },
             "roofline": {
                 "bound": "hbm",
@@ -288,6 +339,11 @@ def main():
             "index": {"device_bytes_rank0": int(all_stats[0, 3]), "segments_rank0": info["n_segments"],
                       "gen_seconds": wl["gen_s"]},
         }
+        if alt:
+            result["index_sharded"] = {
+                "note": "same GPUs, the index cut into %d DFS ranges, ONE %d-query batch answered by all of them "
+                        "(all-gather of the partial lists + merge); %d steps timed after the main region" % (world, nq, steps),
+                "value": nq * steps / alt, "unit": "queries/s", "ms_per_step": 1e3 * alt / steps, "scaling": "strong"}
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(wl, args)
         print(json.dumps(result))
