@@ -6,30 +6,35 @@
 //
 //   lut_build_kernel        a3: T[m][k] = sum_d (c[m][k][d] - q[m*Ds+d])^2 with the
 //                           reference's mixed fp32/fp64 arithmetic (h:2841-2849).
-//   scan_kernel             a5 + filter half of a6: delta decode + ADC + threshold
-//                           filter.  One wavefront = one 64-node chunk per step;
-//                           child codes are rebuilt from parent + packed deltas by
-//                           pointer jumping over ds_bpermute; distances are LDS table
+//   scan_kernel             a5 + most of a6: delta decode + ADC filter + exact check.
+//                           One wavefront = one 64-node chunk per step; child codes
+//                           are rebuilt from parent + packed deltas by pointer jumping
+//                           over ds_bpermute; lower-bound distances are LDS table
 //                           gathers (a lookup workload: no MFMA).  A workgroup keeps
-//                           the filter tables of 32 queries in LDS and decodes every
-//                           chunk once for all of them.
+//                           the filter tables of 64 queries in LDS (16 at M = 16) and
+//                           decodes every chunk once for all of them.  What the filter
+//                           lets through is queued per wavefront and checked exactly
+//                           (the reference's distance, whole (distance, id) keys)
+//                           against the query's threshold key; what passes is a
+//                           candidate key in the workgroup's own region of the
+//                           query's buffer (no global atomics).
 //   decode_segments_kernel  the same decode, writing plain codes (cascade level 0
 //                           is query independent).
-//   select_kernel           exact half of a6: fp64 re-evaluation of the surviving
-//                           candidates, k-th smallest (distance, id) key, winners
-//                           carried to the next level, next-level filter tables;
+//   select_kernel           the rest of a6: level 0 evaluated exactly, later levels'
+//                           candidate regions gathered; k-th smallest (distance, id)
+//                           key = next threshold, winners carried to the next level;
 //                           on the last level the sorted top-k.
 //   merge_kernel            8e: merge of per-shard partial top-k lists.
 //
 // Top-k strategy (replaces the sequential size-k max-heap, h:2851-2853,
 // 2909-2914): a progressive threshold cascade.  Segments are visited in a
 // low-discrepancy order, every segment exactly once; level l keeps the nodes
-// whose distance can still be <= the k-th best key of everything seen before,
-// which is the key of a real node and therefore a valid upper bound of the
-// final k-th key.  The in-scan filter is a CONSERVATIVE LOWER BOUND of the
-// distance in 16-bit fixed point (tables quantised per query in the scan
-// prologue, scaled to its threshold, rounded down; saturating adds), so it never
-// drops a node the exact rule would keep; select_kernel then applies the exact rule.
+// whose key is <= the k-th best key of everything seen before, which is the key
+// of a real node and therefore a valid upper bound of the final k-th key.  The
+// in-scan filter is a CONSERVATIVE LOWER BOUND of the distance in 8-bit fixed
+// point (16-bit at M = 16; tables quantised per query in the scan prologue,
+// scaled to its threshold, rounded down, saturated), so it never drops a node
+// the exact rule would keep.
 #include "dpq_kernels.h"
 
 #include <cfloat>
@@ -40,13 +45,6 @@ namespace dpq {
 // ---------------------------------------------------------------------------
 // small device helpers
 // ---------------------------------------------------------------------------
-
-typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
-
-__device__ __forceinline__ uint32_t pk_sub_sat_u16(uint32_t a, uint32_t b) {  // v_pk_sub_u16 clamp
-    return __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(__builtin_bit_cast(u16x2, a),
-                                                                      __builtin_bit_cast(u16x2, b)));
-}
 
 __device__ __forceinline__ uint32_t bperm(int src_lane, uint32_t v) {
     return (uint32_t)__builtin_amdgcn_ds_bpermute(src_lane << 2, (int)v);
