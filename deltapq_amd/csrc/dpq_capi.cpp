@@ -579,7 +579,7 @@ int open_plain(const uint8_t* codes, int64_t n_codes, int M, int K, const dpq_op
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(DPQ_ERR_NO_DEVICE, "no HIP device visible; this library has no CPU fallback");
     if (o.device < 0 || o.device >= ndev) return fail(DPQ_ERR_NO_DEVICE, "device ordinal out of range");
-    int cps = o.chunks_per_segment <= 0 ? 4 : o.chunks_per_segment;
+    int cps = o.chunks_per_segment <= 0 ? dpq::kDefaultChunksPerSegment : o.chunks_per_segment;
     if (cps > dpq::kSortMax / dpq::kChunk) return fail(DPQ_ERR_ARG, "chunks_per_segment must be <= 64");
     int count = o.shard_count <= 0 ? 1 : o.shard_count;
     if (o.shard_rank < 0 || o.shard_rank >= count) return fail(DPQ_ERR_ARG, "bad shard_rank / shard_count");

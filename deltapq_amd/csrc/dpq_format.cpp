@@ -144,7 +144,7 @@ int transcode(const uint8_t* payload, int64_t n_bytes, int64_t n_codes, int M, i
     int rc = check_args(payload, n_bytes, n_codes, M, err);
     if (rc) return rc;
     if (shard_count <= 0) shard_count = 1;
-    if (chunks_per_segment <= 0) chunks_per_segment = 4;
+    if (chunks_per_segment <= 0) chunks_per_segment = kDefaultChunksPerSegment;
     if (shard_rank < 0 || shard_rank >= shard_count || chunks_per_segment > 1024) {
         if (err) *err = "bad shard_rank / shard_count / chunks_per_segment";
         return DPQ_ERR_ARG;

@@ -14,6 +14,9 @@
 namespace dpq {
 
 constexpr int kChunk = 64;  // nodes per wavefront step
+// chunks per independently decodable segment: 128-node segments balance the scan's wavefronts better than 256
+// (0.431 vs 0.451 ms per 1000-query step at 1 M codes) for 0.56 B/node of checkpoints and offsets
+constexpr int kDefaultChunksPerSegment = 2;
 
 inline int mask_bytes_for(int M) { return M > 8 ? 2 : 1; }
 inline int depth_field_mask(int M) { return M > 8 ? 15 : 7; }  // h:2883 uses & 7 for M <= 8
@@ -54,7 +57,7 @@ struct SoA {
     int M = 8;
     int levels = 8;
     int mask_bytes = 1;
-    int chunks_per_segment = 4;
+    int chunks_per_segment = kDefaultChunksPerSegment;
     int64_t n_codes_total = 0, n_bytes_total = 0;
     int64_t node_lo = 0, node_hi = 0;  // global DFS positions in this image
     int64_t n_segments = 0;            // local segments

@@ -80,7 +80,7 @@ typedef struct dpq_open_opts {
     int32_t shard_rank;         /* this handle holds shard `shard_rank` of `shard_count` */
     int32_t shard_count;        /* 0 or 1 = whole index; shards are contiguous DFS-position ranges
                                    cut at segment boundaries and balanced by payload bytes */
-    int32_t chunks_per_segment; /* 64-node chunks per independently decodable segment; 0 = default (4) */
+    int32_t chunks_per_segment; /* 64-node chunks per independently decodable segment; 0 = default (2) */
     int32_t cand_capacity;      /* candidate keys per query and cascade level, shared out evenly to the scan
                                  * workgroups of the query's group; 0 = auto (16 K keys, >= 256 per workgroup) */
     int32_t reserved[3];

@@ -110,7 +110,7 @@ def test_shards_partition_the_index(lib):
 def test_more_shards_than_segments(lib):
     from deltapq_amd import dist
     tree, payload, nb = make_case(300, seed=4)                      # 2 segments of 256
-    ranges = dist.shard_ranges(payload, 300, 8)
+    ranges = dist.shard_ranges(payload, 300, 8, chunks_per_segment=4)
     assert ranges[0][0] == 0 and ranges[-1][1] == 300
     assert sum(hi - lo for lo, hi, _ in ranges) == 300
     assert sum(1 for lo, hi, _ in ranges if hi > lo) <= 2           # the rest are empty shards

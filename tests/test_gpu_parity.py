@@ -276,13 +276,14 @@ def test_large_shard_config3_per_gpu_share(gpu, oracle, codebook):
     del tree
     qs = synth.make_queries(nq, 128, seed=8)
     ids, dists, prof, info = run(gpu, payload, n, codebook, qs, k)
-    assert info["algorithmic_bytes"] == nb and info["n_segments"] == (n + 255) // 256
+    S = 64 * info["chunks_per_segment"]
+    assert info["algorithmic_bytes"] == nb and info["n_segments"] == (n + S - 1) // S
     sample = [0, 21, 42, 63]
     assert_parity(ids[sample], dists[sample], oracle_topk(oracle, payload, n, codebook, qs[sample], k), n)
     assert np.all(np.diff(dists, axis=1) >= 0)
     for r in range(nq):
         assert len(set(ids[r].tolist())) == k and ids[r].min() >= 0 and ids[r].max() <= n
-    assert prof["scan_node_query_pairs"] == info["n_segments"] * 256 * nq
+    assert prof["scan_node_query_pairs"] == info["n_segments"] * S * nq
     # the same index as shard 5 of 8 (what one rank of the 8-GPU run holds)
     ids5, dists5, _, info5 = run(gpu, payload, n, codebook, qs[:8], k, shard_rank=5, shard_count=8)
     lut = oracle.build_lut(codebook, qs[3])
