@@ -376,6 +376,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanArgs a) {
     // of the query's candidate buffer (plain stores, no global atomics), the counts in the epilogue
     uint32_t* wg_count = reinterpret_cast<uint32_t*>(smem + ScanLds<M>::kCount);        // [QG]
     uint32_t* wg_checks = reinterpret_cast<uint32_t*>(smem + ScanLds<M>::kChecks);      // [1]
+    uint32_t* wg_next = wg_checks + 1;                                                  // [1] next list entry of this workgroup
     // refine queue of this wavefront: filter survivors wait here until 64 of them can be checked at once
     uint32_t* rq_code = reinterpret_cast<uint32_t*>(smem + ScanLds<M>::kQCode) + (size_t)(threadIdx.x >> 6) * C::RQ * C::W;
     uint32_t* rq_id = reinterpret_cast<uint32_t*>(smem + ScanLds<M>::kQId) + (size_t)(threadIdx.x >> 6) * C::RQ;
@@ -383,7 +384,6 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanArgs a) {
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
     // Workgroups are dealt to the 8 XCDs round-robin in launch order.  All workgroups of a query group
     // read the same exact tables (QG * M KB, prologue and exact checks), so give each XCD whole groups:
     // its L2 then holds 1/8 of the batch's tables instead of all of them.
@@ -451,7 +451,10 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanArgs a) {
         s_base[tid] = qq >= 0 ? qq * TE : -1;
         s_thr[tid] = key;
         wg_count[tid] = 0;
-        if (tid == 0) *wg_checks = 0;
+        if (tid == 0) {
+            *wg_checks = 0;
+            *wg_next = 0;
+        }
     }
     __syncthreads();
     // one iteration = one dword column (F slots) of 4 consecutive codes of one (g, m): per slot one
@@ -527,8 +530,15 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanArgs a) {
         __builtin_amdgcn_wave_barrier();
     };
 
-    // list entry s -> workgroup s % splits, wavefront (s / splits) % 16: a short list still reaches every workgroup
-    for (int s = split + (int)gridDim.x * wave; s < a.n_seg_pass; s += gridDim.x * kScanWaves) {
+    // list entry s -> workgroup s % splits (a short list still reaches every workgroup); inside the
+    // workgroup the wavefronts draw their next entry from an LDS counter, so a wavefront that met
+    // segments with many filter survivors does not hold the others back
+    for (;;) {
+        int j = 0;
+        if (lane == 0) j = (int)atomicAdd(wg_next, 1u);
+        j = __builtin_amdgcn_readfirstlane(j);
+        const int s = split + (int)gridDim.x * j;
+        if (s >= a.n_seg_pass) break;
         const uint32_t seg = (uint32_t)__builtin_amdgcn_readfirstlane(a.seg_list ? (int)a.seg_list[s] : s);
         if (!PLAIN) dec.begin_segment(a.img, seg, lane);
         for (int c = 0; c < cps; ++c) {
