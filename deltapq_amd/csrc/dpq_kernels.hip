@@ -46,6 +46,14 @@ namespace dpq {
 // small device helpers
 // ---------------------------------------------------------------------------
 
+// (a & mask) | c in one VALU op; the mask travels in an SGPR (a VOP3 cannot carry a 32-bit literal, and
+// without the asm the compiler emits v_and_b32 + v_or_b32)
+__device__ __forceinline__ uint32_t and_or(uint32_t a, uint32_t mask, uint32_t c) {
+    uint32_t r;
+    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(mask), "v"(c));
+    return r;
+}
+
 __device__ __forceinline__ uint32_t bperm(int src_lane, uint32_t v) {
     return (uint32_t)__builtin_amdgcn_ds_bpermute(src_lane << 2, (int)v);
 }
@@ -578,41 +586,31 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanArgs a) {
                 acc[4 * g + 3] = sw;
             }
             // ---- filter (replaces the heap test h:2909-2914): the top bit of a field rejects.
-            // Fold the top bits of the NA accumulators into MD mask dwords per lane. ----
-            uint32_t pass[MD];
+            // Fold the top bits of the NA accumulators into one pending mask per lane (bit = local slot):
+            // shift-and-insert with one mask constant, accumulator j of a mask dword ends at bit j of
+            // every field. ----
             const bool valid = node < a.img.n_local;
-            uint32_t any = 0;
+            uint64_t pend = 0;
 #pragma unroll
             for (int h = 0; h < MD; ++h) {
                 uint32_t fail = 0;
 #pragma unroll
-                for (int j = 0; j < C::J; ++j) fail |= (acc[EB * h + j] >> (EB - 1 - j)) & (C::LOW << j);
-                pass[h] = valid ? (~fail & live) : 0u;
-                any |= pass[h];
+                for (int j = 0; j < C::J; ++j) fail = and_or(acc[EB * h + j], C::LOW << (EB - 1), fail >> 1);
+                fail >>= EB - C::J;
+                pend |= (uint64_t)(valid ? (~fail & live) : 0u) << (32 * h);
             }
-            if (__any(any != 0)) {
+            if (__any(pend != 0)) {
                 // ---- queue what the filter let through: one (node, query) pair per lane and round;
                 // a full queue is checked exactly by all 64 lanes at once ----
                 const uint32_t id = a.img.id_base + (uint32_t)node;
-                for (;;) {
-                    int ls = -1, hsel = 0;
-                    uint32_t bit = 0;
-#pragma unroll
-                    for (int h = 0; h < MD; ++h) {
-                        if (ls < 0 && pass[h] != 0) {
-                            const int p = __ffs((int)pass[h]) - 1;
-                            bit = 1u << p;
-                            hsel = h;
-                            ls = h * (C::J * F) + (p / EB) * C::J + (p % EB);
-                        }
-                    }
-                    const uint64_t pushing = __ballot(ls >= 0);
-                    if (pushing == 0) break;
+                do {
+                    const bool has = pend != 0;
+                    const int p = has ? __ffsll((unsigned long long)pend) - 1 : 0;
+                    const uint64_t pushing = __ballot(has);  // never 0 here
                     const int pos = rq_n + (int)mbcnt64(pushing, 0);
-                    if (ls >= 0 && pos < C::RQ) {
-#pragma unroll
-                        for (int h = 0; h < MD; ++h)
-                            if (h == hsel) pass[h] &= ~bit;
+                    if (has && pos < C::RQ) {
+                        pend &= pend - 1;
+                        const int ls = (p >> 5) * (C::J * F) + ((p & 31) / EB) * C::J + (p % EB);  // bit -> local slot
 #pragma unroll
                         for (int w = 0; w < W; ++w) rq_code[pos * W + w] = code[w];
                         rq_id[pos] = id;
@@ -623,7 +621,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanArgs a) {
                         refine(C::RQ);
                         rq_n = 0;
                     }
-                }
+                } while (__any(pend != 0));
             }
         }
     }
