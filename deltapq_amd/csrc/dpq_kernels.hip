@@ -361,8 +361,8 @@ struct ScanLds {
     static constexpr size_t kThr = kDtab + 4096;                                    // [QG] u64 threshold keys
     static constexpr size_t kBase = kThr + (size_t)Cfg<M>::QG * 8;                  // [QG] i32 row of the exact tables
     static constexpr size_t kCount = kBase + (size_t)Cfg<M>::QG * 4;                // [QG] candidates of this workgroup
+    static constexpr size_t kChecks = kCount + (size_t)Cfg<M>::QG * 4;              // [4]: pairs checked exactly, next list entry
     // per-wave queue of (node, query) pairs that passed the filter and await the exact check
-    static constexpr size_t kChecks = kCount + (size_t)Cfg<M>::QG * 4;              // [4] statistics: pairs checked exactly
     static constexpr size_t kQCode = kChecks + 16;                                  // [waves][RQ][W] dwords
     static constexpr size_t kQId = kQCode + (size_t)kScanWaves * Cfg<M>::RQ * M;    // [waves][RQ] u32
     static constexpr size_t kQSlot = kQId + (size_t)kScanWaves * Cfg<M>::RQ * 4;    // [waves][RQ] u8
