@@ -105,6 +105,21 @@ def test_candidate_overflow_is_recovered(gpu, oracle, codebook):
     assert_parity(ids, dists, oracle_topk(oracle, payload, n, codebook, qs, 50), n)
 
 
+def test_profile_counts_filter_survivors_and_candidates(gpu, oracle, codebook):
+    """dpq_profile.exact_checks / .candidates: what the 8-bit lower-bound filter lets through is checked
+    exactly in the scan; every final result must have been a candidate, and the filter may only err on the
+    side of letting too much through."""
+    from deltapq_amd import synth
+    n, nq, k = 200000, 100, 20
+    tree, payload, _ = make_case(n, seed=41)
+    qs = synth.make_queries(nq, 128, seed=42)
+    ids, dists, prof, info = run(gpu, payload, n, codebook, qs, k)
+    assert_parity(ids, dists, oracle_topk(oracle, payload, n, codebook, qs, k), n)
+    assert prof["scan_launches"] >= 1 and prof["overflow_reruns"] == 0
+    assert prof["exact_checks"] >= prof["candidates"] > 0
+    assert prof["exact_checks"] < 0.05 * prof["scan_node_query_pairs"]      # the filter does filter
+
+
 def test_large_batch_is_split_internally(gpu, oracle, codebook):
     from deltapq_amd import synth
     n = 3000
