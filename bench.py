@@ -180,15 +180,20 @@ def main():
     dists = torch.empty((nq, k), dtype=torch.float32, device=dev)
     from deltapq_amd import dist as dpq_dist
 
+    # Batches that no collective follows are pipelined (dpq_query_batch_device_async): a step enqueues its
+    # batch, sync() settles them all (dpq_finish: waits, checks the overflow words, reruns if needed).
+    pipelined = by_query or world == 1
+
     def step():
-        idx.query_batch_torch(q_dev, k, ids, dists)
-        if by_query:
-            return ids, dists   # this rank's batch is complete
+        idx.query_batch_torch(q_dev, k, ids, dists, wait=not pipelined)
+        if pipelined:
+            return ids, dists   # this rank's batch; complete after sync()
         # index shards: the path's one exchange step -- all-gather of the partial lists
         # (nq*k*8 B per rank) over RCCL, then the device merge
         return dpq_dist.gather_and_merge(ids, dists)
 
     def sync():
+        idx.finish()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(dev)

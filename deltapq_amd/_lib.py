@@ -82,6 +82,8 @@ SYMBOLS = [
     ("dpq_close", ctypes.c_int, [_VP]),
     ("dpq_query_batch", ctypes.c_int, [_VP, _VP, ctypes.c_int, ctypes.c_int, _VP, _VP]),
     ("dpq_query_batch_device", ctypes.c_int, [_VP, _VP, ctypes.c_int, ctypes.c_int, _VP, _VP, _VP]),
+    ("dpq_query_batch_device_async", ctypes.c_int, [_VP, _VP, ctypes.c_int, ctypes.c_int, _VP, _VP, _VP]),
+    ("dpq_finish", ctypes.c_int, [_VP]),
     ("dpq_merge_topk_host", ctypes.c_int, [_VP, _VP, ctypes.c_int, ctypes.c_int, ctypes.c_int, _VP, _VP]),
     ("dpq_merge_topk_device", ctypes.c_int,
      [_VP, _VP, ctypes.c_int, ctypes.c_int, ctypes.c_int, _VP, _VP, ctypes.c_int, _VP]),

@@ -84,8 +84,19 @@ struct dpq_index {
     unsigned long long* d_counters = nullptr;  // [2] scan statistics (dpq_profile.exact_checks / candidates)
     uint64_t* d_scratch = nullptr;   // [slots][ws_cap] contiguous copy of a slot's keys when they exceed the select's LDS list
     uint32_t* h_overflow = nullptr;  // pinned
-    uint32_t* h_any = nullptr;       // pinned + mapped: set by select_kernel when any query overflowed
+    // pinned + mapped words, one per batch in flight: set by select_kernel when any query of the batch overflowed
+    static constexpr int kFlagSlots = 64;
+    uint32_t* h_any = nullptr;       // [kFlagSlots]; slot 0 serves the synchronous calls
     uint32_t* d_any = nullptr;       // device address of h_any
+    struct Pending {                 // a batch enqueued by dpq_query_batch_device_async and not yet finished
+        const float* d_queries;
+        int nq, top_k;
+        int32_t* d_ids;
+        float* d_dists;
+        hipStream_t stream;
+        int flag_slot;
+    };
+    std::vector<Pending> pending;
     // staging for the host-pointer entry point
     float* d_q_stage = nullptr;
     int32_t* d_ids_stage = nullptr;
@@ -152,7 +163,8 @@ int ensure_workspace(dpq_index* x, int slots, int cap) {
         DPQ_HIP(hipMemset(x->d_counters, 0, 16));
     }
     if (!x->h_any) {
-        DPQ_HIP(hipHostMalloc(reinterpret_cast<void**>(&x->h_any), sizeof(uint32_t), hipHostMallocMapped));
+        DPQ_HIP(hipHostMalloc(reinterpret_cast<void**>(&x->h_any), sizeof(uint32_t) * dpq_index::kFlagSlots,
+                              hipHostMallocMapped));
         DPQ_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&x->d_any), x->h_any, 0));
     }
     x->ws_slots = slots;
@@ -287,8 +299,10 @@ Regions regions_for(const dpq_index* x, int n_seg_pass, int n_groups, int top_k,
 }
 
 // One sub-batch (nq <= kMaxBatchQueries) end to end on `stream`.
+// flag_slot 0: synchronous (waits, checks the overflow word, reruns what overflowed); > 0: enqueue only,
+// dpq_finish looks at the word later.
 int run_batch(dpq_index* x, const float* d_queries, int nq, int top_k, int32_t* d_ids, float* d_dists,
-              hipStream_t stream) {
+              hipStream_t stream, int flag_slot = 0) {
     const int QG = dpq::queries_per_group(x->M);
     const int nqp = (nq + QG - 1) / QG * QG;
     const int ngroups = nqp / QG;
@@ -310,7 +324,7 @@ int run_batch(dpq_index* x, const float* d_queries, int nq, int top_k, int32_t* 
                                       nullptr, x->d_overflow, stream));
     }
     if (x->prof) x->prof_acc.lut_launches++;
-    *x->h_any = 0;  // no batch of this index is in flight here (run_batch ends synchronised)
+    x->h_any[flag_slot] = 0;  // the slot is free: its previous batch has been finished
 
     dpq::ScanArgs sa{};
     sa.img = x->img;
@@ -336,7 +350,7 @@ int run_batch(dpq_index* x, const float* d_queries, int nq, int top_k, int32_t* 
     se.top_k = top_k;
     se.thr_key = x->d_thr_key;
     se.overflow = x->d_overflow;
-    se.any_overflow = x->d_any;
+    se.any_overflow = x->d_any + flag_slot;
     se.out_ids = d_ids;
     se.out_dists = d_dists;
     se.n_codes_total = x->plain ? -1 : x->img.n_codes_total;
@@ -387,6 +401,7 @@ int run_batch(dpq_index* x, const float* d_queries, int nq, int top_k, int32_t* 
 
     // The only host synchronisation of the batch: did any query drop candidates
     // at some level (buffer overflow)?  Then its list may miss entries.
+    if (flag_slot > 0) return DPQ_OK;  // asynchronous batch: dpq_finish checks the word
     DPQ_HIP(hipStreamSynchronize(stream));
     if (*reinterpret_cast<volatile uint32_t*>(x->h_any) == 0) return DPQ_OK;
     std::vector<int> over;
@@ -974,6 +989,10 @@ int dpq_get_info(const dpq_index* x, dpq_info* info) {
 int dpq_close(dpq_index* x) {
     if (!x) return DPQ_OK;
     hipSetDevice(x->device);
+    if (!x->pending.empty()) {  // batches still in flight: let them drain before their buffers go
+        hipDeviceSynchronize();
+        x->pending.clear();
+    }
     for (auto& ep : x->events) {
         hipEventDestroy(ep.a);
         hipEventDestroy(ep.b);
@@ -1000,8 +1019,71 @@ int dpq_close(dpq_index* x) {
     return DPQ_OK;
 }
 
+namespace {
+
+int check_batch_args(dpq_index* x, const float* d_queries, int nq, int top_k, int32_t* d_ids, float* d_dists) {
+    if (!x || !d_queries || !d_ids || !d_dists || nq < 0) return fail(DPQ_ERR_ARG, "NULL argument or nq < 0");
+    if (!x->d_codebook) return fail(DPQ_ERR_STATE, "dpq_set_codebook has not been called");
+    if (top_k < 1 || top_k > dpq::kMaxTopK) return fail(DPQ_ERR_ARG, "top_k must be in 1..2048");
+    if ((int64_t)top_k > x->img.n_codes_total)
+        return fail(DPQ_ERR_TOPK, "top_k exceeds the number of codes in the index");
+    return DPQ_OK;
+}
+
+}  // namespace
+
+int dpq_finish(dpq_index* x) {
+    if (!x) return fail(DPQ_ERR_ARG, "NULL index");
+    if (x->pending.empty()) return DPQ_OK;
+    DPQ_HIP(hipSetDevice(x->device));
+    std::vector<dpq_index::Pending> todo;
+    todo.swap(x->pending);
+    hipStream_t last = nullptr;
+    bool first = true;
+    for (const auto& p : todo) {
+        if (first || p.stream != last) DPQ_HIP(hipStreamSynchronize(p.stream));
+        last = p.stream;
+        first = false;
+    }
+    for (const auto& p : todo) {
+        if (*reinterpret_cast<volatile uint32_t*>(x->h_any + p.flag_slot) == 0) continue;
+        // a query of this batch dropped candidates: answer the batch again, synchronously (it reruns what overflows)
+        int rc = run_batch(x, p.d_queries, p.nq, p.top_k, p.d_ids, p.d_dists, p.stream);
+        if (rc) return rc;
+    }
+    return DPQ_OK;
+}
+
+int dpq_query_batch_device_async(dpq_index* x, const float* d_queries, int nq, int top_k, int32_t* d_ids,
+                                 float* d_dists, void* hip_stream) {
+    int rc = check_batch_args(x, d_queries, nq, top_k, d_ids, d_dists);
+    if (rc || nq == 0) return rc;
+    DPQ_HIP(hipSetDevice(x->device));
+    hipStream_t stream = reinterpret_cast<hipStream_t>(hip_stream);
+    const int D = x->M * x->Ds;
+    for (int base = 0; base < nq; base += kMaxBatchQueries) {
+        const int n = std::min(kMaxBatchQueries, nq - base);
+        if ((int)x->pending.size() >= dpq_index::kFlagSlots - 1 && (rc = dpq_finish(x))) return rc;
+        const int slot = 1 + (int)x->pending.size();
+        rc = run_batch(x, d_queries + (size_t)base * D, n, top_k, d_ids + (size_t)base * top_k,
+                       d_dists + (size_t)base * top_k, stream, slot);
+        if (rc) return rc;
+        x->pending.push_back({d_queries + (size_t)base * D, n, top_k, d_ids + (size_t)base * top_k,
+                              d_dists + (size_t)base * top_k, stream, slot});
+    }
+    if (x->prof) {
+        x->prof_acc.query_batches++;
+        x->prof_acc.queries += nq;
+    }
+    return DPQ_OK;
+}
+
 int dpq_query_batch_device(dpq_index* x, const float* d_queries, int nq, int top_k, int32_t* d_ids, float* d_dists,
                            void* hip_stream) {
+    if (x && !x->pending.empty()) {  // keep the order of the batches on this index
+        int rc = dpq_finish(x);
+        if (rc) return rc;
+    }
     if (!x || !d_queries || !d_ids || !d_dists || nq < 0) return fail(DPQ_ERR_ARG, "NULL argument or nq < 0");
     if (!x->d_codebook) return fail(DPQ_ERR_STATE, "dpq_set_codebook has not been called");
     if (top_k < 1 || top_k > dpq::kMaxTopK) return fail(DPQ_ERR_ARG, "top_k must be in 1..2048");

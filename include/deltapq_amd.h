@@ -222,6 +222,16 @@ int dpq_query_batch(dpq_index* idx, const float* queries, int nq, int top_k, int
  * overflow check at the end of the batch. */
 int dpq_query_batch_device(dpq_index* idx, const float* d_queries, int nq, int top_k, int32_t* d_ids,
                            float* d_dists, void* hip_stream);
+/* Pipelined variant: enqueues the batch on `hip_stream` and returns at once, so consecutive batches run
+ * back to back on the GPU (the call above leaves it idle for the ~15 us between the end of a batch and the
+ * next enqueue).  Inputs and outputs must stay valid, and the outputs must not be read, until dpq_finish(idx):
+ * it waits for every enqueued batch and answers again, synchronously, any batch in which a query overflowed
+ * its candidate buffers.  All batches of one index go to the same stream (they share its workspace); up to
+ * 63 may be in flight, the 64th call finishes the earlier ones first.  The synchronous entry points finish
+ * pending batches before they start. */
+int dpq_query_batch_device_async(dpq_index* idx, const float* d_queries, int nq, int top_k, int32_t* d_ids,
+                                 float* d_dists, void* hip_stream);
+int dpq_finish(dpq_index* idx);
 /* Merge n_lists partial top-k lists per query (lists[l][nq][top_k]) into the
  * final top_k by (distance, id).  Host version for the single-process
  * multi-GPU CLI, device version for use after an RCCL all-gather. */

@@ -120,6 +120,32 @@ def test_profile_counts_filter_survivors_and_candidates(gpu, oracle, codebook):
     assert prof["exact_checks"] < 0.05 * prof["scan_node_query_pairs"]      # the filter does filter
 
 
+def test_pipelined_batches_match_synchronous_ones(gpu, oracle, codebook):
+    """dpq_query_batch_device_async + dpq_finish: several batches in flight on one index, with the
+    default buffers and with tiny ones (every batch overflows and is answered again at dpq_finish)."""
+    import torch
+    from deltapq_amd import synth
+    n, k = 60000, 50
+    tree, payload, _ = make_case(n, seed=51)
+    batches = [synth.make_queries(nq, 128, seed=60 + i) for i, nq in enumerate((40, 7, 130))]
+    for kw in ({}, {"cand_capacity": 64}):
+        with gpu.DeltaPQIndex.open_memory(payload, n, 8, 256, **kw) as idx:
+            idx.set_codebook(codebook)
+            idx.profile_enable(True)
+            qd = [torch.from_numpy(q).cuda() for q in batches]
+            outs = [idx.query_batch_torch(q, k, wait=False) for q in qd]
+            idx.finish()
+            reruns = idx.profile_read()["overflow_reruns"]
+            assert (reruns > 0) == bool(kw)
+            for q, (ids, dists) in zip(batches, outs):
+                assert_parity(ids.cpu().numpy(), dists.cpu().numpy(), oracle_topk(oracle, payload, n, codebook, q, k), n)
+            # a synchronous call after pending work, and an empty finish, are fine too
+            idx.query_batch_torch(qd[0], k, wait=False)
+            ids2, dists2 = idx.query_batch_torch(qd[1], k)
+            assert_parity(ids2.cpu().numpy(), dists2.cpu().numpy(), oracle_topk(oracle, payload, n, codebook, batches[1], k), n)
+            idx.finish()
+
+
 def test_large_batch_is_split_internally(gpu, oracle, codebook):
     from deltapq_amd import synth
     n = 3000
