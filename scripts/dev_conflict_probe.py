@@ -13,5 +13,5 @@ for md in (0.0, 0.5, 1.5, 3.0, 8.0):
     payload, nb = synth.encode_dtc(tree)
     with api.DeltaPQIndex.open_memory(payload, n, 8, 256) as idx:
         idx.set_codebook(cb); idx.query_batch(qs, 100)
-        ms = ctypes.c_float(); rc = lib.dpq_debug_scan_time(idx._h, nq, 0, 10, 8, ms); assert rc == 0
+        ms = ctypes.c_float(); rc = lib.dpq_debug_scan_time(idx._h, nq, 0, 10, 0, ms); assert rc == 0
         print("mean_diffs=%.1f: pure scan %.3f ms (%.2f B/code)" % (md, ms.value, nb / n), flush=True)
