@@ -110,7 +110,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--n", type=int, default=1_000_000, help="codes in the index")
+    ap.add_argument("--n", "--codes", dest="n", type=int, default=1_000_000,
+                    help="codes in the index (under torch.distributed.run use --codes: its parser takes --n for its own)")
     ap.add_argument("--queries", type=int, default=1000)
     ap.add_argument("--topk", type=int, default=100)
     ap.add_argument("--m", type=int, default=8)

@@ -354,6 +354,33 @@ def test_two_process_sharded_run_on_one_gpu(gpu, built):
     assert r.returncode == 0 and "DIST_GPU_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
 
 
+@pytest.mark.parametrize("shard", ["query", "index"])
+def test_bench_two_ranks_rehearsal(gpu, built, shard):
+    """bench.py's N > 1 paths end to end (2 ranks on GPU 0, gloo instead of RCCL): query replicas (weak
+    scaling, index-sharded run timed beside it) and index shards (all-gather + merge, strong scaling)."""
+    import json
+    import socket
+    import sys
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+           "--gpus", "2", "--backend", "gloo", "--shard", shard, "--data", "stream", "--codes", "200000",
+           "--queries", "100", "--steps", "3", "--warmup", "1", "--check", "2", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ, OMP_NUM_THREADS="1"), cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["parity_checked_queries"] == 2 and line["value"] > 0
+    assert line["roofline"]["frac"] > 0 and line["roofline"]["launches_per_step"] >= 1
+    if shard == "query":
+        assert line["scaling"] == "weak" and line["config"]["global_queries_per_step"] == 200
+        assert line["index_sharded"]["value"] > 0
+    else:
+        assert line["scaling"] == "strong" and "index_sharded" not in line
+
+
 M16_SHAPES = [(1, 3, 1), (2, 2, 2), (65, 5, 10), (1000, 20, 10), (10000, 50, 100), (100001, 40, 1000), (300000, 33, 100)]
 
 
