@@ -417,7 +417,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanArgs a) {
     // Computed as fma(T, s32, -off) in fp32: off >= min * s32 (rounded up), one rounding of the
     // result, and s32 carries a (1 - 2^-20) factor, so every entry is <= the exact real value.
     float* q_scale = reinterpret_cast<float*>(smem + ScanLds<M>::kQCode);  // [QG]  (the refine queues are idle until the scan loop)
-    float* q_off = q_scale + QG;                                      // [M][QG]   min_m * scale, rounded UP
+    float* q_off = q_scale + QG;                                      // [M][QG]   min_m * scale, rounded UP (EB = 8: the whole additive term)
     uint32_t* q_bias = reinterpret_cast<uint32_t*>(q_off + M * QG);   // [QG]      added to the m = 0 entries
     if (tid < 256) dtab[tid] = make_decode_entry((uint32_t)tid);
     if (tid < QG) {
@@ -454,6 +454,14 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanArgs a) {
             const double od = (double)mn[m] * (double)s32;
             float of = (float)od;
             if ((double)of < od) of = __uint_as_float(__float_as_uint(of) + 1u);  // od >= 0: next float up
+            if constexpr (EB == 8) {
+                // the table builder adds this to T * s32 and converts with v_cvt_pk_u8_f32: bias (m = 0) and
+                // half a unit of slack against the conversion's rounding folded in, rounded DOWN
+                const double sd = (m == 0 ? (double)bias : 0.0) - 0.5 - (double)of;
+                float sf = (float)sd;
+                if ((double)sf > sd) sf = __uint_as_float(__float_as_uint(sf) + (sf > 0.0f ? -1 : 1));  // next float down
+                of = sf;
+            }
             q_off[m * QG + tid] = of;
         }
         s_base[tid] = qq >= 0 ? qq * TE : -1;
@@ -481,14 +489,26 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanArgs a) {
             float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
             if (base >= 0) t = *reinterpret_cast<const float4*>(a.lut32 + (size_t)base + mk);
             const float tv[4] = {t.x, t.y, t.z, t.w};
+            if constexpr (EB == 8) {
+                // v_cvt_pk_u8_f32: float -> u8 clamped to [0, 255], written into byte f of the dword.  Half a
+                // unit is taken off first, so whichever way the conversion rounds, the byte is <= floor(value):
+                // the entry stays a lower bound (negative -> 0; inf/NaN of centroids beyond K -> SAT by the min).
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const float fv = __fmaf_rn(tv[k], sc, -of);
-                // fv < 0 only by the round-up of `of` (true value 0); NaN/inf (k >= K) saturate
-                uint32_t v = fv < (float)C::SAT ? (fv > 0.0f ? (uint32_t)fv : 0u) : (uint32_t)C::SAT;
-                v += bias;
-                if (base < 0) v = m == 0 ? (uint32_t)C::FIELD_MAX : 0u;  // unused slot: top bit always set
-                out[k] |= v << (EB * f);
+                for (int k = 0; k < 4; ++k) {
+                    const float fv = fminf(__fmaf_rn(tv[k], sc, of), (float)C::SAT + (float)bias);  // `of` holds the shift here
+                    out[k] = base < 0 ? out[k] | ((m == 0 ? (uint32_t)C::FIELD_MAX : 0u) << (EB * f))  // unused slot: top bit always set
+                                      : __builtin_amdgcn_cvt_pk_u8_f32(fv, (uint32_t)f, out[k]);
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float fv = __fmaf_rn(tv[k], sc, -of);
+                    // fv < 0 only by the round-up of `of` (true value 0); NaN/inf (k >= K) saturate
+                    uint32_t v = fv < (float)C::SAT ? (fv > 0.0f ? (uint32_t)fv : 0u) : (uint32_t)C::SAT;
+                    v += bias;
+                    if (base < 0) v = m == 0 ? (uint32_t)C::FIELD_MAX : 0u;  // unused slot: top bit always set
+                    out[k] |= v << (EB * f);
+                }
             }
         }
 #pragma unroll
