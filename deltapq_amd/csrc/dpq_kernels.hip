@@ -841,14 +841,27 @@ __global__ __launch_bounds__(THREADS) void select_kernel(const SelectArgs a) {
         const float4* src = reinterpret_cast<const float4*>(a.lut32 + (size_t)q * TE);
         for (int i = tid; i < TE / 4; i += THREADS) reinterpret_cast<float4*>(T)[i] = src[i];
         __syncthreads();
-        for (int i = tid; i < n; i += THREADS) {
-            const uint32_t id = a.shared_id[i];
-            uint64_t key = ~0ull;
-            if (id != 0xffffffffu)
-                key = make_key(exact_dist<M>(T, a.shared_code + (size_t)W * i, a.fp32_accum != 0), id);
-            else
-                atomicAdd(&counters[1], 1u);  // padding node
-            keys[i] = key;
+        // four nodes per thread and pass: their ids and codes are fetched before any is evaluated
+        for (int i0 = tid; i0 < n; i0 += 4 * THREADS) {
+            uint32_t id[4], c[4][W];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = min(i0 + u * THREADS, n - 1);
+                id[u] = a.shared_id[i];
+#pragma unroll
+                for (int w = 0; w < W; ++w) c[u][w] = a.shared_code[(size_t)W * i + w];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u * THREADS;
+                if (i >= n) break;
+                uint64_t key = ~0ull;
+                if (id[u] != 0xffffffffu)
+                    key = make_key(exact_dist<M>(T, c[u], a.fp32_accum != 0), id[u]);
+                else
+                    atomicAdd(&counters[1], 1u);  // padding node
+                keys[i] = key;
+            }
         }
     } else {
         // later levels: the scan already evaluated its survivors exactly.  Gather the regions of the
