@@ -23,6 +23,18 @@ def shard_ranges(payload, n_codes, world, M=8, chunks_per_segment=0):
     return out
 
 
+def pack_lists(ids, dists):
+    """[nq][k] int32 ids + [nq][k] float32 distances -> one [nq][2k] int32 tensor (distance bits as they are)."""
+    import torch
+    return torch.cat((ids.contiguous(), dists.contiguous().view(torch.int32)), dim=1).contiguous()
+
+
+def unpack_lists(gathered, k):
+    """[world][nq][2k] int32 -> ([world][nq][k] int32 ids, [world][nq][k] float32 distances)."""
+    import torch
+    return gathered[:, :, :k].contiguous(), gathered[:, :, k:].contiguous().view(torch.float32)
+
+
 def gather_and_merge(ids, dists, group=None):
     """All-gather the per-shard partial top-k lists and merge them.
 
@@ -37,12 +49,12 @@ def gather_and_merge(ids, dists, group=None):
     if world == 1:
         return ids, dists
     nq, k = ids.shape
-    g_ids = torch.empty((world, nq, k), dtype=ids.dtype, device=ids.device)
-    g_dists = torch.empty((world, nq, k), dtype=dists.dtype, device=dists.device)
     if ids.is_cuda and dist.get_backend(group) != "gloo":
-        dist.all_gather_into_tensor(g_ids, ids.contiguous(), group=group)
-        dist.all_gather_into_tensor(g_dists, dists.contiguous(), group=group)
-        return api.merge_topk_torch(g_ids, g_dists)
+        # ONE collective: ids and distance bits travel together as [nq][2k] int32 (the exchange is
+        # latency-bound: nq * k * 8 B per rank)
+        gathered = torch.empty((world, nq, 2 * k), dtype=torch.int32, device=ids.device)
+        dist.all_gather_into_tensor(gathered, pack_lists(ids, dists), group=group)
+        return api.merge_topk_torch(*unpack_lists(gathered, k))
     if ids.is_cuda:
         # rehearsal mode (gloo with device tensors, e.g. several ranks sharing one GPU):
         # exchange through host memory, merge on the device as the RCCL path does
@@ -51,6 +63,8 @@ def gather_and_merge(ids, dists, group=None):
         dist.all_gather(list(h_ids.unbind(0)), ids.cpu().contiguous(), group=group)
         dist.all_gather(list(h_dists.unbind(0)), dists.cpu().contiguous(), group=group)
         return api.merge_topk_torch(h_ids.to(ids.device), h_dists.to(dists.device))
+    g_ids = torch.empty((world, nq, k), dtype=ids.dtype)
+    g_dists = torch.empty((world, nq, k), dtype=dists.dtype)
     dist.all_gather(list(g_ids.unbind(0)), ids.contiguous(), group=group)
     dist.all_gather(list(g_dists.unbind(0)), dists.contiguous(), group=group)
     mi, md = api.merge_topk_host(g_ids.numpy(), g_dists.numpy())
