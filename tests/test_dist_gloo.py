@@ -29,6 +29,7 @@ def test_sharded_gather_and_merge(built, world, n, k):
 
 def test_packed_exchange_round_trip():
     """The RCCL path sends ids and distance bits in one tensor: packing must be lossless (inf, -1 padding)."""
+    import numpy as np
     import torch
     from deltapq_amd import dist as dpq_dist
     rng = np.random.default_rng(3)
