@@ -166,9 +166,8 @@ def main():
     shard_mode = args.shard
     if shard_mode == "auto":
         shard_mode = "query" if (5 * args.n) < (64 << 30) else "index"
-    if world == 1:
-        shard_mode = "index"   # one shard == the whole index
-    by_query = shard_mode == "query"
+    weak = shard_mode == "query"   # the label the N > 1 runs of this mode carry; at N = 1 both modes are the same run
+    by_query = weak and world > 1
     wl = build_workload(args, local_rank, query_seed=101 + (rank if by_query else 0))
     idx = api.DeltaPQIndex.open_memory(wl["payload"], args.n, args.m, 256, device=local_rank,
                                        shard_rank=0 if by_query else rank, shard_count=1 if by_query else world,
@@ -301,7 +300,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / steps,
             "higher_is_better": True,
-            "scaling": "weak" if by_query else "strong",
+            "scaling": "weak" if weak else "strong",
             "vs_baseline": None,
             "dtype": "f64-sum-of-f32 (u8 code decode)",
             "data": "synthetic",
@@ -311,7 +310,7 @@ def main():
                                                               (wl["n_bytes"] - args.m) / args.n - (1.5 if args.m <= 8 else 2.5)),
                 "n_codes": args.n, "queries_per_step": nq, "topk": k, "n_bytes": int(wl["n_bytes"]),
                 "sharding": ("query replicas x%d: every GPU holds the whole index and answers its own %d-query batch"
-                             % (world, nq)) if by_query else "dfs-range index shards x%d, one batch" % world,
+                             % (world, nq)) if weak else "dfs-range index shards x%d, one batch" % world,
                 "global_queries_per_step": (world if by_query else 1) * nq,
                 "queries_per_decode_pass": 64 if args.m <= 8 else 16,
             },
