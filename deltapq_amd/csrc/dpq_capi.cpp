@@ -967,6 +967,7 @@ int dpq_open_plain_file(const char* path, int M, int K, const dpq_open_opts* opt
 
 int dpq_set_codebook(dpq_index* x, const float* codewords, int Ds) {
     if (!x || !codewords || Ds < 1 || Ds > 4096) return fail(DPQ_ERR_ARG, "bad codebook argument");
+    if (int rc = dpq_finish(x)) return rc;  // batches in flight still read the old codebook
     DPQ_HIP(hipSetDevice(x->device));
     hipFree(x->d_codebook);
     x->d_codebook = nullptr;
