@@ -291,8 +291,10 @@ Regions regions_for(const dpq_index* x, int n_seg_pass, int n_groups, int top_k,
     r.splits = splits_for(n_seg_pass, n_groups);
     r.region_cap = (cap - top_k) / r.splits;
     // automatic sizing: a query's candidates cluster in few segments (DFS neighbours are similar codes), so a
-    // region must absorb a few dense segments; 16 K keys per slot, at least one segment's worth per region
-    if (x->cap_auto) r.region_cap = std::max(r.region_cap, std::max(256, 16384 / r.splits));
+    // region must absorb a few dense segments; 16 K keys per slot, at least one segment's worth per region,
+    // and four times a level's expected candidates (top_k x 16) spread over the regions
+    if (x->cap_auto)
+        r.region_cap = std::max(r.region_cap, std::max(std::max(256, 16384 / r.splits), 64 * top_k / r.splits));
     r.region_cap = std::max(r.region_cap, 1);
     r.stride = (int64_t)top_k + (int64_t)r.splits * r.region_cap;
     return r;
