@@ -198,7 +198,7 @@ int ensure_plan(dpq_index* x, int top_k, int cap, int coarse) {
         // A level costs a fixed ~45 us (scan prologue, launch, select) plus ~top_k * (ratio - 1) candidates per
         // query to check and select: the best ratio falls with top_k (measured: 8 at top-100, 3 at top-1000).
         const int r = (int)std::lround(std::min(16.0, std::max(2.0, 8.0 * std::sqrt(100.0 / (double)top_k))));
-        int fine[] = {std::max(2, r / 2), r, r};
+        int fine[] = {r >= 16 ? r : std::max(2, r / 2), r, r};  // few candidates (small top_k): the fewest levels win
         if (const char* ev = getenv("DPQ_PLAN_RATIOS")) sscanf(ev, "%d,%d,%d", &fine[0], &fine[1], &fine[2]);
         for (int& f : fine) f = std::max(2, f);
         // expected survivors of a level = top_k * (ratio - 1) must stay well inside the candidate buffer
