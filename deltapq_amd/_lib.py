@@ -15,7 +15,7 @@ P = ctypes.POINTER
 
 class OpenOpts(ctypes.Structure):
     _fields_ = [("device", c_i32), ("shard_rank", c_i32), ("shard_count", c_i32), ("chunks_per_segment", c_i32),
-                ("cand_capacity", c_i32), ("reserved", c_i32 * 3)]
+                ("cand_capacity", c_i32), ("num_codes", c_i32), ("reserved", c_i32 * 2)]
 
 
 class Info(ctypes.Structure):
@@ -32,7 +32,8 @@ class Profile(ctypes.Structure):
     _fields_ = [("lut_ms", ctypes.c_double), ("scan_ms", ctypes.c_double), ("select_ms", ctypes.c_double),
                 ("lut_launches", c_i64), ("scan_launches", c_i64), ("select_launches", c_i64),
                 ("scan_node_query_pairs", c_i64), ("scan_stream_bytes", c_i64), ("query_batches", c_i64),
-                ("queries", c_i64), ("overflow_reruns", c_i64), ("exact_checks", c_i64), ("candidates", c_i64)]
+                ("queries", c_i64), ("overflow_reruns", c_i64), ("exact_checks", c_i64), ("candidates", c_i64),
+                ("quantise_ms", ctypes.c_double)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

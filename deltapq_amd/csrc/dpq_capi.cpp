@@ -11,6 +11,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <new>
+#include <stdexcept>
 #include <string>
 #include <type_traits>
 #include <vector>
@@ -27,6 +29,23 @@ thread_local std::string g_last_error;
 int fail(int code, const std::string& msg) {
     g_last_error = msg;
     return code;
+}
+
+// No C++ exception may cross the C ABI (a corrupt header can ask for a multi-GB vector): every
+// extern "C" entry point runs its body through guarded().
+template <class F>
+int guarded(F&& body) noexcept {
+    try {
+        return body();
+    } catch (const std::bad_alloc&) {
+        return fail(DPQ_ERR_NOMEM, "out of host memory");
+    } catch (const std::length_error& e) {
+        return fail(DPQ_ERR_NOMEM, std::string("allocation size out of range: ") + e.what());
+    } catch (const std::exception& e) {
+        return fail(DPQ_ERR_STATE, std::string("internal error: ") + e.what());
+    } catch (...) {
+        return fail(DPQ_ERR_STATE, "internal error: unknown exception");
+    }
 }
 
 #define DPQ_HIP(expr)                                                                              \
@@ -47,7 +66,7 @@ int dev_alloc(T** p, size_t count) {
 }
 
 struct EventPair {
-    int kind;  // 0 lut, 1 scan, 2 select
+    int kind;  // 0 lut, 1 scan, 2 select, 3 quantise
     hipEvent_t a, b;
 };
 
@@ -78,7 +97,8 @@ struct dpq_index {
     // workspace, sized for ws_slots padded queries and ws_cap candidates each
     int ws_slots = 0, ws_cap = 0;
     float* d_lut32 = nullptr;       // exact tables [query][8][256]
-    float* d_lut_min = nullptr;     // [query][8] minima (filter quantisation in the scan prologue)
+    float* d_lut_min = nullptr;     // [query][8] minima (anchor of the filter quantisation)
+    uint4* d_qtab = nullptr;        // [slot groups][128 KB] filter tables of the cascade level being scanned
     uint32_t *d_cand_count = nullptr, *d_overflow = nullptr;
     uint64_t *d_cand_key = nullptr, *d_thr_key = nullptr;  // candidate keys [slots][ws_cap], threshold keys [slots]
     unsigned long long* d_counters = nullptr;  // [2] scan statistics (dpq_profile.exact_checks / candidates)
@@ -120,11 +140,15 @@ struct dpq_index {
             ev_pool.pop_back();
             return e;
         }
-        hipEvent_t e;
+        hipEvent_t e = nullptr;
         // timing events between kernels of one stream: no system-scope fence needed (saves ~2 us per record)
-        hipEventCreateWithFlags(&e, hipEventDisableSystemFence);
+        if (hipEventCreateWithFlags(&e, hipEventDisableSystemFence) != hipSuccess) {
+            prof_failed = true;
+            return nullptr;
+        }
         return e;
     }
+    bool prof_failed = false;        // an event could not be created / recorded: dpq_profile_read reports it
 };
 
 namespace {
@@ -132,6 +156,7 @@ namespace {
 void free_workspace(dpq_index* x) {
     hipFree(x->d_lut32);
     hipFree(x->d_lut_min);
+    hipFree(x->d_qtab);
     hipFree(x->d_cand_count);
     hipFree(x->d_cand_key);
     hipFree(x->d_scratch);
@@ -139,6 +164,7 @@ void free_workspace(dpq_index* x) {
     hipFree(x->d_thr_key);
     x->d_lut32 = nullptr;
     x->d_lut_min = nullptr;
+    x->d_qtab = nullptr;
     x->d_cand_count = x->d_overflow = nullptr;
     x->d_cand_key = x->d_thr_key = x->d_scratch = nullptr;
     x->ws_slots = x->ws_cap = 0;
@@ -152,6 +178,9 @@ int ensure_workspace(dpq_index* x, int slots, int cap) {
     int rc;
     if ((rc = dev_alloc(&x->d_lut32, (size_t)slots * x->M * 256))) return rc;
     if ((rc = dev_alloc(&x->d_lut_min, (size_t)slots * x->M))) return rc;
+    if ((rc = dev_alloc(&x->d_qtab, (size_t)(slots / dpq::queries_per_group(x->M) + 1) *
+                                        (dpq::qtab_bytes_per_group(x->M) / sizeof(uint4)))))
+        return rc;
     if ((rc = dev_alloc(&x->d_cand_count, (size_t)slots * dpq::kRegionStride))) return rc;
     if ((rc = dev_alloc(&x->d_cand_key, (size_t)slots * cap))) return rc;
     if ((rc = dev_alloc(&x->d_scratch, (size_t)slots * cap))) return rc;
@@ -261,12 +290,17 @@ struct Timer {
             ep.kind = kind;
             ep.a = x->get_event();
             ep.b = x->get_event();
-            hipEventRecord(ep.a, s);
+            if (!ep.a || !ep.b || hipEventRecord(ep.a, s) != hipSuccess) {
+                x->prof_failed = true;
+                if (ep.a) x->ev_pool.push_back(ep.a);
+                if (ep.b) x->ev_pool.push_back(ep.b);
+                on = false;
+            }
         }
     }
     ~Timer() {
         if (on) {
-            hipEventRecord(ep.b, s);
+            if (hipEventRecord(ep.b, s) != hipSuccess) x->prof_failed = true;
             x->events.push_back(ep);
         }
     }
@@ -343,6 +377,7 @@ int run_batch(dpq_index* x, const float* d_queries, int nq, int top_k, int32_t* 
     sa.cand_stride = stride;
     sa.region_off = top_k;
     sa.counters = x->prof && !x->prof_scan_only ? x->d_counters : nullptr;
+    sa.qtab = x->d_qtab;
 
     dpq::SelectArgs se{};
     se.cand_count = x->d_cand_count;
@@ -385,6 +420,10 @@ int run_batch(dpq_index* x, const float* d_queries, int nq, int top_k, int32_t* 
             const Regions rg = regions_for(x, sa.n_seg_pass, ngroups, top_k, cap);
             sa.region_cap = se.region_cap = rg.region_cap;
             se.n_regions = 1 + rg.splits;
+            {
+                Timer t(x, stream, 3);
+                DPQ_HIP(dpq::launch_quantise(sa, ngroups, stream));
+            }
             {
                 Timer t(x, stream, 1);
                 DPQ_HIP(dpq::launch_scan(sa, ngroups, rg.splits, stream));
@@ -441,8 +480,10 @@ int run_batch(dpq_index* x, const float* d_queries, int nq, int top_k, int32_t* 
         int32_t* d_slot_query = nullptr;
         uint32_t *c_count = nullptr, *c_over = nullptr;
         uint64_t *c_keys = nullptr, *c_scratch = nullptr, *c_tk = nullptr;
+        uint4* c_qtab = nullptr;
         auto cleanup = [&]() {
             hipFree(d_slot_query); hipFree(c_count); hipFree(c_over); hipFree(c_keys); hipFree(c_scratch); hipFree(c_tk);
+            hipFree(c_qtab);
         };
         rc = stride2 > INT32_MAX ? fail(DPQ_ERR_NOMEM, "candidate buffer too large") : DPQ_OK;
         if (!rc) rc = dev_alloc(&d_slot_query, (size_t)slots2);
@@ -451,6 +492,7 @@ int run_batch(dpq_index* x, const float* d_queries, int nq, int top_k, int32_t* 
         if (!rc) rc = dev_alloc(&c_keys, (size_t)slots2 * stride2);
         if (!rc) rc = dev_alloc(&c_scratch, (size_t)slots2 * stride2);
         if (!rc) rc = dev_alloc(&c_tk, (size_t)slots2);
+        if (!rc) rc = dev_alloc(&c_qtab, (size_t)ng2 * (dpq::qtab_bytes_per_group(x->M) / sizeof(uint4)));
         if (rc) {
             cleanup();
             return rc;
@@ -470,6 +512,8 @@ int run_batch(dpq_index* x, const float* d_queries, int nq, int top_k, int32_t* 
         sa.cand_key = c_keys;
         sa.cand_stride = stride2;
         sa.region_cap = (int32_t)rcap2;
+        sa.qtab = c_qtab;
+        chk(dpq::launch_quantise(sa, ng2, stream));
         chk(dpq::launch_scan(sa, ng2, splits2, stream));
         std::vector<uint32_t> h_cnt((size_t)slots2 * dpq::kRegionStride, 0);
         chk(hipMemcpyAsync(h_cnt.data(), c_count, sizeof(uint32_t) * h_cnt.size(), hipMemcpyDeviceToHost, stream));
@@ -525,7 +569,7 @@ int open_from_payload(const uint8_t* payload, int64_t n_bytes, int64_t n_codes, 
     dpq::SoA soa;
     std::string err;
     int rc = dpq::transcode(payload, n_bytes, n_codes, M, o.shard_rank, o.shard_count, o.chunks_per_segment, &soa,
-                            &err);
+                            &err, o.num_codes);
     if (rc) return fail(rc, err);
 
     DPQ_HIP(hipSetDevice(o.device));
@@ -603,6 +647,8 @@ int open_plain(const uint8_t* codes, int64_t n_codes, int M, int K, const dpq_op
     if (cps > dpq::kSortMax / dpq::kChunk) return fail(DPQ_ERR_ARG, "chunks_per_segment must be <= 64");
     int count = o.shard_count <= 0 ? 1 : o.shard_count;
     if (o.shard_rank < 0 || o.shard_rank >= count) return fail(DPQ_ERR_ARG, "bad shard_rank / shard_count");
+    if (o.num_codes < 0 || (int64_t)o.num_codes > n_codes) return fail(DPQ_ERR_ARG, "num_codes outside 0..n_codes");
+    if (o.num_codes > 0) n_codes = o.num_codes;  // scan only the first num_codes codes (h:2625-2629)
     const int64_t S = (int64_t)dpq::kChunk * cps;
     const int64_t nseg_total = (n_codes + S - 1) / S;
     const int64_t seg_lo = nseg_total * o.shard_rank / count, seg_hi = nseg_total * (o.shard_rank + 1) / count;
@@ -698,13 +744,16 @@ int dpq_device_count(void) {
 }
 
 int dpq_read_dtc_header(const char* path, int64_t* n_codes, int64_t* n_bytes) {
+    return guarded([&]() -> int {
     if (!path || !n_codes || !n_bytes) return fail(DPQ_ERR_ARG, "NULL argument");
     std::string err;
     int rc = dpq::read_dtc_header(path, n_codes, n_bytes, &err);
     return rc ? fail(rc, err) : DPQ_OK;
+    });
 }
 
 int dpq_read_codewords(const char* path, int32_t* M, int32_t* K, int32_t* Ds, float* out) {
+    return guarded([&]() -> int {
     if (!path || !M || !K || !Ds) return fail(DPQ_ERR_ARG, "NULL argument");
     std::string err;
     std::vector<float> v;
@@ -716,9 +765,11 @@ int dpq_read_codewords(const char* path, int32_t* M, int32_t* K, int32_t* Ds, fl
     *Ds = ds;
     if (out) memcpy(out, v.data(), v.size() * sizeof(float));
     return DPQ_OK;
+    });
 }
 
 int dpq_read_vecs(const char* path, int is_bvecs, int64_t* n, int32_t* D, float* out, int64_t cap) {
+    return guarded([&]() -> int {
     if (!path || !n || !D) return fail(DPQ_ERR_ARG, "NULL argument");
     std::string err;
     std::vector<float> v;
@@ -728,31 +779,37 @@ int dpq_read_vecs(const char* path, int is_bvecs, int64_t* n, int32_t* D, float*
     *D = d;
     if (out) memcpy(out, v.data(), v.size() * sizeof(float));
     return DPQ_OK;
+    });
 }
 
 int dpq_dtc_file_name(const char* dataset_dir, int M, int K, int64_t N, char* out, int64_t out_len) {
+    return guarded([&]() -> int {
     if (!dataset_dir || !out) return fail(DPQ_ERR_ARG, "NULL argument");
     std::string s = dpq::dtc_file_name(dataset_dir, M, K, N);
     if ((int64_t)s.size() + 1 > out_len) return fail(DPQ_ERR_ARG, "output buffer too small");
     memcpy(out, s.c_str(), s.size() + 1);
     return DPQ_OK;
+    });
 }
 
 int dpq_dtc_validate(const uint8_t* payload, int64_t n_bytes, int64_t n_codes, int M, dpq_dtc_stats* stats) {
+    return guarded([&]() -> int {
     std::string err;
     int rc = dpq::validate(payload, n_bytes, n_codes, M, stats, &err);
     return rc ? fail(rc, err) : DPQ_OK;
+    });
 }
 
 int dpq_soa_build(const uint8_t* payload, int64_t n_bytes, int64_t n_codes, int M, const dpq_open_opts* opts,
                   dpq_soa** out) {
+    return guarded([&]() -> int {
     if (!out) return fail(DPQ_ERR_ARG, "out is NULL");
     dpq_open_opts o{};
     if (opts) o = *opts;
     dpq_soa* s = new dpq_soa();
     std::string err;
     int rc = dpq::transcode(payload, n_bytes, n_codes, M, o.shard_rank, o.shard_count, o.chunks_per_segment, &s->soa,
-                            &err);
+                            &err, o.num_codes);
     if (rc) {
         delete s;
         *out = nullptr;
@@ -760,15 +817,19 @@ int dpq_soa_build(const uint8_t* payload, int64_t n_bytes, int64_t n_codes, int 
     }
     *out = s;
     return DPQ_OK;
+    });
 }
 
 int dpq_soa_info(const dpq_soa* soa, dpq_info* info) {
+    return guarded([&]() -> int {
     if (!soa || !info) return fail(DPQ_ERR_ARG, "NULL argument");
     fill_info_from_soa(soa->soa, info);
     return DPQ_OK;
+    });
 }
 
 int dpq_soa_array(const dpq_soa* soa, int which, const void** ptr, int64_t* n_bytes) {
+    return guarded([&]() -> int {
     if (!soa || !ptr || !n_bytes) return fail(DPQ_ERR_ARG, "NULL argument");
     const dpq::SoA& s = soa->soa;
     switch (which) {
@@ -780,19 +841,23 @@ int dpq_soa_array(const dpq_soa* soa, int which, const void** ptr, int64_t* n_by
         default: return fail(DPQ_ERR_ARG, "which must be 0..4");
     }
     return DPQ_OK;
+    });
 }
 
 void dpq_soa_free(dpq_soa* soa) { delete soa; }
 
 int dpq_dtc_encode(const uint8_t* root_code, const uint8_t* depths, const uint16_t* masks, const uint8_t* deltas,
                    int64_t n_codes, int M, uint8_t* out, int64_t* n_bytes) {
+    return guarded([&]() -> int {
     std::string err;
     int rc = dpq::encode(root_code, depths, masks, deltas, n_codes, M, out, n_bytes, &err);
     return rc ? fail(rc, err) : DPQ_OK;
+    });
 }
 
 int dpq_tree_build(const uint8_t* codes, int64_t n_codes, int M, int K, int max_height_folds, const float* codewords,
                    int Ds, dpq_tree** out) {
+    return guarded([&]() -> int {
     if (!out) return fail(DPQ_ERR_ARG, "out is NULL");
     *out = nullptr;
     dpq_tree* t = new dpq_tree();
@@ -804,10 +869,12 @@ int dpq_tree_build(const uint8_t* codes, int64_t n_codes, int M, int K, int max_
     }
     *out = t;
     return DPQ_OK;
+    });
 }
 
 int dpq_tree_build_gpu(const uint8_t* codes, int64_t n_codes, int M, int K, int max_height_folds,
                        const float* codewords, int Ds, int device, dpq_tree** out) {
+    return guarded([&]() -> int {
     if (!out) return fail(DPQ_ERR_ARG, "out is NULL");
     *out = nullptr;
     if (!codes || n_codes < 1 || n_codes >= (int64_t)INT32_MAX || M < 1 || M > 16 || K < 1 || K > 256 ||
@@ -826,9 +893,11 @@ int dpq_tree_build_gpu(const uint8_t* codes, int64_t n_codes, int M, int K, int 
     }
     *out = t;
     return DPQ_OK;
+    });
 }
 
 int dpq_tree_stats(const dpq_tree* t, dpq_dtc_stats* stats) {
+    return guarded([&]() -> int {
     if (!t || !stats) return fail(DPQ_ERR_ARG, "NULL argument");
     const dpq::Tree& tr = t->tree;
     memset(stats, 0, sizeof *stats);
@@ -839,9 +908,11 @@ int dpq_tree_stats(const dpq_tree* t, dpq_dtc_stats* stats) {
     stats->max_depth = tr.max_depth;
     stats->M = tr.M;
     return DPQ_OK;
+    });
 }
 
 int dpq_tree_array(const dpq_tree* t, int which, const void** ptr, int64_t* n_bytes) {
+    return guarded([&]() -> int {
     if (!t || !ptr || !n_bytes) return fail(DPQ_ERR_ARG, "NULL argument");
     const dpq::Tree& tr = t->tree;
     switch (which) {
@@ -855,27 +926,33 @@ int dpq_tree_array(const dpq_tree* t, int which, const void** ptr, int64_t* n_by
         default: return fail(DPQ_ERR_ARG, "which must be 0..6");
     }
     return DPQ_OK;
+    });
 }
 
 int dpq_tree_encode(const dpq_tree* t, uint8_t* out, int64_t* n_bytes) {
+    return guarded([&]() -> int {
     if (!t || !n_bytes) return fail(DPQ_ERR_ARG, "NULL argument");
     const dpq::Tree& tr = t->tree;
     std::string err;
     int rc = dpq::encode(tr.root_code.data(), tr.depth.data(), tr.mask.data(), tr.deltas.data(), tr.n, tr.M, out,
                          n_bytes, &err);
     return rc ? fail(rc, err) : DPQ_OK;
+    });
 }
 
 int dpq_tree_write_files(const dpq_tree* t, const char* dataset_dir) {
+    return guarded([&]() -> int {
     if (!t || !dataset_dir) return fail(DPQ_ERR_ARG, "NULL argument");
     std::string err;
     int rc = dpq::tree_write_files(t->tree, dataset_dir, &err);
     return rc ? fail(rc, err) : DPQ_OK;
+    });
 }
 
 void dpq_tree_free(dpq_tree* t) { delete t; }
 
 int dpq_read_qnode_ids(const char* path, int64_t n_codes, uint32_t* vec_ids) {
+    return guarded([&]() -> int {
     if (!path || !vec_ids || n_codes < 0) return fail(DPQ_ERR_ARG, "bad argument");
     std::vector<uint32_t> ids;
     std::string err;
@@ -883,9 +960,11 @@ int dpq_read_qnode_ids(const char* path, int64_t n_codes, uint32_t* vec_ids) {
     if (rc) return fail(rc, err);
     memcpy(vec_ids, ids.data(), ids.size() * 4);
     return DPQ_OK;
+    });
 }
 
 int dpq_read_codes_plain(const char* path, int M, int64_t* n_codes, uint8_t* out) {
+    return guarded([&]() -> int {
     if (!path || !n_codes || M < 1) return fail(DPQ_ERR_ARG, "bad argument");
     std::vector<uint8_t> codes;
     std::string err;
@@ -893,17 +972,21 @@ int dpq_read_codes_plain(const char* path, int M, int64_t* n_codes, uint8_t* out
     if (rc) return fail(rc, err);
     if (out) memcpy(out, codes.data(), codes.size());
     return DPQ_OK;
+    });
 }
 
 int dpq_write_codes_plain(const char* path, const uint8_t* codes, int64_t n_codes, int M) {
+    return guarded([&]() -> int {
     if (!path || (!codes && n_codes > 0) || n_codes < 0 || M < 1) return fail(DPQ_ERR_ARG, "bad argument");
     std::string err;
     int rc = dpq::write_codes_plain(path, codes, n_codes, M, &err);
     return rc ? fail(rc, err) : DPQ_OK;
+    });
 }
 
 int dpq_encode_pq(const float* vectors, int64_t n, int D, const float* codewords, int M, int K, int Ds, int device,
                   uint8_t* codes_out) {
+    return guarded([&]() -> int {
     if (!vectors || !codewords || !codes_out || n < 0 || D < 1 || M < 1 || K < 1 || K > 256 || Ds < 1)
         return fail(DPQ_ERR_ARG, "bad argument to dpq_encode_pq");
     int ndev = 0;
@@ -934,9 +1017,11 @@ int dpq_encode_pq(const float* vectors, int64_t n, int D, const float* codewords
     if (rc) return rc;
     if (e != hipSuccess) return fail(DPQ_ERR_HIP, std::string("dpq_encode_pq: ") + hipGetErrorString(e));
     return DPQ_OK;
+    });
 }
 
 int dpq_open_file(const char* path, int M, int K, const dpq_open_opts* opts, dpq_index** out) {
+    return guarded([&]() -> int {
     if (!path || !out) return fail(DPQ_ERR_ARG, "NULL argument");
     std::vector<uint8_t> buf;
     std::string err;
@@ -948,19 +1033,25 @@ int dpq_open_file(const char* path, int M, int K, const dpq_open_opts* opts, dpq
     if (h[1] < 0 || (uint64_t)h[1] > buf.size() - 16)
         return fail(DPQ_ERR_FORMAT, "n_bytes in the header exceeds the file size");
     return open_from_payload(buf.data() + 16, h[1], h[0], M, K, opts, out);
+    });
 }
 
 int dpq_open_memory(const uint8_t* payload, int64_t n_bytes, int64_t n_codes, int M, int K,
                     const dpq_open_opts* opts, dpq_index** out) {
+    return guarded([&]() -> int {
     return open_from_payload(payload, n_bytes, n_codes, M, K, opts, out);
+    });
 }
 
 int dpq_open_plain_memory(const uint8_t* codes, int64_t n_codes, int M, int K, const dpq_open_opts* opts,
                           dpq_index** out) {
+    return guarded([&]() -> int {
     return open_plain(codes, n_codes, M, K, opts, out);
+    });
 }
 
 int dpq_open_plain_file(const char* path, int M, int K, const dpq_open_opts* opts, dpq_index** out) {
+    return guarded([&]() -> int {
     if (!path || !out) return fail(DPQ_ERR_ARG, "NULL argument");
     std::vector<uint8_t> codes;
     int64_t n = 0;
@@ -968,9 +1059,11 @@ int dpq_open_plain_file(const char* path, int M, int K, const dpq_open_opts* opt
     int rc = dpq::read_codes_plain(path, M, &n, &codes, &err);
     if (rc) return fail(rc, err);
     return open_plain(codes.data(), n, M, K, opts, out);
+    });
 }
 
 int dpq_set_codebook(dpq_index* x, const float* codewords, int Ds) {
+    return guarded([&]() -> int {
     if (!x || !codewords || Ds < 1 || Ds > 4096) return fail(DPQ_ERR_ARG, "bad codebook argument");
     if (int rc = dpq_finish(x)) return rc;  // batches in flight still read the old codebook
     DPQ_HIP(hipSetDevice(x->device));
@@ -983,16 +1076,20 @@ int dpq_set_codebook(dpq_index* x, const float* codewords, int Ds) {
     x->Ds = Ds;
     x->info.Ds = Ds;
     return DPQ_OK;
+    });
 }
 
 int dpq_get_info(const dpq_index* x, dpq_info* info) {
+    return guarded([&]() -> int {
     if (!x || !info) return fail(DPQ_ERR_ARG, "NULL argument");
     *info = x->info;
     info->cand_capacity = x->cap_auto ? 0 : x->cap;
     return DPQ_OK;
+    });
 }
 
 int dpq_close(dpq_index* x) {
+    return guarded([&]() -> int {
     if (!x) return DPQ_OK;
     hipSetDevice(x->device);
     if (!x->pending.empty()) {  // batches still in flight: let them drain before their buffers go
@@ -1023,6 +1120,7 @@ int dpq_close(dpq_index* x) {
     hipFree(x->d_counters);
     delete x;
     return DPQ_OK;
+    });
 }
 
 namespace {
@@ -1039,6 +1137,7 @@ int check_batch_args(dpq_index* x, const float* d_queries, int nq, int top_k, in
 }  // namespace
 
 int dpq_finish(dpq_index* x) {
+    return guarded([&]() -> int {
     if (!x) return fail(DPQ_ERR_ARG, "NULL index");
     if (x->pending.empty()) return DPQ_OK;
     DPQ_HIP(hipSetDevice(x->device));
@@ -1058,14 +1157,19 @@ int dpq_finish(dpq_index* x) {
         if (rc) return rc;
     }
     return DPQ_OK;
+    });
 }
 
 int dpq_query_batch_device_async(dpq_index* x, const float* d_queries, int nq, int top_k, int32_t* d_ids,
                                  float* d_dists, void* hip_stream) {
+    return guarded([&]() -> int {
     int rc = check_batch_args(x, d_queries, nq, top_k, d_ids, d_dists);
     if (rc || nq == 0) return rc;
     DPQ_HIP(hipSetDevice(x->device));
     hipStream_t stream = reinterpret_cast<hipStream_t>(hip_stream);
+    // all batches in flight share one workspace (tables, candidate buffers, thresholds): they are ordered
+    // by the stream only.  A batch for another stream first settles what is in flight.
+    if (!x->pending.empty() && x->pending.back().stream != stream && (rc = dpq_finish(x))) return rc;
     const int D = x->M * x->Ds;
     for (int base = 0; base < nq; base += kMaxBatchQueries) {
         const int n = std::min(kMaxBatchQueries, nq - base);
@@ -1082,10 +1186,12 @@ int dpq_query_batch_device_async(dpq_index* x, const float* d_queries, int nq, i
         x->prof_acc.queries += nq;
     }
     return DPQ_OK;
+    });
 }
 
 int dpq_query_batch_device(dpq_index* x, const float* d_queries, int nq, int top_k, int32_t* d_ids, float* d_dists,
                            void* hip_stream) {
+    return guarded([&]() -> int {
     if (x && !x->pending.empty()) {  // keep the order of the batches on this index
         int rc = dpq_finish(x);
         if (rc) return rc;
@@ -1110,9 +1216,11 @@ int dpq_query_batch_device(dpq_index* x, const float* d_queries, int nq, int top
         x->prof_acc.queries += nq;
     }
     return DPQ_OK;
+    });
 }
 
 int dpq_query_batch(dpq_index* x, const float* queries, int nq, int top_k, int32_t* ids, float* dists) {
+    return guarded([&]() -> int {
     if (!x || !queries || !ids || !dists || nq < 0) return fail(DPQ_ERR_ARG, "NULL argument or nq < 0");
     if (!x->d_codebook) return fail(DPQ_ERR_STATE, "dpq_set_codebook has not been called");
     if (nq == 0) return DPQ_OK;
@@ -1143,10 +1251,12 @@ int dpq_query_batch(dpq_index* x, const float* queries, int nq, int top_k, int32
     DPQ_HIP(hipMemcpy(ids, x->d_ids_stage, oe * sizeof(int32_t), hipMemcpyDeviceToHost));
     DPQ_HIP(hipMemcpy(dists, x->d_dists_stage, oe * sizeof(float), hipMemcpyDeviceToHost));
     return DPQ_OK;
+    });
 }
 
 int dpq_merge_topk_host(const int32_t* ids, const float* dists, int n_lists, int nq, int top_k, int32_t* out_ids,
                         float* out_dists) {
+    return guarded([&]() -> int {
     if (!ids || !dists || !out_ids || !out_dists || n_lists < 1 || nq < 0 || top_k < 1)
         return fail(DPQ_ERR_ARG, "bad merge argument");
     std::vector<uint64_t> keys;
@@ -1175,10 +1285,12 @@ int dpq_merge_topk_host(const int32_t* ids, const float* dists, int n_lists, int
         }
     }
     return DPQ_OK;
+    });
 }
 
 int dpq_merge_topk_device(const int32_t* d_ids, const float* d_dists, int n_lists, int nq, int top_k,
                           int32_t* d_out_ids, float* d_out_dists, int device, void* hip_stream) {
+    return guarded([&]() -> int {
     if (!d_ids || !d_dists || !d_out_ids || !d_out_dists || n_lists < 1 || nq < 0 || top_k < 1)
         return fail(DPQ_ERR_ARG, "bad merge argument");
     if ((int64_t)n_lists * top_k > 16384) return fail(DPQ_ERR_ARG, "n_lists * top_k exceeds 16384");
@@ -1186,6 +1298,7 @@ int dpq_merge_topk_device(const int32_t* d_ids, const float* d_dists, int n_list
     DPQ_HIP(dpq::launch_merge(d_ids, d_dists, n_lists, nq, top_k, d_out_ids, d_out_dists,
                               reinterpret_cast<hipStream_t>(hip_stream)));
     return DPQ_OK;
+    });
 }
 
 // Developer hook (not in the public header): time `reps` full-index filter-scan
@@ -1193,6 +1306,7 @@ int dpq_merge_topk_device(const int32_t* d_ids, const float* d_dists, int n_list
 // survives; 1: everything survives), to separate decode/ADC cost from
 // candidate handling.  Needs a prior dpq_query_batch* call with >= nq queries.
 int dpq_debug_scan_time(dpq_index* x, int nq, int pass_all, int reps, int splits, float* ms_out) {
+    return guarded([&]() -> int {
     if (!x || !ms_out || !x->d_lut32) return fail(DPQ_ERR_STATE, "run a query batch first");
     DPQ_HIP(hipSetDevice(x->device));
     const int QG = dpq::queries_per_group(x->M);
@@ -1215,9 +1329,11 @@ int dpq_debug_scan_time(dpq_index* x, int nq, int pass_all, int reps, int splits
     sa.cand_stride = x->ws_cap;
     sa.region_off = 0;
     sa.region_cap = std::max(1, x->ws_cap / splits);
+    sa.qtab = x->d_qtab;
     hipEvent_t a, b;
     DPQ_HIP(hipEventCreate(&a));
     DPQ_HIP(hipEventCreate(&b));
+    DPQ_HIP(dpq::launch_quantise(sa, nqp / QG, nullptr));
     DPQ_HIP(dpq::launch_scan(sa, nqp / QG, splits, nullptr));
     DPQ_HIP(hipEventRecord(a, nullptr));
     for (int r = 0; r < reps; ++r) DPQ_HIP(dpq::launch_scan(sa, nqp / QG, splits, nullptr));
@@ -1229,10 +1345,63 @@ int dpq_debug_scan_time(dpq_index* x, int nq, int pass_all, int reps, int splits
     hipEventDestroy(a);
     hipEventDestroy(b);
     return DPQ_OK;
+    });
+}
+
+// Developer hook (not in the public header): one full-index filter-scan launch of the STAMPS build of the
+// scan kernel (s_memtime brackets around the sections of the loop) with the thresholds the last batch
+// left behind; out[0..n) = per-section cycle sums over all wavefronts (order: enum in dpq_kernels.hip).
+int dpq_debug_scan_stamps(dpq_index* x, int nq, int splits, unsigned long long* out, int n_out, float* ms_out) {
+    return guarded([&]() -> int {
+    if (!x || !out || !x->d_lut32) return fail(DPQ_ERR_STATE, "run a query batch first");
+    if (x->M != 8) return fail(DPQ_ERR_ARG, "the STAMPS build exists for M = 8");
+    DPQ_HIP(hipSetDevice(x->device));
+    const int QG = dpq::queries_per_group(x->M);
+    const int nqp = (nq + QG - 1) / QG * QG;
+    if (nqp > x->ws_slots) return fail(DPQ_ERR_ARG, "nq exceeds the workspace");
+    const int n = std::min(n_out, dpq::scan_stamp_count());
+    unsigned long long* d_st = nullptr;
+    int rc = dev_alloc(&d_st, (size_t)dpq::scan_stamp_count());
+    if (rc) return rc;
+    DPQ_HIP(hipMemset(d_st, 0, sizeof(unsigned long long) * dpq::scan_stamp_count()));
+    dpq::ScanArgs sa{};
+    sa.img = x->img;
+    sa.lut32 = x->d_lut32;
+    sa.lut_min = x->d_lut_min;
+    sa.thr_key = x->d_thr_key;
+    sa.n_queries = nq;
+    sa.n_seg_pass = x->img.n_segments;
+    if (const char* e = getenv("DPQ_DEBUG_NSEG")) sa.n_seg_pass = std::min(x->img.n_segments, atoi(e));
+    if (splits <= 0) splits = splits_for(sa.n_seg_pass, nqp / QG);
+    sa.cand_count = x->d_cand_count;
+    sa.cand_key = x->d_cand_key;
+    sa.cand_stride = x->ws_cap;
+    sa.region_off = 0;
+    sa.region_cap = std::max(1, x->ws_cap / splits);
+    sa.qtab = x->d_qtab;
+    sa.stamps = d_st;
+    hipEvent_t a, b;
+    DPQ_HIP(hipEventCreate(&a));
+    DPQ_HIP(hipEventCreate(&b));
+    DPQ_HIP(dpq::launch_quantise(sa, nqp / QG, nullptr));
+    DPQ_HIP(hipEventRecord(a, nullptr));
+    DPQ_HIP(dpq::launch_scan(sa, nqp / QG, splits, nullptr));
+    DPQ_HIP(hipEventRecord(b, nullptr));
+    DPQ_HIP(hipEventSynchronize(b));
+    float ms = 0;
+    DPQ_HIP(hipEventElapsedTime(&ms, a, b));
+    if (ms_out) *ms_out = ms;
+    DPQ_HIP(hipMemcpy(out, d_st, sizeof(unsigned long long) * n, hipMemcpyDeviceToHost));
+    hipEventDestroy(a);
+    hipEventDestroy(b);
+    hipFree(d_st);
+    return DPQ_OK;
+    });
 }
 
 // Developer hook: time the level-0 select (shared, query-independent candidate list).
 int dpq_debug_select_time(dpq_index* x, int nq, int top_k, int flags, int reps, float* ms_out) {
+    return guarded([&]() -> int {
     if (!x || !ms_out || !x->d_lut32 || !x->d_l0_id) return fail(DPQ_ERR_STATE, "run a query batch first");
     DPQ_HIP(hipSetDevice(x->device));
     dpq::SelectArgs se{};
@@ -1265,16 +1434,20 @@ int dpq_debug_select_time(dpq_index* x, int nq, int top_k, int flags, int reps, 
     hipEventDestroy(a);
     hipEventDestroy(b);
     return DPQ_OK;
+    });
 }
 
 int dpq_profile_enable(dpq_index* x, int on) {
+    return guarded([&]() -> int {
     if (!x) return fail(DPQ_ERR_ARG, "NULL index");
     x->prof = on != 0;
     x->prof_scan_only = on == 2;
     return DPQ_OK;
+    });
 }
 
 int dpq_profile_reset(dpq_index* x) {
+    return guarded([&]() -> int {
     if (!x) return fail(DPQ_ERR_ARG, "NULL index");
     hipSetDevice(x->device);
     for (auto& ep : x->events) {
@@ -1285,11 +1458,17 @@ int dpq_profile_reset(dpq_index* x) {
     memset(&x->prof_acc, 0, sizeof x->prof_acc);
     if (x->d_counters) hipMemset(x->d_counters, 0, 16);
     return DPQ_OK;
+    });
 }
 
 int dpq_profile_read(dpq_index* x, dpq_profile* out) {
+    return guarded([&]() -> int {
     if (!x || !out) return fail(DPQ_ERR_ARG, "NULL argument");
     DPQ_HIP(hipSetDevice(x->device));
+    if (x->prof_failed) {
+        x->prof_failed = false;
+        return fail(DPQ_ERR_HIP, "a profiling event could not be created or recorded; timings are incomplete");
+    }
     for (auto& ep : x->events) {
         DPQ_HIP(hipEventSynchronize(ep.b));
         float ms = 0.f;
@@ -1297,6 +1476,7 @@ int dpq_profile_read(dpq_index* x, dpq_profile* out) {
         if (ep.kind == 0) x->prof_acc.lut_ms += ms;
         if (ep.kind == 1) x->prof_acc.scan_ms += ms;
         if (ep.kind == 2) x->prof_acc.select_ms += ms;
+        if (ep.kind == 3) x->prof_acc.quantise_ms += ms;
         x->ev_pool.push_back(ep.a);
         x->ev_pool.push_back(ep.b);
     }
@@ -1309,6 +1489,7 @@ int dpq_profile_read(dpq_index* x, dpq_profile* out) {
     }
     *out = x->prof_acc;
     return DPQ_OK;
+    });
 }
 
 }  // extern "C"

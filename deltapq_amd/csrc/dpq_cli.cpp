@@ -162,8 +162,13 @@ int main(int argc, char* argv[]) {
         return 0;
     }
     const bool pqscan = task == "pqscan";  // main:496-556: uncompressed comparator over codes.bin.plain
+    // -task batch_query (main:351-420) is accepted as an alias of -task query: the engine behind `query`
+    // already decodes every chunk once for a whole batch of queries, with the -task query arithmetic and ids
+    // (the reference's batch variant accumulates in fp32 and records the second node of a pair under the
+    // first one's id, h:3079, h:3389-3392 -- not reproduced).
+    if (task == "batch_query") task = "query";
     if (task != "query" && task != "query_im" && !pqscan) {
-        std::cout << "deltapq (MI355X build): -task query, query_im, pqscan, approx_tree and encode are implemented; got '" << task
+        std::cout << "deltapq (MI355X build): -task query, query_im, batch_query, pqscan, approx_tree and encode are implemented; got '" << task
                   << "'" << std::endl;
         return 2;
     }
@@ -212,11 +217,13 @@ int main(int argc, char* argv[]) {
         rc = dpq_read_dtc_header(fname, &n_codes, &n_bytes);
         if (rc) return die("open index", rc);
     }
-    if (N != n_codes) {  // h:2826-2829 / main:629-632
-        std::cout << "scan only part of the codes " << N << " / " << n_codes
-                  << " is not supported by this build: pass -N " << n_codes << std::endl;
+    if (N == -1) N = n_codes;  // h:2825
+    if (N < 1 || N > n_codes) {
+        std::cout << "-N " << N << " outside 1.." << n_codes << std::endl;
         return 1;
     }
+    if (N != n_codes)  // h:2826-2829 / main:629-632: the first N codes of a larger index
+        std::cout << "scan only part of the codes " << N << " / " << n_codes << std::endl;
     std::cout << "M = " << PQ_M << std::endl;
     std::cout << "K = " << PQ_K << std::endl;
     std::cout << "N = " << N << std::endl;
@@ -267,6 +274,7 @@ int main(int argc, char* argv[]) {
         o.device = g;
         o.shard_rank = g;
         o.shard_count = gpus;
+        o.num_codes = N != n_codes ? (int32_t)N : 0;
         rc = pqscan ? dpq_open_plain_file(fname, PQ_M, PQ_K, &o, &shards[(size_t)g])
                     : dpq_open_file(fname, PQ_M, PQ_K, &o, &shards[(size_t)g]);
         if (rc) return die("dpq_open_file", rc);

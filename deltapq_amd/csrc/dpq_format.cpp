@@ -102,6 +102,13 @@ static int check_args(const uint8_t* payload, int64_t n_bytes, int64_t n_codes, 
         if (err) *err = "number of codes does not fit a 32-bit id";
         return DPQ_ERR_ARG;
     }
+    // a header that promises more nodes than the payload can hold (root + per node a mask and half a depth byte)
+    // is refused before anything is sized by it
+    const int64_t least = (int64_t)M + (n_codes - 1) * mask_bytes_for(M) + n_codes / 2;
+    if (n_bytes < least) {
+        if (err) *err = "n_codes in the header needs more payload bytes than n_bytes";
+        return DPQ_ERR_FORMAT;
+    }
     return DPQ_OK;
 }
 
@@ -140,9 +147,16 @@ int validate(const uint8_t* payload, int64_t n_bytes, int64_t n_codes, int M, dp
 }
 
 int transcode(const uint8_t* payload, int64_t n_bytes, int64_t n_codes, int M, int shard_rank, int shard_count,
-              int chunks_per_segment, SoA* out, std::string* err) {
+              int chunks_per_segment, SoA* out, std::string* err, int64_t scan_codes) {
     int rc = check_args(payload, n_bytes, n_codes, M, err);
     if (rc) return rc;
+    if (scan_codes < 0 || scan_codes > n_codes) {
+        if (err) *err = "num_codes (prefix to scan) outside 0..n_codes";
+        return DPQ_ERR_ARG;
+    }
+    // The prefix [0, n_scan) is what this image stands for; n_codes keeps deciding how the stream parses.
+    const int64_t n_scan = scan_codes > 0 ? scan_codes : n_codes;
+    const bool prefix = n_scan < n_codes;
     if (shard_count <= 0) shard_count = 1;
     if (chunks_per_segment <= 0) chunks_per_segment = kDefaultChunksPerSegment;
     if (shard_rank < 0 || shard_rank >= shard_count || chunks_per_segment > 1024) {
@@ -150,7 +164,7 @@ int transcode(const uint8_t* payload, int64_t n_bytes, int64_t n_codes, int M, i
         return DPQ_ERR_ARG;
     }
     const int64_t S = (int64_t)kChunk * chunks_per_segment;
-    const int64_t nseg_total = (n_codes + S - 1) / S;
+    const int64_t nseg_total = (n_scan + S - 1) / S;
     const int levels = levels_for(M);
     const int mb = mask_bytes_for(M);
 
@@ -160,7 +174,8 @@ int transcode(const uint8_t* payload, int64_t n_bytes, int64_t n_codes, int M, i
         std::vector<int64_t> seg_bytes((size_t)nseg_total, 0);
         DtcWalker w(payload, n_bytes, n_codes, M);
         NodeRec r;
-        while (!w.done()) {
+        int64_t bytes_scanned = 0;
+        while (!w.done() && w.pos() < n_scan) {
             int64_t i = w.pos();
             rc = w.next(&r);
             if (rc) {
@@ -168,8 +183,9 @@ int transcode(const uint8_t* payload, int64_t n_bytes, int64_t n_codes, int M, i
                 return rc;
             }
             seg_bytes[(size_t)(i / S)] += r.payload_end - r.payload_begin;
+            bytes_scanned += r.payload_end - r.payload_begin;
         }
-        if (w.offset() != n_bytes) {
+        if (!prefix && w.offset() != n_bytes) {
             if (err) *err = "stream length does not match n_bytes";
             return DPQ_ERR_FORMAT;
         }
@@ -177,7 +193,7 @@ int transcode(const uint8_t* payload, int64_t n_bytes, int64_t n_codes, int M, i
         auto boundary = [&](int r_) -> int64_t {
             if (r_ <= 0) return 0;
             if (r_ >= shard_count) return nseg_total;
-            long double target = (long double)n_bytes * r_ / shard_count;
+            long double target = (long double)bytes_scanned * r_ / shard_count;
             int64_t acc = 0;
             for (int64_t s = 0; s < nseg_total; s++) {
                 if ((long double)acc >= target) return s;
@@ -196,10 +212,10 @@ int transcode(const uint8_t* payload, int64_t n_bytes, int64_t n_codes, int M, i
     o.levels = levels;
     o.mask_bytes = mb;
     o.chunks_per_segment = chunks_per_segment;
-    o.n_codes_total = n_codes;
+    o.n_codes_total = n_scan;  // the even-N id rule (h:2949, 2970) applies to the codes scanned
     o.n_bytes_total = n_bytes;
-    o.node_lo = std::min(seg_lo * S, n_codes);
-    o.node_hi = std::min(seg_hi * S, n_codes);
+    o.node_lo = std::min(seg_lo * S, n_scan);
+    o.node_hi = std::min(seg_hi * S, n_scan);
     o.n_segments = seg_hi - seg_lo;
     const int64_t n_pad = o.n_segments * S;
     o.nib.assign((size_t)(n_pad / 2), 0x11);  // padding nodes: depth 1, no change
@@ -213,7 +229,7 @@ int transcode(const uint8_t* payload, int64_t n_bytes, int64_t n_codes, int M, i
     NodeRec r;
     while (!w.done()) {
         const int64_t i = w.pos();
-        if (shard_count > 1 && i >= o.node_hi) break;  // the rest was validated by the first pass
+        if ((shard_count > 1 || prefix) && i >= o.node_hi) break;  // the rest was validated by the first pass / is not scanned
         if (i >= o.node_lo && i < o.node_hi && (i - o.node_lo) % S == 0) {
             const int64_t t = (i - o.node_lo) / S;
             memcpy(&o.seg_ckpt[(size_t)(t * levels * M)], stack.data(), (size_t)levels * M);
@@ -316,9 +332,13 @@ int read_file(const std::string& path, std::vector<uint8_t>* out, std::string* e
         if (err) *err = "cannot open file " + path;  // the reference prints this and goes on (h:2819-2821)
         return DPQ_ERR_IO;
     }
-    fseek(f, 0, SEEK_END);
-    long sz = ftell(f);
-    fseek(f, 0, SEEK_SET);
+    long sz = -1;
+    if (fseek(f, 0, SEEK_END) == 0) sz = ftell(f);
+    if (sz < 0 || fseek(f, 0, SEEK_SET) != 0) {
+        fclose(f);
+        if (err) *err = "cannot determine the size of " + path;
+        return DPQ_ERR_IO;
+    }
     out->resize((size_t)sz);
     size_t got = sz ? fread(out->data(), 1, (size_t)sz, f) : 0;
     fclose(f);

@@ -76,8 +76,10 @@ struct SoA {
 };
 
 int validate(const uint8_t* payload, int64_t n_bytes, int64_t n_codes, int M, dpq_dtc_stats* stats, std::string* err);
+// scan_codes > 0: image of the first scan_codes nodes only (the reference's `-N` below the header's n_codes,
+// h:2825-2829); the stream is parsed with the header's n_codes (it decides which node owns a whole depth byte).
 int transcode(const uint8_t* payload, int64_t n_bytes, int64_t n_codes, int M, int shard_rank, int shard_count,
-              int chunks_per_segment, SoA* out, std::string* err);
+              int chunks_per_segment, SoA* out, std::string* err, int64_t scan_codes = 0);
 int encode(const uint8_t* root_code, const uint8_t* depths, const uint16_t* masks, const uint8_t* deltas,
            int64_t n_codes, int M, uint8_t* out, int64_t* n_bytes, std::string* err);
 

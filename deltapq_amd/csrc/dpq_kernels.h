@@ -51,6 +51,10 @@ struct ScanArgs {
     int64_t cand_stride;
     int32_t region_off, region_cap;
     unsigned long long* counters;  // statistics (may be NULL): [0] += pairs checked exactly, [1] += candidates
+    // this level's filter tables, [groups][qtab_bytes_per_group / 16] x 16 B: written by launch_quantise
+    // (from lut32 / lut_min / thr_key), copied into LDS by every scan workgroup of the group
+    uint4* qtab;
+    unsigned long long* stamps;    // developer diagnostics (NULL in every query call): per-section cycle sums
 };
 
 struct SelectArgs {
@@ -84,7 +88,12 @@ hipError_t launch_lut_build(const float* d_codebook, const float* d_queries, int
                             hipStream_t stream);
 hipError_t launch_decode_segments(const DeviceImage& img, const uint32_t* seg_list, int n_seg, uint32_t* out_id,
                                   uint32_t* out_code, hipStream_t stream);
+// launch_quantise builds the level's filter tables of every query group (needs the level's thresholds in
+// thr_key); launch_scan must follow it on the same stream.
+hipError_t launch_quantise(const ScanArgs& a, int n_slot_groups, hipStream_t stream);
 hipError_t launch_scan(const ScanArgs& a, int n_slot_groups, int splits, hipStream_t stream);
+size_t qtab_bytes_per_group(int M);
+int scan_stamp_count();
 hipError_t launch_select(const SelectArgs& a, int M, int n_slots, hipStream_t stream);
 hipError_t launch_merge(const int32_t* d_ids, const float* d_dists, int n_lists, int nq, int top_k, int32_t* d_out_ids,
                         float* d_out_dists, hipStream_t stream);

@@ -37,6 +37,7 @@
 // the exact rule would keep.
 #include "dpq_kernels.h"
 
+#include <atomic>
 #include <cfloat>
 #include <cmath>
 
@@ -169,27 +170,42 @@ struct Cfg {
     static constexpr int FIELD_MAX = (1 << EB) - 1;
     static_assert(M * SAT + BIAS <= FIELD_MAX, "a field sum must not carry into its neighbour");
     static constexpr uint32_t LOW = EB == 8 ? 0x01010101u : 0x00010001u;  // bit 0 of every field
-    static constexpr int RQ = M <= 8 ? 128 : 64;      // (node, query) pairs a wavefront queues before their exact check
+    // refine queue of a wavefront: one entry per node with filter survivors = (code, id, survivor mask);
+    // 1920 B per wavefront (16 of them share what the 128 KB of tables leave of the 160 KB)
+    static constexpr int QE_BYTES = 4 * W + 4 + 4 * MD;
+    static constexpr int QCAP = 1920 / QE_BYTES;      // 96 entries (M = 8), 80 (M = 16)
+    static_assert(QCAP >= 64 + 16, "a step pushes up to 64 entries");
     // local slot of field f of accumulator dword acc: survivor-mask dword acc / EB, bit EB * f + acc % EB
     __host__ __device__ static constexpr int slot_of(int acc, int f) { return (acc / EB) * (J * F) + f * J + acc % EB; }
 };
 
 // a7: the reference's decoder[256] (main:312-325) as byte-permute selectors.
-// entry.x/.y: v_perm_b32 selectors that move a node's packed changed bytes to
-// positions 0..3 / 4..7 of an 8-position group (0x0c = constant zero);
-// entry.z/.w: byte masks of the changed positions.
-__device__ __forceinline__ uint4 make_decode_entry(uint32_t b) {
-    uint32_t sel[2] = {0, 0}, pm[2] = {0, 0};
-    uint32_t rank = 0;
-#pragma unroll
-    for (int m = 0; m < 8; ++m) {
-        const bool set = (b >> m) & 1u;
-        const uint32_t s = set ? rank : 0x0cu;
-        sel[m >> 2] |= s << (8 * (m & 3));
-        pm[m >> 2] |= (set ? 0xffu : 0u) << (8 * (m & 3));
-        rank += set;
+// entry[0]/[1]: v_perm_b32 selectors that move a node's packed changed bytes to
+// positions 0..3 / 4..7 of an 8-position group (0x0c = constant zero).
+// A compile-time table in global memory (4 KB, lives in the vector L1): the
+// scan is bound by LDS cycles, so the decode keeps its table out of the LDS.
+struct DecodeTable {
+    uint32_t e[256][2];
+    constexpr DecodeTable() : e() {
+        for (int b = 0; b < 256; ++b) {
+            uint32_t sel[2] = {0, 0};
+            uint32_t rank = 0;
+            for (int m = 0; m < 8; ++m) {
+                const bool set = (b >> m) & 1;
+                sel[m >> 2] |= (set ? rank : 0x0cu) << (8 * (m & 3));
+                rank += set ? 1u : 0u;
+            }
+            e[b][0] = sel[0];
+            e[b][1] = sel[1];
+        }
     }
-    return make_uint4(sel[0], sel[1], pm[0], pm[1]);
+};
+__device__ const DecodeTable g_dtab{};
+
+// bit i (0..3) of `nib` -> v_perm_b32 selector byte i: i (take the own byte) where the bit is set,
+// 4 + i (take the other operand's byte) elsewhere.  perm(other, own, sel).
+__device__ __forceinline__ uint32_t own_sel(uint32_t nib) {
+    return 0x07060504u - ((nib * 0x00810204u) & 0x04040404u);  // nib < 16: bit i lands on bit 8 i + 2, no carries
 }
 
 template <int M>
@@ -212,13 +228,12 @@ struct WaveDecoder {
 
     // Decode node `node` (= this lane's node of the chunk).  `carry`: update the
     // stack for the next chunk of the segment.
-    __device__ __forceinline__ void step(const DeviceImage& img, int64_t node, int lane, uint64_t lt_mask,
-                                         const uint4* dtab, bool carry, uint32_t (&code)[W]) {
+    __device__ __forceinline__ void step(const DeviceImage& img, int64_t node, int lane, uint64_t lt_mask, bool carry,
+                                         uint32_t (&code)[W]) {
         // depth nibble and mask (coalesced)
         const uint32_t nb = img.nib[node >> 1];
         const uint32_t d = (node & 1) ? (nb >> 4) : (nb & 15u);
-        const uint32_t mk = M <= 8 ? (uint32_t)img.mask[node]
-                                   : (uint32_t)reinterpret_cast<const uint16_t*>(img.mask)[node];
+        uint32_t mk = M <= 8 ? (uint32_t)img.mask[node] : (uint32_t)reinterpret_cast<const uint16_t*>(img.mask)[node];
         const uint32_t pc = __popc(mk);
         // wave exclusive scan of pc by bit planes: v_mbcnt, no LDS traffic
         uint32_t excl = 0, total = 0;
@@ -230,7 +245,7 @@ struct WaveDecoder {
         }
         // changed bytes at byte granularity, one 8-position group at a time:
         // 3 aligned dwords + funnel shift, then scatter to positions (a7)
-        uint32_t pv[W], pm[W];
+        uint32_t pv[W];
 #pragma unroll
         for (int h = 0; h < W / 2; ++h) {
             const uint32_t skip = h == 0 ? 0u : (uint32_t)__popc(mk & 0xffu);
@@ -241,11 +256,9 @@ struct WaveDecoder {
             const uint32_t w0 = wp[0], w1 = wp[1], w2 = wp[2];
             const uint32_t raw_lo = __builtin_amdgcn_alignbyte(w1, w0, sh);
             const uint32_t raw_hi = __builtin_amdgcn_alignbyte(w2, w1, sh);
-            const uint4 t = dtab[(mk >> (8 * h)) & 0xffu];
+            const uint2 t = *reinterpret_cast<const uint2*>(g_dtab.e[(mk >> (8 * h)) & 0xffu]);
             pv[2 * h] = __builtin_amdgcn_perm(raw_hi, raw_lo, t.x);
             pv[2 * h + 1] = __builtin_amdgcn_perm(raw_hi, raw_lo, t.y);
-            pm[2 * h] = t.z;
-            pm[2 * h + 1] = t.w;
         }
         doff += total;
         // parent = nearest preceding node with depth-1 (h:2888: stack[depth-1])
@@ -258,32 +271,31 @@ struct WaveDecoder {
         const uint64_t prev = selB & lt_mask;
         int P = prev ? 63 - __clzll((long long)prev) : -1;  // -1: the parent precedes the chunk
         uint32_t td = d;                                     // depth of the top of my resolved chain
-        // pointer jumping: compose patches along the in-chunk ancestor chain
+        // Pointer jumping: compose patches along the in-chunk ancestor chain.  A patch travels as its
+        // W value dwords plus ONE dword (position mask | parent lane | top depth): the byte selectors that
+        // merge two patches are rebuilt from the position mask (VALU) instead of being carried through
+        // the LDS crossbar -- the scan is bound by LDS cycles.
 #pragma unroll
         for (int s = 0; s < Cfg<M>::JUMPS; ++s) {
+            if (__ballot(P >= 0) == 0) break;  // every chain is resolved (wave-uniform)
             const int src = P < 0 ? lane : P;
-            uint32_t q_pv[W], q_pm[W];
+            uint32_t q_pv[W];
 #pragma unroll
-            for (int w = 0; w < W; ++w) {
-                q_pv[w] = bperm(src, pv[w]);
-                q_pm[w] = bperm(src, pm[w]);
-            }
-            const uint32_t q_ptd = bperm(src, ((uint32_t)(P & 0xff)) | (td << 8));
+            for (int w = 0; w < W; ++w) q_pv[w] = bperm(src, pv[w]);
+            const uint32_t q_meta = bperm(src, mk | ((uint32_t)(P & 0xff) << 16) | (td << 24));
             if (P >= 0) {
 #pragma unroll
-                for (int w = 0; w < W; ++w) {
-                    pv[w] = (q_pv[w] & ~pm[w]) | pv[w];
-                    pm[w] |= q_pm[w];
-                }
-                const uint32_t pp = q_ptd & 0xffu;
+                for (int w = 0; w < W; ++w) pv[w] = __builtin_amdgcn_perm(q_pv[w], pv[w], own_sel((mk >> (4 * w)) & 15u));
+                mk |= q_meta & 0xffffu;
+                const uint32_t pp = (q_meta >> 16) & 0xffu;
                 P = pp == 0xffu ? -1 : (int)pp;
-                td = q_ptd >> 8;
+                td = q_meta >> 24;
             }
         }
         // apply to the ancestor that precedes the chunk
         const int e = td > 0 ? (int)td - 1 : 0;
 #pragma unroll
-        for (int w = 0; w < W; ++w) code[w] = (bperm(e, stk[w]) & ~pm[w]) | pv[w];
+        for (int w = 0; w < W; ++w) code[w] = __builtin_amdgcn_perm(bperm(e, stk[w]), pv[w], own_sel((mk >> (4 * w)) & 15u));
         // carry the stack: stack[D] = code of the last node with depth D
         if (carry) {
             int srcl = -1;
@@ -306,10 +318,7 @@ __global__ __launch_bounds__(64) void decode_segments_kernel(const DeviceImage i
                                                               uint32_t* __restrict__ out_id,
                                                               uint32_t* __restrict__ out_code) {
     constexpr int W = Cfg<M>::W;
-    __shared__ uint4 dtab[256];
     const int lane = threadIdx.x;
-    for (int i = lane; i < 256; i += 64) dtab[i] = make_decode_entry((uint32_t)i);
-    __syncthreads();
     const uint32_t seg = seg_list ? seg_list[blockIdx.x] : blockIdx.x;
     const uint64_t lt_mask = (1ull << lane) - 1ull;
     const int cps = img.chunks_per_segment;
@@ -322,7 +331,7 @@ __global__ __launch_bounds__(64) void decode_segments_kernel(const DeviceImage i
 #pragma unroll
             for (int w = 0; w < W; ++w) code[w] = reinterpret_cast<const uint32_t*>(img.raw)[(size_t)node * W + w];
         } else {
-            dec.step(img, node, lane, lt_mask, dtab, c + 1 < cps, code);
+            dec.step(img, node, lane, lt_mask, c + 1 < cps, code);
         }
         const size_t o = ((size_t)blockIdx.x * cps + c) * 64 + lane;
         out_id[o] = node < img.n_local ? img.id_base + (uint32_t)node : 0xffffffffu;
@@ -353,31 +362,137 @@ __device__ __forceinline__ float exact_dist(const float* __restrict__ T, const u
     return (float)dsum;
 }
 
+// ---------------------------------------------------------------------------
+// Filter tables of one cascade level, built ONCE per query group (the 16 scan
+// workgroups of a group used to rebuild the same 128 KB each): conservative
+// lower-bound tables, F queries per dword, in the LDS layout of the scan
+// ([g][m][code] x 16 B), written to global memory; a scan workgroup copies them.
+// For slot q with threshold tau:
+//   entry[m][k] = min(floor((T[m][k] - min_m) * s), SAT) (+ BIAS for m = 0),  s = QT / (tau' - sum_m min_m)
+//   tau' = tau * (1 + 2^-20): covers the fp32 rounding of the exact distance and, for the plain
+//   scan, the M fp32 roundings of its accumulated distance (<= M * 2^-24 relative)
+// floor and min only lower an entry, so sum_m entry <= (d - sum min) * s, which is <= QT for a node
+// with exact distance d <= tau: its field sum stays <= QT + BIAS < 2^(EB-1).  The top bit of a field
+// is therefore a safe reject flag (no per-query compare in the scan loop), M * SAT + BIAS <= 2^EB - 1
+// keeps the fields of a dword from carrying into each other, and what the filter lets through is
+// checked exactly before it becomes a candidate.
+// Computed as fma(T, s32, -off) in fp32: off >= min * s32 (rounded up), one rounding of the
+// result, and s32 carries a (1 - 2^-20) factor, so every entry is <= the exact real value.
+// grid = (NG * M, groups), block = 256 threads: thread k builds the 16-byte entry (g, m, k).
+// ---------------------------------------------------------------------------
+template <int M>
+__global__ __launch_bounds__(256) void quantise_kernel(const ScanArgs a) {
+    using C = Cfg<M>;
+    constexpr int F = C::F, EB = C::EB, QG = C::QG, NG = C::NG;
+    constexpr int TE = M * 256;
+    constexpr int NS = 4 * F;  // slots served by one 16-byte entry
+    __shared__ float s_scale[NS], s_off[NS];
+    __shared__ int32_t s_row[NS];
+    __shared__ uint32_t s_bias[NS];
+    const int g = blockIdx.x / M, m = blockIdx.x % M, group = blockIdx.y, k = threadIdx.x;
+    if (k < NS) {
+        const int c = k / F, f = k % F;
+        const int ls = C::slot_of(4 * g + c, f);
+        const int slot = group * QG + ls;
+        int qq = a.slot_query ? a.slot_query[slot] : (slot < a.n_queries ? slot : -1);
+        float s32 = 0.0f;   // 0: all entries 0, everything passes the filter
+        uint32_t bias = 0;
+        float mn_m = 0.0f;
+        if (qq >= 0 && a.debug_pass != 1) {
+            uint64_t key = ~0ull;
+            if (a.debug_pass != 2) key = a.thr_key[slot];
+            double B = 0.0;
+#pragma unroll
+            for (int mm = 0; mm < M; ++mm) B += (double)a.lut_min[(size_t)qq * M + mm];
+            const double taup = (double)__uint_as_float((uint32_t)(key >> 32)) * (1.0 + 0x1p-20);
+            const double R = taup - B;
+            if (key != ~0ull && R > 0.0 && R < 1e300) {  // else: no threshold yet (or degenerate), keep everything
+                s32 = (float)((double)C::QT / R * (1.0 - 0x1p-20));
+                bias = (uint32_t)C::BIAS;
+                mn_m = a.lut_min[(size_t)qq * M + m];
+            }
+        } else {
+            qq = -1;
+        }
+        // entry = fma(T, s32, -off) with off >= min*s32 (rounded up): never above (T - min) * s32
+        const double od = (double)mn_m * (double)s32;
+        float of = (float)od;
+        if ((double)of < od) of = __uint_as_float(__float_as_uint(of) + 1u);  // od >= 0: next float up
+        if constexpr (EB == 8) {
+            // added to T * s32 before v_cvt_pk_u8_f32: bias (m = 0) and half a unit of slack against the
+            // conversion's rounding folded in, rounded DOWN
+            const double sd = (m == 0 ? (double)bias : 0.0) - 0.5 - (double)of;
+            float sf = (float)sd;
+            if ((double)sf > sd) sf = __uint_as_float(__float_as_uint(sf) + (sf > 0.0f ? -1 : 1));  // next float down
+            of = sf;
+        }
+        s_scale[k] = s32;
+        s_off[k] = of;
+        s_bias[k] = m == 0 ? bias : 0u;
+        s_row[k] = qq >= 0 ? qq * TE + m * 256 : -1;
+    }
+    __syncthreads();
+    uint32_t out[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+#pragma unroll
+        for (int f = 0; f < F; ++f) {
+            const int i = c * F + f;
+            const int row = s_row[i];
+            const float sc = s_scale[i], of = s_off[i];
+            const uint32_t bias = s_bias[i];
+            const float tv = row >= 0 ? a.lut32[(size_t)row + k] : 0.0f;
+            if constexpr (EB == 8) {
+                // v_cvt_pk_u8_f32: float -> u8 clamped to [0, 255], written into byte f of the dword.  Half a
+                // unit is taken off first, so whichever way the conversion rounds, the byte is <= floor(value):
+                // the entry stays a lower bound (negative -> 0; inf/NaN of centroids beyond K -> SAT by the min).
+                const float fv = fminf(__fmaf_rn(tv, sc, of), (float)C::SAT + (float)bias);  // `of` holds the shift here
+                out[c] = row < 0 ? out[c] | ((m == 0 ? (uint32_t)C::FIELD_MAX : 0u) << (EB * f))  // unused slot: top bit always set
+                                 : __builtin_amdgcn_cvt_pk_u8_f32(fv, (uint32_t)f, out[c]);
+            } else {
+                const float fv = __fmaf_rn(tv, sc, -of);
+                // fv < 0 only by the round-up of `of` (true value 0); NaN/inf (k >= K) saturate
+                uint32_t v = fv < (float)C::SAT ? (fv > 0.0f ? (uint32_t)fv : 0u) : (uint32_t)C::SAT;
+                v += bias;
+                if (row < 0) v = m == 0 ? (uint32_t)C::FIELD_MAX : 0u;  // unused slot: top bit always set
+                out[c] |= v << (EB * f);
+            }
+        }
+    }
+    a.qtab[((size_t)group * NG * M + blockIdx.x) * 256 + k] = make_uint4(out[0], out[1], out[2], out[3]);
+}
+
 // LDS map of the scan workgroup
 template <int M>
 struct ScanLds {
-    static constexpr size_t kTables = (size_t)Cfg<M>::NG * M * 256 * 16;          // filter tables
-    static constexpr size_t kDtab = kTables;                                        // decode table [256] x 16 B
-    static constexpr size_t kThr = kDtab + 4096;                                    // [QG] u64 threshold keys
-    static constexpr size_t kBase = kThr + (size_t)Cfg<M>::QG * 8;                  // [QG] i32 row of the exact tables
-    static constexpr size_t kCount = kBase + (size_t)Cfg<M>::QG * 4;                // [QG] candidates of this workgroup
-    static constexpr size_t kChecks = kCount + (size_t)Cfg<M>::QG * 4;              // [4]: pairs checked exactly, next list entry
-    // per-wave queue of (node, query) pairs that passed the filter and await the exact check
-    static constexpr size_t kQCode = kChecks + 16;                                  // [waves][RQ][W] dwords
-    static constexpr size_t kQId = kQCode + (size_t)kScanWaves * Cfg<M>::RQ * M;    // [waves][RQ] u32
-    static constexpr size_t kQSlot = kQId + (size_t)kScanWaves * Cfg<M>::RQ * 4;    // [waves][RQ] u8
-    static constexpr size_t kBytes = kQSlot + (size_t)kScanWaves * Cfg<M>::RQ;
+    using C = Cfg<M>;
+    static constexpr size_t kTables = (size_t)C::NG * M * 256 * 16;                  // filter tables
+    static constexpr size_t kThr = kTables;                                           // [QG] u64 threshold keys
+    static constexpr size_t kBase = kThr + (size_t)C::QG * 8;                         // [QG] i32 row of the exact tables
+    static constexpr size_t kCount = kBase + (size_t)C::QG * 4;                       // [QG] candidates of this workgroup
+    static constexpr size_t kChecks = kCount + (size_t)C::QG * 4;                     // [4]: pairs checked exactly, next list entry
+    // per-wave ring of nodes with filter survivors awaiting the exact check
+    static constexpr size_t kQCode = kChecks + 16;                                    // [waves][QCAP][W] dwords
+    static constexpr size_t kQId = kQCode + (size_t)kScanWaves * C::QCAP * M;         // [waves][QCAP] u32
+    static constexpr size_t kQMask = kQId + (size_t)kScanWaves * C::QCAP * 4;         // [waves][QCAP][MD] dwords
+    static constexpr size_t kBytes = kQMask + (size_t)kScanWaves * C::QCAP * 4 * C::MD;
     static_assert(kBytes <= 160 * 1024, "one workgroup per CU: 160 KB of LDS");
 };
 
-template <int M, bool PLAIN>
+// Diagnostic build of the scan (STAMPS): per-wavefront s_memtime brackets around the sections of the
+// loop, summed into a.stamps[].  Reading the counter drains the wave's LDS/scalar queue, so sections
+// do not overlap inside a wavefront as they do in the product kernel (about +10 % cycles); the split
+// between sections is what it is for.  Never used by a query call.
+enum { kStPrologue = 0, kStSegment, kStDecode, kStGather, kStFold, kStPush, kStRefine, kStTotal, kStSteps, kStRefines,
+       kStWaves, kStEntries, kStCount };
+
+template <int M, bool PLAIN, bool STAMPS>
 __global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanArgs a) {
     using C = Cfg<M>;
-    constexpr int W = C::W, QG = C::QG, NG = C::NG, NA = C::NA, EB = C::EB, F = C::F, MD = C::MD;
+    constexpr int W = C::W, QG = C::QG, NG = C::NG, NA = C::NA, EB = C::EB, F = C::F, MD = C::MD, QCAP = C::QCAP;
     constexpr int TE = M * 256;  // table entries per query
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint4* lut = reinterpret_cast<uint4*>(smem);                                        // [NG][M][256] x 16 B = 128 KB
-    uint4* dtab = reinterpret_cast<uint4*>(smem + ScanLds<M>::kDtab);                   // [256]
     uint64_t* s_thr = reinterpret_cast<uint64_t*>(smem + ScanLds<M>::kThr);             // [QG]
     int32_t* s_base = reinterpret_cast<int32_t*>(smem + ScanLds<M>::kBase);             // [QG], -1 = unused slot
     // candidates found by this workgroup per query; their keys go straight to the workgroup's own region
@@ -385,84 +500,48 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanArgs a) {
     uint32_t* wg_count = reinterpret_cast<uint32_t*>(smem + ScanLds<M>::kCount);        // [QG]
     uint32_t* wg_checks = reinterpret_cast<uint32_t*>(smem + ScanLds<M>::kChecks);      // [1]
     uint32_t* wg_next = wg_checks + 1;                                                  // [1] next list entry of this workgroup
-    // refine queue of this wavefront: filter survivors wait here until 64 of them can be checked at once
-    uint32_t* rq_code = reinterpret_cast<uint32_t*>(smem + ScanLds<M>::kQCode) + (size_t)(threadIdx.x >> 6) * C::RQ * C::W;
-    uint32_t* rq_id = reinterpret_cast<uint32_t*>(smem + ScanLds<M>::kQId) + (size_t)(threadIdx.x >> 6) * C::RQ;
-    uint8_t* rq_slot = smem + ScanLds<M>::kQSlot + (size_t)(threadIdx.x >> 6) * C::RQ;
+    // refine ring of this wavefront
+    uint32_t* rq_code = reinterpret_cast<uint32_t*>(smem + ScanLds<M>::kQCode) + (size_t)(threadIdx.x >> 6) * QCAP * W;
+    uint32_t* rq_id = reinterpret_cast<uint32_t*>(smem + ScanLds<M>::kQId) + (size_t)(threadIdx.x >> 6) * QCAP;
+    uint32_t* rq_mask = reinterpret_cast<uint32_t*>(smem + ScanLds<M>::kQMask) + (size_t)(threadIdx.x >> 6) * QCAP * MD;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    // Workgroups are dealt to the 8 XCDs round-robin in launch order.  All workgroups of a query group
-    // read the same exact tables (QG * M KB, prologue and exact checks), so give each XCD whole groups:
-    // its L2 then holds 1/8 of the batch's tables instead of all of them.
-    int group = blockIdx.y, split = blockIdx.x;
-    if ((gridDim.y & 7) == 0) {
-        const int linear = blockIdx.x + gridDim.x * blockIdx.y;
-        const int r = linear >> 3;
-        group = (linear & 7) * (gridDim.y >> 3) + r / gridDim.x;
-        split = r % gridDim.x;
+    uint64_t st[kStCount] = {};
+    uint64_t t_mark = 0, t_start = 0;
+    auto stamp = [&](int section) {
+        if constexpr (STAMPS) {
+            const uint64_t now = __builtin_amdgcn_s_memtime();
+            st[section] += now - t_mark;
+            t_mark = now;
+        }
+    };
+    if constexpr (STAMPS) t_start = t_mark = __builtin_amdgcn_s_memtime();
+
+    // Workgroups are dealt to the 8 XCDs round-robin in launch order (observed; speed only).  All
+    // workgroups of a query group read the same filter tables and exact tables (QG * M KB), so give each
+    // XCD a contiguous run of (group, split) pairs: its L2 then holds 1/8 of the batch's tables.
+    int group, split;
+    {
+        const int total = (int)(gridDim.x * gridDim.y);
+        const int linear = (int)(blockIdx.x + gridDim.x * blockIdx.y);
+        const int xcd = linear & 7, r = linear >> 3;
+        const int per = total >> 3, extra = total & 7;             // XCD x runs per + (x < extra) workgroups
+        const int j = xcd * per + min(xcd, extra) + r;             // position in group-major order
+        group = j / (int)gridDim.x;
+        split = j % (int)gridDim.x;
     }
     const int slot0 = group * QG;
 
-    // ---- prologue: quantise the QG queries' exact tables into conservative
-    // lower-bound tables, F per dword, straight into LDS.  For slot q with threshold tau:
-    //   entry[m][k] = min(floor((T[m][k] - min_m) * s), SAT) (+ BIAS for m = 0),  s = QT / (tau' - sum_m min_m)
-    //   tau' = tau * (1 + 2^-20): covers the fp32 rounding of the exact distance and, for the plain
-    //   scan, the M fp32 roundings of its accumulated distance (<= M * 2^-24 relative)
-    // floor and min only lower an entry, so sum_m entry <= (d - sum min) * s, which is <= QT for a node
-    // with exact distance d <= tau: its field sum stays <= QT + BIAS < 2^(EB-1).  The top bit of a field
-    // is therefore a safe reject flag (no per-query compare in the loop), M * SAT + BIAS <= 2^EB - 1
-    // keeps the fields of a dword from carrying into each other, and what the filter lets through is
-    // checked exactly before it becomes a candidate.
-    // Computed as fma(T, s32, -off) in fp32: off >= min * s32 (rounded up), one rounding of the
-    // result, and s32 carries a (1 - 2^-20) factor, so every entry is <= the exact real value.
-    float* q_scale = reinterpret_cast<float*>(smem + ScanLds<M>::kQCode);  // [QG]  (the refine queues are idle until the scan loop)
-    float* q_off = q_scale + QG;                                      // [M][QG]   min_m * scale, rounded UP (EB = 8: the whole additive term)
-    uint32_t* q_bias = reinterpret_cast<uint32_t*>(q_off + M * QG);   // [QG]      added to the m = 0 entries
-    if (tid < 256) dtab[tid] = make_decode_entry((uint32_t)tid);
+    // ---- prologue: this level's filter tables of the group (quantise_kernel) -> LDS ----
     if (tid < QG) {
         const int slot = slot0 + tid;
         int qq = a.slot_query ? a.slot_query[slot] : (slot < a.n_queries ? slot : -1);
-        float s32 = 0.0f;   // 0: all entries 0, everything passes the filter
-        uint32_t bias = 0;
         uint64_t key = ~0ull;
-        float mn[M];
-#pragma unroll
-        for (int m = 0; m < M; ++m) mn[m] = 0.0f;
         if (qq >= 0 && a.debug_pass != 1) {
             if (a.debug_pass != 2) key = a.thr_key[slot];
-            double B = 0.0;
-#pragma unroll
-            for (int m = 0; m < M; ++m) {
-                mn[m] = a.lut_min[(size_t)qq * M + m];
-                B += (double)mn[m];
-            }
-            const double taup = (double)__uint_as_float((uint32_t)(key >> 32)) * (1.0 + 0x1p-20);
-            const double R = taup - B;
-            if (key != ~0ull && R > 0.0 && R < 1e300) {  // else: no threshold yet (or degenerate), keep everything
-                s32 = (float)((double)C::QT / R * (1.0 - 0x1p-20));
-                bias = (uint32_t)C::BIAS;
-            }
         } else {
             qq = -1;
-        }
-        q_scale[tid] = s32;
-        q_bias[tid] = bias;
-#pragma unroll
-        for (int m = 0; m < M; ++m) {
-            // entry = fma(T, s32, -off) with off >= min*s32 (rounded up): never above (T - min) * s32
-            const double od = (double)mn[m] * (double)s32;
-            float of = (float)od;
-            if ((double)of < od) of = __uint_as_float(__float_as_uint(of) + 1u);  // od >= 0: next float up
-            if constexpr (EB == 8) {
-                // the table builder adds this to T * s32 and converts with v_cvt_pk_u8_f32: bias (m = 0) and
-                // half a unit of slack against the conversion's rounding folded in, rounded DOWN
-                const double sd = (m == 0 ? (double)bias : 0.0) - 0.5 - (double)of;
-                float sf = (float)sd;
-                if ((double)sf > sd) sf = __uint_as_float(__float_as_uint(sf) + (sf > 0.0f ? -1 : 1));  // next float down
-                of = sf;
-            }
-            q_off[m * QG + tid] = of;
         }
         s_base[tid] = qq >= 0 ? qq * TE : -1;
         s_thr[tid] = key;
@@ -472,49 +551,17 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanArgs a) {
             *wg_next = 0;
         }
     }
-    __syncthreads();
-    // one iteration = one dword column (F slots) of 4 consecutive codes of one (g, m): per slot one
-    // 16-byte global read (coalesced over the codes), one dword of each of the four LDS entries written
-    uint32_t* lut_dw = reinterpret_cast<uint32_t*>(lut);
-    for (int it = tid; it < NG * TE; it += kScanThreads) {
-        const int c = it & 3, e4 = it >> 2;
-        const int g = e4 / (TE / 4), mk = (e4 % (TE / 4)) * 4, m = mk >> 8;
-        uint32_t out[4] = {0, 0, 0, 0};
+    {
+        const uint4* src = a.qtab + (size_t)group * (NG * TE);
+        constexpr int PER = NG * TE / kScanThreads;  // 8
+        uint4 v[PER];
 #pragma unroll
-        for (int f = 0; f < F; ++f) {
-            const int ls = C::slot_of(4 * g + c, f);
-            const int base = s_base[ls];
-            const float sc = q_scale[ls], of = q_off[m * QG + ls];
-            const uint32_t bias = m == 0 ? q_bias[ls] : 0u;
-            float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (base >= 0) t = *reinterpret_cast<const float4*>(a.lut32 + (size_t)base + mk);
-            const float tv[4] = {t.x, t.y, t.z, t.w};
-            if constexpr (EB == 8) {
-                // v_cvt_pk_u8_f32: float -> u8 clamped to [0, 255], written into byte f of the dword.  Half a
-                // unit is taken off first, so whichever way the conversion rounds, the byte is <= floor(value):
-                // the entry stays a lower bound (negative -> 0; inf/NaN of centroids beyond K -> SAT by the min).
+        for (int i = 0; i < PER; ++i) v[i] = src[tid + i * kScanThreads];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const float fv = fminf(__fmaf_rn(tv[k], sc, of), (float)C::SAT + (float)bias);  // `of` holds the shift here
-                    out[k] = base < 0 ? out[k] | ((m == 0 ? (uint32_t)C::FIELD_MAX : 0u) << (EB * f))  // unused slot: top bit always set
-                                      : __builtin_amdgcn_cvt_pk_u8_f32(fv, (uint32_t)f, out[k]);
-                }
-            } else {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const float fv = __fmaf_rn(tv[k], sc, -of);
-                    // fv < 0 only by the round-up of `of` (true value 0); NaN/inf (k >= K) saturate
-                    uint32_t v = fv < (float)C::SAT ? (fv > 0.0f ? (uint32_t)fv : 0u) : (uint32_t)C::SAT;
-                    v += bias;
-                    if (base < 0) v = m == 0 ? (uint32_t)C::FIELD_MAX : 0u;  // unused slot: top bit always set
-                    out[k] |= v << (EB * f);
-                }
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) lut_dw[((size_t)g * TE + mk + k) * 4 + c] = out[k];
+        for (int i = 0; i < PER; ++i) lut[tid + i * kScanThreads] = v[i];
     }
-    __syncthreads();  // tables complete; the queue area (q_* scratch) may be reused from here on
+    __syncthreads();
+    stamp(kStPrologue);
 
     const uint64_t lt_mask = (1ull << lane) - 1ull;
     const int cps = a.img.chunks_per_segment;
@@ -524,37 +571,63 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanArgs a) {
 #pragma unroll
     for (int f = 0; f < F; ++f) live |= ((1u << C::J) - 1u) << (EB * f);
 
-    // exact check of the first n queued pairs (same distance rule and key order as the select kernel);
-    // what passes is a candidate
-    int rq_n = 0;  // wave-uniform
+    // Refine ring: one entry per node that has filter survivors.  refine(n) checks the n oldest entries
+    // (lane = entry; a lane walks the set bits of its entry's survivor mask, two per round so that their
+    // table gathers are in flight together) exactly -- same distance rule and key order as the select
+    // kernel; what passes is a candidate.
+    int rq_head = 0, rq_n = 0;  // wave-uniform
     const size_t region0 = (size_t)a.region_off + (size_t)split * a.region_cap;  // this workgroup's region in a slot's buffer
+    auto bit_slot = [](int p) { return (p >> 5) * (C::J * F) + ((p & 31) / EB) * C::J + (p % EB); };  // bit -> local slot
     auto refine = [&](int n) {
-        __builtin_amdgcn_wave_barrier();  // queue entries were written by other lanes of this wavefront
-        if (a.counters && lane == 0) atomicAdd(wg_checks, (uint32_t)n);
-        constexpr int E = C::RQ / 64;  // entries per lane: their table gathers are in flight together
-        uint32_t c[E][W];
-        int ls[E];
-        uint32_t eid[E];
-        float d[E];
+        __builtin_amdgcn_wave_barrier();  // ring entries were written by other lanes of this wavefront
+        int i = rq_head + lane;
+        i = i >= QCAP ? i - QCAP : i;
+        uint32_t c[W];
+        uint32_t eid = 0;
+        uint64_t pend = 0;
+        if (lane < n) {
 #pragma unroll
-        for (int e = 0; e < E; ++e) {
-            const int i = min(lane + 64 * e, n - 1);
+            for (int w = 0; w < W; ++w) c[w] = rq_code[i * W + w];
+            eid = rq_id[i];
+            pend = rq_mask[i * MD];
+            if constexpr (MD == 2) pend |= (uint64_t)rq_mask[i * MD + 1] << 32;
+        } else {
 #pragma unroll
-            for (int w = 0; w < W; ++w) c[e][w] = rq_code[i * W + w];
-            ls[e] = rq_slot[i];
-            eid[e] = rq_id[i];
+            for (int w = 0; w < W; ++w) c[w] = 0;
         }
+        if (a.counters || STAMPS) {
+            uint32_t pc = (uint32_t)__popcll(pend);
 #pragma unroll
-        for (int e = 0; e < E; ++e) d[e] = exact_dist<M>(a.lut32 + s_base[ls[e]], c[e], PLAIN);
+            for (int off = 32; off > 0; off >>= 1) pc += (uint32_t)__shfl_xor((int)pc, off, 64);
+            if (a.counters && lane == 0) atomicAdd(wg_checks, pc);
+            if constexpr (STAMPS) st[kStEntries] += pc;
+        }
+        while (__ballot(pend != 0)) {
+            int ls[2];
+            bool has[2];
+            float d[2];
 #pragma unroll
-        for (int e = 0; e < E; ++e) {
-            const uint64_t key = make_key(d[e], eid[e]);
-            if (lane + 64 * e < n && key <= s_thr[ls[e]]) {
-                const uint32_t li = atomicAdd(&wg_count[ls[e]], 1u);
-                if (li < (uint32_t)a.region_cap)
-                    a.cand_key[(size_t)(slot0 + ls[e]) * a.cand_stride + region0 + li] = key;
+            for (int e = 0; e < 2; ++e) {
+                has[e] = pend != 0;
+                ls[e] = has[e] ? bit_slot(__ffsll((unsigned long long)pend) - 1) : 0;
+                pend &= pend - 1;  // 0 stays 0
+            }
+#pragma unroll
+            for (int e = 0; e < 2; ++e) d[e] = has[e] ? exact_dist<M>(a.lut32 + s_base[ls[e]], c, PLAIN) : 0.0f;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const uint64_t key = make_key(d[e], eid);
+                if (has[e] && key <= s_thr[ls[e]]) {
+                    const uint32_t li = atomicAdd(&wg_count[ls[e]], 1u);
+                    if (li < (uint32_t)a.region_cap)
+                        a.cand_key[(size_t)(slot0 + ls[e]) * a.cand_stride + region0 + li] = key;
+                }
             }
         }
+        rq_head += n;
+        rq_head = rq_head >= QCAP ? rq_head - QCAP : rq_head;
+        rq_n -= n;
+        if constexpr (STAMPS) st[kStRefines] += 1;
         __builtin_amdgcn_wave_barrier();
     };
 
@@ -569,6 +642,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanArgs a) {
         if (s >= a.n_seg_pass) break;
         const uint32_t seg = (uint32_t)__builtin_amdgcn_readfirstlane(a.seg_list ? (int)a.seg_list[s] : s);
         if (!PLAIN) dec.begin_segment(a.img, seg, lane);
+        stamp(kStSegment);
         for (int c = 0; c < cps; ++c) {
             const int64_t node = ((int64_t)seg * cps + c) * 64 + lane;  // local position
             uint32_t code[W];
@@ -577,8 +651,14 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanArgs a) {
                 for (int w = 0; w < W; ++w)
                     code[w] = reinterpret_cast<const uint32_t*>(a.img.raw)[(size_t)node * W + w];
             } else {
-                dec.step(a.img, node, lane, lt_mask, dtab, c + 1 < cps, code);
+                dec.step(a.img, node, lane, lt_mask, c + 1 < cps, code);
             }
+            if constexpr (STAMPS) {
+                st[kStSteps] += 1;
+                // the decode's result must exist before its section ends
+                asm volatile("" ::"v"(code[0]), "v"(code[W - 1]));
+            }
+            stamp(kStDecode);
 
             // ---- ADC lower bound: M LDS gathers per 4 * F queries; the fields of a dword are
             // summed with 3-input integer adds (no carry can cross a field) ----
@@ -605,6 +685,11 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanArgs a) {
                 acc[4 * g + 2] = sz;
                 acc[4 * g + 3] = sw;
             }
+            if constexpr (STAMPS) {
+#pragma unroll
+                for (int i = 0; i < NA; ++i) asm volatile("" ::"v"(acc[i]));
+            }
+            stamp(kStGather);
             // ---- filter (replaces the heap test h:2909-2914): the top bit of a field rejects.
             // Fold the top bits of the NA accumulators into one pending mask per lane (bit = local slot):
             // shift-and-insert with one mask constant, accumulator j of a mask dword ends at bit j of
@@ -619,33 +704,31 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanArgs a) {
                 fail >>= EB - C::J;
                 pend |= (uint64_t)(valid ? (~fail & live) : 0u) << (32 * h);
             }
-            if (__any(pend != 0)) {
-                // ---- queue what the filter let through: one (node, query) pair per lane and round;
-                // a full queue is checked exactly by all 64 lanes at once ----
-                const uint32_t id = a.img.id_base + (uint32_t)node;
-                do {
-                    const bool has = pend != 0;
-                    const int p = has ? __ffsll((unsigned long long)pend) - 1 : 0;
-                    const uint64_t pushing = __ballot(has);  // never 0 here
-                    const int pos = rq_n + (int)mbcnt64(pushing, 0);
-                    if (has && pos < C::RQ) {
-                        pend &= pend - 1;
-                        const int ls = (p >> 5) * (C::J * F) + ((p & 31) / EB) * C::J + (p % EB);  // bit -> local slot
+            const uint64_t pushing = __ballot(pend != 0);
+            stamp(kStFold);
+            if (pushing) {
+                // ---- queue the nodes the filter let through for some query: (code, id, survivor mask) ----
+                const int cnt = (int)__popcll(pushing);
+                while (rq_n + cnt > QCAP) {
+                    refine(min(rq_n, 64));
+                    stamp(kStRefine);
+                }
+                if (pend != 0) {
+                    int pos = rq_head + rq_n + (int)mbcnt64(pushing, 0);
+                    pos = pos >= QCAP ? pos - QCAP : pos;
 #pragma unroll
-                        for (int w = 0; w < W; ++w) rq_code[pos * W + w] = code[w];
-                        rq_id[pos] = id;
-                        rq_slot[pos] = (uint8_t)ls;
-                    }
-                    rq_n = min(C::RQ, rq_n + (int)__popcll(pushing));
-                    if (rq_n == C::RQ) {
-                        refine(C::RQ);
-                        rq_n = 0;
-                    }
-                } while (__any(pend != 0));
+                    for (int w = 0; w < W; ++w) rq_code[pos * W + w] = code[w];
+                    rq_id[pos] = a.img.id_base + (uint32_t)node;
+                    rq_mask[pos * MD] = (uint32_t)pend;
+                    if constexpr (MD == 2) rq_mask[pos * MD + 1] = (uint32_t)(pend >> 32);
+                }
+                rq_n += cnt;
+                stamp(kStPush);
             }
         }
     }
-    if (rq_n > 0) refine(rq_n);
+    while (rq_n > 0) refine(min(rq_n, 64));
+    stamp(kStRefine);
 
     // ---- epilogue: this workgroup's candidate counts (a count above region_cap tells the select
     // kernel that candidates were dropped) ----
@@ -660,6 +743,12 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanArgs a) {
             atomicAdd(&a.counters[0], (unsigned long long)*wg_checks);
             atomicAdd(&a.counters[1], (unsigned long long)c);
         }
+    }
+    if constexpr (STAMPS) {
+        st[kStTotal] = __builtin_amdgcn_s_memtime() - t_start;
+        st[kStWaves] = 1;
+        if (a.stamps && lane == 0)
+            for (int i = 0; i < kStCount; ++i) atomicAdd(&a.stamps[i], (unsigned long long)st[i]);
     }
 }
 
@@ -1028,24 +1117,27 @@ __global__ __launch_bounds__(256) void encode_pq_kernel(const float* __restrict_
 // launchers
 // ---------------------------------------------------------------------------
 
+// hipFuncSetAttribute is per device; handles may live on several GPUs
+static hipError_t ensure_dynamic_lds(const void* fn, size_t bytes, std::atomic<bool>* done) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 0 || dev >= 64 || !done[dev].load(std::memory_order_acquire)) {
+        e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e != hipSuccess) return e;
+        if (dev >= 0 && dev < 64) done[dev].store(true, std::memory_order_release);
+    }
+    return hipSuccess;
+}
+
 hipError_t launch_encode_pq(const float* d_vectors, int64_t n, int D, const float* d_codebook, int M, int K, int Ds,
                             uint8_t* d_codes, hipStream_t stream) {
     if (n <= 0) return hipSuccess;
     const size_t lds = ((size_t)K * Ds + (size_t)Ds * 256) * sizeof(float);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
-    static bool done[64] = {};
-    hipError_t e = hipSuccess;
-    {
-        int dev = 0;
-        e = hipGetDevice(&dev);
-        if (e != hipSuccess) return e;
-        if (dev < 0 || dev >= 64 || !done[dev]) {
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&encode_pq_kernel),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            if (e != hipSuccess) return e;
-            if (dev >= 0 && dev < 64) done[dev] = true;
-        }
-    }
+    static std::atomic<bool> done[64] = {};
+    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&encode_pq_kernel), 160 * 1024, done);
+    if (e != hipSuccess) return e;
     hipLaunchKernelGGL(encode_pq_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)M), dim3(256), lds, stream,
                        d_vectors, n, D, d_codebook, M, K, Ds, d_codes);
     return hipGetLastError();
@@ -1060,19 +1152,6 @@ size_t select_lds_bytes(int M, int top_k, int n_shared) {
     const size_t n_keys = n_shared > 0 ? (size_t)std::min(n_shared, kSortMax) : (size_t)kSortMax;
     const size_t select_bytes = kp * 8 + 266 * 4, table_bytes = n_shared > 0 ? (size_t)M * 256 * 4 : 0;
     return n_keys * 8 + std::max(select_bytes, table_bytes) + 16;
-}
-
-// hipFuncSetAttribute is per device; handles may live on several GPUs
-static hipError_t ensure_dynamic_lds(const void* fn, size_t bytes, bool* done) {
-    int dev = 0;
-    hipError_t e = hipGetDevice(&dev);
-    if (e != hipSuccess) return e;
-    if (dev < 0 || dev >= 64 || !done[dev]) {
-        e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-        if (e != hipSuccess) return e;
-        if (dev >= 0 && dev < 64) done[dev] = true;
-    }
-    return hipSuccess;
 }
 
 hipError_t launch_lut_build(const float* d_codebook, const float* d_queries, int nq, int n_slots, int M, int K, int Ds,
@@ -1100,29 +1179,52 @@ hipError_t launch_decode_segments(const DeviceImage& img, const uint32_t* seg_li
     return hipGetLastError();
 }
 
-template <int M, bool PLAIN>
+template <int M, bool PLAIN, bool STAMPS>
 static hipError_t launch_scan_m(const ScanArgs& a, int n_slot_groups, int splits, hipStream_t stream) {
-    static bool done[64] = {};
-    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&scan_kernel<M, PLAIN>), scan_lds_bytes(M), done);
+    static std::atomic<bool> done[64] = {};
+    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&scan_kernel<M, PLAIN, STAMPS>), scan_lds_bytes(M), done);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((scan_kernel<M, PLAIN>), dim3((unsigned)splits, (unsigned)n_slot_groups), dim3(kScanThreads),
-                       scan_lds_bytes(M), stream, a);
+    hipLaunchKernelGGL((scan_kernel<M, PLAIN, STAMPS>), dim3((unsigned)splits, (unsigned)n_slot_groups),
+                       dim3(kScanThreads), scan_lds_bytes(M), stream, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_quantise(const ScanArgs& a, int n_slot_groups, hipStream_t stream) {
+    if (n_slot_groups <= 0) return hipSuccess;
+    if (!a.qtab) return hipErrorInvalidValue;
+    if (a.img.M == 8)
+        hipLaunchKernelGGL(quantise_kernel<8>, dim3((unsigned)(Cfg<8>::NG * 8), (unsigned)n_slot_groups), dim3(256), 0,
+                           stream, a);
+    else if (a.img.M == 16)
+        hipLaunchKernelGGL(quantise_kernel<16>, dim3((unsigned)(Cfg<16>::NG * 16), (unsigned)n_slot_groups), dim3(256),
+                           0, stream, a);
+    else
+        return hipErrorInvalidValue;
     return hipGetLastError();
 }
 
 hipError_t launch_scan(const ScanArgs& a, int n_slot_groups, int splits, hipStream_t stream) {
     if (a.n_seg_pass <= 0 || n_slot_groups <= 0) return hipSuccess;
+    if (!a.qtab) return hipErrorInvalidValue;
     const bool plain = a.img.raw != nullptr;
-    if (a.img.M == 8) return plain ? launch_scan_m<8, true>(a, n_slot_groups, splits, stream)
-                                   : launch_scan_m<8, false>(a, n_slot_groups, splits, stream);
-    if (a.img.M == 16) return plain ? launch_scan_m<16, true>(a, n_slot_groups, splits, stream)
-                                    : launch_scan_m<16, false>(a, n_slot_groups, splits, stream);
+    if (a.stamps) {  // diagnostic instantiation (M = 8 only)
+        if (a.img.M != 8) return hipErrorInvalidValue;
+        return plain ? launch_scan_m<8, true, true>(a, n_slot_groups, splits, stream)
+                     : launch_scan_m<8, false, true>(a, n_slot_groups, splits, stream);
+    }
+    if (a.img.M == 8) return plain ? launch_scan_m<8, true, false>(a, n_slot_groups, splits, stream)
+                                   : launch_scan_m<8, false, false>(a, n_slot_groups, splits, stream);
+    if (a.img.M == 16) return plain ? launch_scan_m<16, true, false>(a, n_slot_groups, splits, stream)
+                                    : launch_scan_m<16, false, false>(a, n_slot_groups, splits, stream);
     return hipErrorInvalidValue;
 }
 
+size_t qtab_bytes_per_group(int M) { return M <= 8 ? ScanLds<8>::kTables : ScanLds<16>::kTables; }
+int scan_stamp_count() { return kStCount; }
+
 template <int M, int THREADS>
 static hipError_t launch_select_m(const SelectArgs& a, int n_slots, hipStream_t stream) {
-    static bool done[64] = {};
+    static std::atomic<bool> done[64] = {};
     hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&select_kernel<M, THREADS>),
                                       select_lds_bytes(M, kMaxTopK, kSortMax), done);
     if (e != hipSuccess) return e;
@@ -1146,7 +1248,7 @@ hipError_t launch_merge(const int32_t* d_ids, const float* d_dists, int n_lists,
     while (p2 < n) p2 <<= 1;
     const size_t lds = (size_t)p2 * sizeof(uint64_t);
     if (lds > 128 * 1024) return hipErrorInvalidValue;
-    static bool done[64] = {};
+    static std::atomic<bool> done[64] = {};
     hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&merge_kernel), 128 * 1024, done);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(merge_kernel, dim3((unsigned)nq), dim3(kSelectThreads), lds, stream, d_ids, d_dists, n_lists,

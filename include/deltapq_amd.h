@@ -83,7 +83,13 @@ typedef struct dpq_open_opts {
     int32_t chunks_per_segment; /* 64-node chunks per independently decodable segment; 0 = default (2) */
     int32_t cand_capacity;      /* candidate keys per query and cascade level, shared out evenly to the scan
                                  * workgroups of the query's group; 0 = auto (16 K keys, >= 256 per workgroup) */
-    int32_t reserved[3];
+    int32_t num_codes;          /* 0 = the whole index; n > 0 = scan only the first n codes of it, the reference's `-N`
+                                 * smaller than the header's n_codes (h:2825-2829 "scan only part of the codes").
+                                 * Odd n: exactly the reference's result.  Even n: the reference reads the pair byte of
+                                 * node n-1 as a whole-byte depth (>= 16: a stack row out of bounds, undefined); this
+                                 * build decodes node n-1 with its real depth and reports it with id n, as the trailing
+                                 * rule (h:2949, 2970) does for an index of n codes. */
+    int32_t reserved[2];
 } dpq_open_opts;
 
 typedef struct dpq_info {
@@ -112,6 +118,7 @@ typedef struct dpq_profile {
     int64_t overflow_reruns;           /* queries that needed a second final pass (candidate overflow) */
     int64_t exact_checks;              /* (code, query) pairs the filter let through, checked exactly in the scan */
     int64_t candidates;                /* pairs that passed the exact check (counted with dpq_profile_enable(idx, 1) only) */
+    double quantise_ms;                /* filter-table builds (one per scan launch; dpq_profile_enable(idx, 1) only) */
 } dpq_profile;
 
 typedef struct dpq_dtc_stats {
