@@ -15,14 +15,15 @@ P = ctypes.POINTER
 
 class OpenOpts(ctypes.Structure):
     _fields_ = [("device", c_i32), ("shard_rank", c_i32), ("shard_count", c_i32), ("chunks_per_segment", c_i32),
-                ("cand_capacity", c_i32), ("num_codes", c_i32), ("reserved", c_i32 * 2)]
+                ("cand_capacity", c_i32), ("num_codes", c_i32), ("bootstrap", c_i32), ("reserved", c_i32 * 1)]
 
 
 class Info(ctypes.Structure):
     _fields_ = [("n_codes_total", c_i64), ("n_bytes_total", c_i64), ("node_lo", c_i64), ("node_hi", c_i64),
                 ("algorithmic_bytes", c_i64), ("device_bytes", c_i64), ("n_diffs", c_i64), ("M", c_i32),
                 ("K", c_i32), ("Ds", c_i32), ("n_segments", c_i32), ("chunks_per_segment", c_i32),
-                ("max_depth", c_i32), ("device", c_i32), ("cand_capacity", c_i32)]
+                ("max_depth", c_i32), ("device", c_i32), ("cand_capacity", c_i32), ("bootstrap_bytes", c_i64),
+                ("bootstrap_stride", c_i32), ("reserved", c_i32)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

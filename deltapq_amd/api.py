@@ -77,17 +77,18 @@ def dtc_encode(root, depths, masks, deltas, M=8):
 class HostSoA:
     """The transcoded structure-of-arrays image, built on the host (no GPU)."""
 
-    def __init__(self, payload, n_codes, M=8, shard_rank=0, shard_count=1, chunks_per_segment=0, num_codes=0):
+    def __init__(self, payload, n_codes, M=8, shard_rank=0, shard_count=1, chunks_per_segment=0, num_codes=0,
+                 multi_index_stride=0):
         lib = _lib.load()
         pl = np.ascontiguousarray(payload, dtype=np.uint8)
-        opts = OpenOpts(0, shard_rank, shard_count, chunks_per_segment, 0, num_codes)
+        opts = OpenOpts(0, shard_rank, shard_count, chunks_per_segment, 0, num_codes, multi_index_stride)
         h = ctypes.c_void_p()
         check(lib.dpq_soa_build(_np_ptr(pl), pl.size, n_codes, M, opts, h), "dpq_soa_build")
         self._h = h
         info = Info()
         check(lib.dpq_soa_info(h, info), "dpq_soa_info")
         self.info = info.as_dict()
-        names = ["nib", "mask", "delta", "seg_delta_off", "seg_ckpt"]
+        names = ["nib", "mask", "delta", "seg_delta_off", "seg_ckpt", "mi_cell_start", "mi_code", "mi_id"]
         for which, name in enumerate(names):
             ptr, nb = ctypes.c_void_p(), _lib.c_i64()
             check(lib.dpq_soa_array(h, which, ptr, nb), "dpq_soa_array")
@@ -95,6 +96,8 @@ class HostSoA:
             arr = np.frombuffer(buf, dtype=np.uint8).copy()
             if name == "seg_delta_off":
                 arr = arr.view(np.uint64)
+            if name.startswith("mi_"):
+                arr = arr.view(np.uint32)
             setattr(self, name, arr)
         lib.dpq_soa_free(h)
         self._h = None
@@ -201,31 +204,32 @@ class DeltaPQIndex:
 
     @classmethod
     def open_file(cls, path, M=8, K=256, device=0, shard_rank=0, shard_count=1, chunks_per_segment=0,
-                  cand_capacity=0, num_codes=0):
-        """num_codes > 0: scan only the first num_codes codes (the reference's -N below the header's n_codes)."""
+                  cand_capacity=0, num_codes=0, bootstrap=0):
+        """num_codes > 0: scan only the first num_codes codes (the reference's -N below the header's n_codes).
+        bootstrap: 0 auto, 1 on, -1 off (dpq_open_opts.bootstrap)."""
         lib = _lib.load()
-        opts = OpenOpts(device, shard_rank, shard_count, chunks_per_segment, cand_capacity, num_codes)
+        opts = OpenOpts(device, shard_rank, shard_count, chunks_per_segment, cand_capacity, num_codes, bootstrap)
         h = ctypes.c_void_p()
         check(lib.dpq_open_file(path.encode(), M, K, opts, h), "dpq_open_file")
         return cls(h)
 
     @classmethod
     def open_memory(cls, payload, n_codes, M=8, K=256, device=0, shard_rank=0, shard_count=1, chunks_per_segment=0,
-                    cand_capacity=0, num_codes=0):
+                    cand_capacity=0, num_codes=0, bootstrap=0):
         lib = _lib.load()
         pl = np.ascontiguousarray(payload, dtype=np.uint8)
-        opts = OpenOpts(device, shard_rank, shard_count, chunks_per_segment, cand_capacity, num_codes)
+        opts = OpenOpts(device, shard_rank, shard_count, chunks_per_segment, cand_capacity, num_codes, bootstrap)
         h = ctypes.c_void_p()
         check(lib.dpq_open_memory(_np_ptr(pl), pl.size, n_codes, M, K, opts, h), "dpq_open_memory")
         return cls(h)
 
     @classmethod
     def open_plain(cls, codes, K=256, device=0, shard_rank=0, shard_count=1, chunks_per_segment=0, cand_capacity=0,
-                   num_codes=0):
+                   num_codes=0, bootstrap=0):
         """Uncompressed comparator index (`-task pqscan`, h:2590-2678): raw codes, fp32-accumulated distances."""
         lib = _lib.load()
         c = np.ascontiguousarray(codes, dtype=np.uint8)
-        opts = OpenOpts(device, shard_rank, shard_count, chunks_per_segment, cand_capacity, num_codes)
+        opts = OpenOpts(device, shard_rank, shard_count, chunks_per_segment, cand_capacity, num_codes, bootstrap)
         h = ctypes.c_void_p()
         check(lib.dpq_open_plain_memory(_np_ptr(c), c.shape[0], c.shape[1], K, opts, h), "dpq_open_plain_memory")
         return cls(h)

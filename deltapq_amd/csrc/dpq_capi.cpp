@@ -93,6 +93,9 @@ struct dpq_index {
     uint8_t *d_nib = nullptr, *d_mask = nullptr, *d_delta = nullptr, *d_ckpt = nullptr, *d_raw = nullptr;
     bool plain = false;  // uncompressed comparator index (fp32-accumulate rule, no id quirk)
     uint64_t* d_seg_off = nullptr;
+    // threshold bootstrap: inverted multi-index over the shard's nodes (dpq::SoA::mi_*); boot = it is in use
+    uint32_t *d_mi_cell = nullptr, *d_mi_code = nullptr, *d_mi_id = nullptr;
+    bool boot = false;
     float* d_codebook = nullptr;
     // workspace, sized for ws_slots padded queries and ws_cap candidates each
     int ws_slots = 0, ws_cap = 0;
@@ -217,7 +220,30 @@ int ensure_plan(dpq_index* x, int top_k, int cap, int coarse) {
     const int64_t nseg = x->img.n_segments;
     const int64_t s0 = std::min<int64_t>(nseg, std::max<int64_t>(1, dpq::kLevel0Nodes / S));
     std::vector<int64_t> bounds;
-    if (s0 >= nseg) {
+    if (x->boot) {
+        // The bootstrap kernel delivers the first threshold (no segments consumed: level 0 is empty), as tight
+        // as the k-th of a spread sample of a quarter of a 1 M-node index; the filter levels then cover ALL
+        // segments.  One level up to 2 M nodes; beyond, levels growing by 8 (a larger shard's first threshold
+        // admits more nodes in absolute terms).  DPQ_PLAN_RATIOS=a[,b[,c]] forces extra levels for experiments.
+        bounds.push_back(nseg);
+        std::vector<int> ratios;
+        int forced[3] = {0, 0, 0};
+        if (const char* ev = getenv("DPQ_PLAN_RATIOS")) sscanf(ev, "%d,%d,%d", &forced[0], &forced[1], &forced[2]);
+        if (forced[0] >= 2) {
+            for (int f : forced)
+                if (f >= 2) ratios.push_back(f);
+        } else {
+            for (int64_t b = nseg; b * S > ((int64_t)2 << 20); b /= 8) ratios.push_back(8);
+        }
+        int64_t b = nseg;
+        for (int r : ratios) {
+            b /= r;
+            if (b < 1) break;
+            bounds.push_back(b);
+        }
+        bounds.push_back(0);
+        std::reverse(bounds.begin(), bounds.end());
+    } else if (s0 >= nseg) {
         bounds.push_back(nseg);
     } else {
         bounds.push_back(nseg);
@@ -261,7 +287,7 @@ int ensure_plan(dpq_index* x, int top_k, int cap, int coarse) {
         if (rc) return rc;
         DPQ_HIP(hipMemcpy(x->d_order, order.data(), (size_t)nseg * sizeof(uint32_t), hipMemcpyHostToDevice));
     }
-    if (nseg > 0 && x->l0_segments != (int)s0) {
+    if (!x->boot && nseg > 0 && x->l0_segments != (int)s0) {
         hipFree(x->d_l0_id);
         hipFree(x->d_l0_code);
         x->d_l0_id = x->d_l0_code = nullptr;
@@ -395,6 +421,7 @@ int run_batch(dpq_index* x, const float* d_queries, int nq, int top_k, int32_t* 
     se.out_dists = d_dists;
     se.n_codes_total = x->plain ? -1 : x->img.n_codes_total;
     se.fp32_accum = x->plain ? 1 : 0;
+    se.keep_thr = x->boot ? 1 : 0;
 
     const int64_t S = (int64_t)dpq::kChunk * x->img.chunks_per_segment;
     const size_t n_levels = x->img.n_segments > 0 ? x->level_cnt.size() : 0;
@@ -405,6 +432,28 @@ int run_batch(dpq_index* x, const float* d_queries, int nq, int top_k, int32_t* 
     }
     for (size_t l = 0; l < n_levels; ++l) {
         const bool final_pass = l + 1 == n_levels;
+        if (l == 0 && x->boot) {
+            // level 0 with a multi-index: the nodes of the query's best cells, evaluated exactly -> first threshold
+            static const int cap_env = getenv("DPQ_BOOT_CAP") ? atoi(getenv("DPQ_BOOT_CAP")) : 0;
+            dpq::BootArgs ba{};
+            ba.cell_start = x->d_mi_cell;
+            ba.mi_code = x->d_mi_code;
+            ba.mi_id = x->d_mi_id;
+            ba.lut32 = x->d_lut32;
+            ba.slot_query = nullptr;
+            ba.top_k = top_k;
+            ba.cap = cap_env > 0 ? std::max(cap_env, top_k) : std::max(top_k <= 256 ? 3072 : 8192, top_k);
+            ba.target = ba.cap;
+            ba.thr_key = x->d_thr_key;
+            ba.cand_count = x->d_cand_count;
+            ba.fp32_accum = x->plain ? 1 : 0;
+            {
+                Timer t(x, stream, 2);
+                DPQ_HIP(dpq::launch_bootstrap(ba, x->M, nq, stream));
+            }
+            if (x->prof) x->prof_acc.select_launches++;
+            continue;
+        }
         if (l == 0) {
             // level 0: the pre-decoded, query-independent list; every query evaluates it exactly
             se.shared_id = x->d_l0_id;
@@ -568,8 +617,13 @@ int open_from_payload(const uint8_t* payload, int64_t n_bytes, int64_t n_codes, 
 
     dpq::SoA soa;
     std::string err;
+    // threshold bootstrap: auto = on from 256 K nodes per shard (estimated before the byte-balanced cut)
+    const int64_t n_scan = o.num_codes > 0 ? std::min<int64_t>(o.num_codes, n_codes) : n_codes;
+    const int64_t per_shard = n_scan / std::max(1, o.shard_count);
+    int mi_stride = o.bootstrap < 0 ? 0 : dpq::bootstrap_stride_for(per_shard);
+    if (o.bootstrap > 0 && mi_stride == 0 && per_shard >= 16384) mi_stride = 1;  // forced on (tests, experiments)
     int rc = dpq::transcode(payload, n_bytes, n_codes, M, o.shard_rank, o.shard_count, o.chunks_per_segment, &soa,
-                            &err, o.num_codes);
+                            &err, o.num_codes, mi_stride);
     if (rc) return fail(rc, err);
 
     DPQ_HIP(hipSetDevice(o.device));
@@ -594,6 +648,12 @@ int open_from_payload(const uint8_t* payload, int64_t n_bytes, int64_t n_codes, 
     if (!rc) rc = up(&x->d_delta, soa.delta.data(), soa.delta.size());
     if (!rc) rc = up(&x->d_seg_off, soa.seg_delta_off.data(), soa.seg_delta_off.size() * 8);
     if (!rc) rc = up(&x->d_ckpt, soa.seg_ckpt.data(), soa.seg_ckpt.size());
+    if (!rc && soa.mi_stride > 0 && (int64_t)soa.mi_id.size() >= 16384) {
+        rc = up(&x->d_mi_cell, soa.mi_cell_start.data(), soa.mi_cell_start.size() * 4);
+        if (!rc) rc = up(&x->d_mi_code, soa.mi_code.data(), soa.mi_code.size() * 4);
+        if (!rc) rc = up(&x->d_mi_id, soa.mi_id.data(), soa.mi_id.size() * 4);
+        x->boot = !rc;
+    }
     if (rc) {
         dpq_close(x);
         return rc;
@@ -618,6 +678,8 @@ int open_from_payload(const uint8_t* payload, int64_t n_bytes, int64_t n_codes, 
     inf.node_hi = soa.node_hi;
     inf.algorithmic_bytes = soa.algorithmic_bytes;
     inf.device_bytes = soa.device_bytes();
+    inf.bootstrap_bytes = x->boot ? soa.bootstrap_bytes() : 0;
+    inf.bootstrap_stride = x->boot ? soa.mi_stride : 0;
     inf.n_diffs = soa.n_diffs;
     inf.M = M;
     inf.K = K;
@@ -673,6 +735,37 @@ int open_plain(const uint8_t* codes, int64_t n_codes, int M, int K, const dpq_op
         dpq_close(x);
         return rc;
     }
+    {
+        int mi_stride = o.bootstrap < 0 ? 0 : dpq::bootstrap_stride_for(hi - lo);
+        if (o.bootstrap > 0 && mi_stride == 0 && hi - lo >= 16384) mi_stride = 1;
+        if (mi_stride > 0) {
+            dpq::SoA mi;
+            std::vector<uint32_t> ids;
+            std::vector<uint8_t> cds;
+            for (int64_t i = lo; i < hi; i += mi_stride) {
+                ids.push_back((uint32_t)i);
+                cds.insert(cds.end(), codes + (size_t)i * M, codes + (size_t)(i + 1) * M);
+            }
+            dpq::build_multi_index(ids, cds, M, mi_stride, &mi);
+            auto upl = [&](uint32_t** d, const std::vector<uint32_t>& v) -> int {
+                int r = dev_alloc(d, v.size() + 16);
+                if (r) return r;
+                if (!v.empty() && hipMemcpy(*d, v.data(), v.size() * 4, hipMemcpyHostToDevice) != hipSuccess)
+                    return fail(DPQ_ERR_HIP, "upload of the bootstrap multi-index failed");
+                return DPQ_OK;
+            };
+            rc = upl(&x->d_mi_cell, mi.mi_cell_start);
+            if (!rc) rc = upl(&x->d_mi_code, mi.mi_code);
+            if (!rc) rc = upl(&x->d_mi_id, mi.mi_id);
+            if (rc) {
+                dpq_close(x);
+                return rc;
+            }
+            x->boot = true;
+            x->info.bootstrap_bytes = mi.bootstrap_bytes();
+            x->info.bootstrap_stride = mi_stride;
+        }
+    }
     x->img.raw = x->d_raw;
     x->img.n_local = hi - lo;
     x->img.n_codes_total = n_codes;
@@ -706,6 +799,8 @@ void fill_info_from_soa(const dpq::SoA& s, dpq_info* inf) {
     inf->node_hi = s.node_hi;
     inf->algorithmic_bytes = s.algorithmic_bytes;
     inf->device_bytes = s.device_bytes();
+    inf->bootstrap_bytes = s.bootstrap_bytes();
+    inf->bootstrap_stride = s.mi_stride;
     inf->n_diffs = s.n_diffs;
     inf->M = s.M;
     inf->n_segments = (int32_t)s.n_segments;
@@ -809,7 +904,7 @@ int dpq_soa_build(const uint8_t* payload, int64_t n_bytes, int64_t n_codes, int 
     dpq_soa* s = new dpq_soa();
     std::string err;
     int rc = dpq::transcode(payload, n_bytes, n_codes, M, o.shard_rank, o.shard_count, o.chunks_per_segment, &s->soa,
-                            &err, o.num_codes);
+                            &err, o.num_codes, o.bootstrap > 0 && M % 4 == 0 ? o.bootstrap : 0);
     if (rc) {
         delete s;
         *out = nullptr;
@@ -838,7 +933,10 @@ int dpq_soa_array(const dpq_soa* soa, int which, const void** ptr, int64_t* n_by
         case 2: *ptr = s.delta.data(); *n_bytes = (int64_t)s.delta.size(); break;
         case 3: *ptr = s.seg_delta_off.data(); *n_bytes = (int64_t)s.seg_delta_off.size() * 8; break;
         case 4: *ptr = s.seg_ckpt.data(); *n_bytes = (int64_t)s.seg_ckpt.size(); break;
-        default: return fail(DPQ_ERR_ARG, "which must be 0..4");
+        case 5: *ptr = s.mi_cell_start.data(); *n_bytes = (int64_t)s.mi_cell_start.size() * 4; break;
+        case 6: *ptr = s.mi_code.data(); *n_bytes = (int64_t)s.mi_code.size() * 4; break;
+        case 7: *ptr = s.mi_id.data(); *n_bytes = (int64_t)s.mi_id.size() * 4; break;
+        default: return fail(DPQ_ERR_ARG, "which must be 0..7");
     }
     return DPQ_OK;
     });
@@ -1108,6 +1206,9 @@ int dpq_close(dpq_index* x) {
     hipFree(x->d_ckpt);
     hipFree(x->d_raw);
     hipFree(x->d_seg_off);
+    hipFree(x->d_mi_cell);
+    hipFree(x->d_mi_code);
+    hipFree(x->d_mi_id);
     hipFree(x->d_codebook);
     hipFree(x->d_order);
     hipFree(x->d_l0_id);

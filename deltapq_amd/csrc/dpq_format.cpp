@@ -147,7 +147,7 @@ int validate(const uint8_t* payload, int64_t n_bytes, int64_t n_codes, int M, dp
 }
 
 int transcode(const uint8_t* payload, int64_t n_bytes, int64_t n_codes, int M, int shard_rank, int shard_count,
-              int chunks_per_segment, SoA* out, std::string* err, int64_t scan_codes) {
+              int chunks_per_segment, SoA* out, std::string* err, int64_t scan_codes, int multi_index_stride) {
     int rc = check_args(payload, n_bytes, n_codes, M, err);
     if (rc) return rc;
     if (scan_codes < 0 || scan_codes > n_codes) {
@@ -225,6 +225,12 @@ int transcode(const uint8_t* payload, int64_t n_bytes, int64_t n_codes, int M, i
     o.delta.reserve((size_t)std::min<int64_t>(n_bytes, (o.node_hi - o.node_lo) * (int64_t)M / 2 + 64));
 
     std::vector<uint8_t> stack((size_t)levels * M, 0);  // vecs_stack (h:2858-2862)
+    std::vector<uint32_t> mi_ids;   // bootstrap sample: global position and decoded code of every stride-th node
+    std::vector<uint8_t> mi_codes;
+    if (multi_index_stride > 0) {
+        mi_ids.reserve((size_t)((o.node_hi - o.node_lo) / multi_index_stride + 1));
+        mi_codes.reserve((size_t)((o.node_hi - o.node_lo) / multi_index_stride + 1) * M);
+    }
     DtcWalker w(payload, n_bytes, n_codes, M);
     NodeRec r;
     while (!w.done()) {
@@ -259,8 +265,13 @@ int transcode(const uint8_t* payload, int64_t n_bytes, int64_t n_codes, int M, i
             o.algorithmic_bytes += r.payload_end - r.payload_begin;
             if (i > 0) o.n_diffs += r.n_diff;
             if (r.depth > o.max_depth) o.max_depth = r.depth;
+            if (multi_index_stride > 0 && l % multi_index_stride == 0) {
+                mi_ids.push_back((uint32_t)i);
+                mi_codes.insert(mi_codes.end(), cur, cur + M);
+            }
         }
     }
+    if (multi_index_stride > 0) build_multi_index(mi_ids, mi_codes, M, multi_index_stride, &o);
     if (w.done() && w.offset() != n_bytes) {
         if (err) {
             char msg[160];
@@ -273,6 +284,23 @@ int transcode(const uint8_t* payload, int64_t n_bytes, int64_t n_codes, int M, i
     o.seg_delta_off[(size_t)o.n_segments] = o.delta.size();
     o.delta.resize(o.delta.size() + 32, 0);  // lanes read up to 20 bytes past their first delta
     return DPQ_OK;
+}
+
+void build_multi_index(const std::vector<uint32_t>& ids, const std::vector<uint8_t>& codes, int M, int stride, SoA* out) {
+    const size_t n = ids.size(), W = (size_t)M / 4;
+    out->mi_stride = stride;
+    out->mi_cell_start.assign(65537, 0);
+    out->mi_code.assign(n * W, 0);
+    out->mi_id.assign(n, 0);
+    auto cell_of = [&](size_t e) { return (size_t)codes[e * M] | ((size_t)codes[e * M + 1] << 8); };
+    for (size_t e = 0; e < n; ++e) out->mi_cell_start[cell_of(e) + 1]++;
+    for (size_t c = 0; c < 65536; ++c) out->mi_cell_start[c + 1] += out->mi_cell_start[c];
+    std::vector<uint32_t> fill(out->mi_cell_start.begin(), out->mi_cell_start.end() - 1);
+    for (size_t e = 0; e < n; ++e) {  // stable: entries of a cell stay in DFS order
+        const size_t p = fill[cell_of(e)]++;
+        out->mi_id[p] = ids[e];
+        memcpy(&out->mi_code[p * W], &codes[e * M], (size_t)M);
+    }
 }
 
 // Writer: h:1765-1826 (M <= 8).  For M > 8 (this build's own extension, the

@@ -69,17 +69,35 @@ struct SoA {
     std::vector<uint8_t> delta;           // changed bytes, node order, ascending position; 16 bytes of tail padding
     std::vector<uint64_t> seg_delta_off;  // [n_segments + 1]
     std::vector<uint8_t> seg_ckpt;        // [n_segments][levels][M]: ancestor stack at the segment's first node
+    // Threshold bootstrap (DESIGN.md "bootstrap"): an inverted multi-index over every mi_stride-th node,
+    // cell = (code[0], code[1]).  A query evaluates the nodes of its best cells exactly and takes the k-th
+    // key as its first threshold -- as tight as a spread sample of a quarter of the index.  Empty = not built.
+    int mi_stride = 0;
+    std::vector<uint32_t> mi_cell_start;  // [65537] first entry of every cell
+    std::vector<uint32_t> mi_code;        // [entries][M / 4] decoded codes, cell-major
+    std::vector<uint32_t> mi_id;          // [entries] global DFS position
     int64_t nodes_per_segment() const { return (int64_t)kChunk * chunks_per_segment; }
     int64_t device_bytes() const {
         return (int64_t)(nib.size() + mask.size() + delta.size() + seg_delta_off.size() * 8 + seg_ckpt.size());
     }
+    int64_t bootstrap_bytes() const { return (int64_t)((mi_cell_start.size() + mi_code.size() + mi_id.size()) * 4); }
 };
 
 int validate(const uint8_t* payload, int64_t n_bytes, int64_t n_codes, int M, dpq_dtc_stats* stats, std::string* err);
 // scan_codes > 0: image of the first scan_codes nodes only (the reference's `-N` below the header's n_codes,
 // h:2825-2829); the stream is parsed with the header's n_codes (it decides which node owns a whole depth byte).
+// multi_index_stride > 0: also build the bootstrap multi-index over every multi_index_stride-th local node.
 int transcode(const uint8_t* payload, int64_t n_bytes, int64_t n_codes, int M, int shard_rank, int shard_count,
-              int chunks_per_segment, SoA* out, std::string* err, int64_t scan_codes = 0);
+              int chunks_per_segment, SoA* out, std::string* err, int64_t scan_codes = 0, int multi_index_stride = 0);
+// The bootstrap multi-index of a list of (global position, code) pairs: counting sort by cell.
+void build_multi_index(const std::vector<uint32_t>& ids, const std::vector<uint8_t>& codes, int M, int stride, SoA* out);
+// Nodes below which the bootstrap is not worth its tables (the spread-sample cascade serves small indexes), and
+// the sampling stride that keeps the multi-index at <= 4 M entries.
+constexpr int64_t kBootstrapMinNodes = 262144;
+inline int bootstrap_stride_for(int64_t n_local) {
+    if (n_local < kBootstrapMinNodes) return 0;
+    return (int)((n_local + (1 << 22) - 1) >> 22);
+}
 int encode(const uint8_t* root_code, const uint8_t* depths, const uint16_t* masks, const uint8_t* deltas,
            int64_t n_codes, int M, uint8_t* out, int64_t* n_bytes, std::string* err);
 

@@ -79,6 +79,22 @@ struct SelectArgs {
     float* out_dists;              // [nq][top_k]
     int64_t n_codes_total;         // N for the even-N id quirk of the DTC scan; odd (-1) for the plain scan
     int32_t fp32_accum;            // 1: plain-scan rule, distance accumulated in fp32 (h:2658-2662)
+    int32_t keep_thr;              // 1: thr_key = min(thr_key, this level's k-th key) (levels after a bootstrap)
+};
+
+// Threshold bootstrap from the inverted multi-index (see bootstrap_kernel).
+struct BootArgs {
+    const uint32_t* cell_start;    // [65537]
+    const uint32_t* mi_code;       // [entries][M / 4]
+    const uint32_t* mi_id;         // [entries] global DFS positions
+    const float* lut32;            // exact tables [query][m][256]
+    const int32_t* slot_query;     // slot -> query, NULL = identity, -1 = skip
+    int32_t top_k;
+    int32_t target;                // stop walking cells once this many nodes are evaluated
+    int32_t cap;                   // keys the block holds (LDS): target <= cap
+    uint64_t* thr_key;             // out [slots]
+    uint32_t* cand_count;          // [slots][kRegionStride]: region 0 (carried winners) is set to 0
+    int32_t fp32_accum;
 };
 
 // Builds the exact tables of queries [0, nq) and clears the candidate counters / overflow flags of
@@ -95,6 +111,7 @@ hipError_t launch_scan(const ScanArgs& a, int n_slot_groups, int splits, hipStre
 size_t qtab_bytes_per_group(int M);
 int scan_stamp_count();
 hipError_t launch_select(const SelectArgs& a, int M, int n_slots, hipStream_t stream);
+hipError_t launch_bootstrap(const BootArgs& a, int M, int n_slots, hipStream_t stream);
 hipError_t launch_merge(const int32_t* d_ids, const float* d_dists, int n_lists, int nq, int top_k, int32_t* d_out_ids,
                         float* d_out_dists, hipStream_t stream);
 // PQ encoding: codes[n][M] = argmin_k |v_m - c[m][k]|^2 in fp32.

@@ -43,6 +43,8 @@
 
 namespace dpq {
 
+static hipError_t ensure_dynamic_lds(const void* fn, size_t bytes, std::atomic<bool>* done);
+
 // ---------------------------------------------------------------------------
 // small device helpers
 // ---------------------------------------------------------------------------
@@ -1000,7 +1002,12 @@ __global__ __launch_bounds__(THREADS) void select_kernel(const SelectArgs a) {
 
     // The k-th smallest key seen so far bounds the final k-th key from above
     // (candidates are real nodes), so it is the next level's threshold.
-    if (tid == 0) a.thr_key[slot] = n_valid >= a.top_k ? kth : ~0ull;
+    if (tid == 0) {
+        uint64_t t = n_valid >= a.top_k ? kth : ~0ull;
+        // after a bootstrap the previous threshold's nodes are not among this level's keys: keep the tighter one
+        if (a.keep_thr) t = min(t, a.thr_key[slot]);
+        a.thr_key[slot] = t;
+    }
 
     // winners = the kk keys <= kth (keys are unique: the id is part of the key)
     int p2 = 1;
@@ -1035,6 +1042,160 @@ __global__ __launch_bounds__(THREADS) void select_kernel(const SelectArgs a) {
             a.out_dists[o] = INFINITY;
         }
     }
+}
+
+// ---------------------------------------------------------------------------
+// Threshold bootstrap (replaces cascade level 0 and the early filter levels on
+// indexes of >= 256 K nodes).  The index carries an inverted multi-index over
+// its nodes: cell = (code[0], code[1]), 65536 cells, entries = (global position,
+// decoded code).  A query ranks the 256 centroids of sub-spaces 0 and 1 by its
+// table rows, walks the cells (i-th best of sub-space 0, j-th best of
+// sub-space 1) in shells of growing max(i, j), evaluates the nodes it meets
+// EXACTLY (same distance rule and keys as everywhere else) until it has
+// `target` of them, and takes the k-th smallest key as its first threshold.
+// These are real nodes, so the threshold is a valid upper bound of the final
+// k-th key; being the best of the nodes nearest to the query in two of the
+// sub-spaces it is as tight as the k-th of a spread sample of a quarter of the
+// index (scripts/sim_bootstrap.py), at the cost of ~3 K exact evaluations.
+// Only the threshold leaves the kernel: the nodes are met again by the scan.
+// grid = slots, block = 512 threads.
+// ---------------------------------------------------------------------------
+constexpr int kBootThreads = 512;
+constexpr int kBootCells = 1024;  // cells per round (their prefix sums live in LDS)
+
+template <int M>
+__global__ __launch_bounds__(kBootThreads) void bootstrap_kernel(const BootArgs a) {
+    constexpr int W = Cfg<M>::W;
+    constexpr int TE = M * 256;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint64_t* keys = reinterpret_cast<uint64_t*>(smem);                                   // [cap]
+    float* T = reinterpret_cast<float*>(smem + (size_t)a.cap * 8);                        // [M][256] exact tables
+    uint32_t* pre = reinterpret_cast<uint32_t*>(T + TE);                                  // [kBootCells + 1] node prefix of the round's cells
+    uint16_t* ord = reinterpret_cast<uint16_t*>(pre + kBootCells + 1 + 1);                // [2][256] centroids by rank
+    uint32_t* hist = reinterpret_cast<uint32_t*>(ord + 512);                              // [264] radix-select scratch
+    uint32_t* bcast = hist + 264;                                                         // [2]
+    uint32_t* wave_sum = bcast + 2;                                                       // [8]
+
+    const int slot = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int q = a.slot_query ? a.slot_query[slot] : slot;
+    if (q < 0) return;
+    if (tid == 0) a.cand_count[(size_t)slot * kRegionStride] = 0;  // no carried winners: the scan meets every node again
+    {
+        const float4* src = reinterpret_cast<const float4*>(a.lut32 + (size_t)q * TE);
+        for (int i = tid; i < TE / 4; i += kBootThreads) reinterpret_cast<float4*>(T)[i] = src[i];
+    }
+    __syncthreads();
+    {   // rank the centroids of sub-spaces 0 and 1 (ties by index): thread -> (sub-space, centroid)
+        const int m = tid >> 8, kk = tid & 255;
+        const uint32_t mine = __float_as_uint(T[m * 256 + kk]);  // entries are >= 0 (or +inf beyond K): uint order = float order
+        int rank = 0;
+        for (int j = 0; j < 256; ++j) {
+            const uint32_t o = __float_as_uint(T[m * 256 + j]);
+            rank += (o < mine || (o == mine && j < kk)) ? 1 : 0;
+        }
+        ord[m * 256 + rank] = (uint16_t)kk;
+    }
+    __syncthreads();
+
+    // cell u of a round that starts at shell t0: shell t = floor(sqrt(u + t0^2)), position s = u + t0^2 - t^2 in it;
+    // s <= t: (i, j) = (t, s), else (s - t - 1, t)
+    auto cell_of = [&](int u, int t0) -> uint32_t {
+        const int v = u + t0 * t0;
+        int t = (int)sqrtf((float)v);
+        while (t * t > v) --t;
+        while ((t + 1) * (t + 1) <= v) ++t;
+        const int sft = v - t * t;
+        const int i = sft <= t ? t : sft - t - 1, j = sft <= t ? sft : t;
+        return (uint32_t)ord[i] | ((uint32_t)ord[256 + j] << 8);
+    };
+
+    int have = 0;  // keys so far (block-uniform)
+    int t0 = 0;
+    while (t0 < 256 && have < a.target) {
+        // shells [t0, t1): as many as fit kBootCells cells (one shell alone has at most 511)
+        int t1 = t0 + 1;
+        while (t1 < 256 && (t1 + 1) * (t1 + 1) - t0 * t0 <= kBootCells) ++t1;
+        const int n_cells = t1 * t1 - t0 * t0;
+        // node counts of the round's cells -> exclusive prefix in LDS
+        uint32_t cnt[kBootCells / kBootThreads], mine = 0;
+#pragma unroll
+        for (int r = 0; r < kBootCells / kBootThreads; ++r) {
+            const int u = tid * (kBootCells / kBootThreads) + r;
+            cnt[r] = 0;
+            if (u < n_cells) {
+                const uint32_t c = cell_of(u, t0);
+                cnt[r] = a.cell_start[c + 1] - a.cell_start[c];
+            }
+            mine += cnt[r];
+        }
+        uint32_t incl = mine;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t up = (uint32_t)__shfl_up((int)incl, off, 64);
+            if (lane >= off) incl += up;
+        }
+        if (lane == 63) wave_sum[wave] = incl;
+        __syncthreads();
+        uint32_t base = 0, total = 0;
+        for (int w = 0; w < kBootThreads / 64; ++w) {
+            if (w < wave) base += wave_sum[w];
+            total += wave_sum[w];
+        }
+        uint32_t run = base + incl - mine;
+#pragma unroll
+        for (int r = 0; r < kBootCells / kBootThreads; ++r) {
+            const int u = tid * (kBootCells / kBootThreads) + r;
+            if (u <= n_cells) pre[u] = run;  // pre[n_cells] = total (cnt of u >= n_cells is 0)
+            run += cnt[r];
+        }
+        __syncthreads();
+        // exact evaluation of the round's nodes, as many as the key list still takes
+        const int take = min((int)total, a.cap - have);
+        for (int v = tid; v < take; v += kBootThreads) {
+            int lo = 0, hi = n_cells;  // largest u with pre[u] <= v
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (pre[mid] <= (uint32_t)v) lo = mid; else hi = mid;
+            }
+            const uint32_t c = cell_of(lo, t0);
+            const size_t e = (size_t)a.cell_start[c] + ((uint32_t)v - pre[lo]);
+            uint32_t code[W];
+#pragma unroll
+            for (int w = 0; w < W; ++w) code[w] = a.mi_code[e * W + w];
+            keys[have + v] = make_key(exact_dist<M>(T, code, a.fp32_accum != 0), a.mi_id[e]);
+        }
+        have += take;
+        t0 = t1;
+        __syncthreads();  // pre / wave_sum are rewritten by the next round
+        if (have >= a.cap) break;
+    }
+    uint64_t kth = ~0ull;  // fewer than k nodes in the whole multi-index: no threshold
+    if (have >= a.top_k) kth = block_radix_select(keys, have, a.top_k, hist, bcast, tid, kBootThreads);
+    if (tid == 0) a.thr_key[slot] = kth;
+}
+
+size_t bootstrap_lds_bytes(int M, int cap) {
+    return (size_t)cap * 8 + (size_t)M * 256 * 4 + (kBootCells + 2) * 4 + 512 * 2 + (264 + 2 + 8) * 4;
+}
+
+hipError_t launch_bootstrap(const BootArgs& a, int M, int n_slots, hipStream_t stream) {
+    if (n_slots <= 0) return hipSuccess;
+    if (a.cap < a.top_k || a.cap > 16384 || !a.cell_start) return hipErrorInvalidValue;
+    const size_t lds = bootstrap_lds_bytes(M, a.cap);
+    if (M == 8) {
+        static std::atomic<bool> done[64] = {};
+        hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&bootstrap_kernel<8>), 160 * 1024, done);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(bootstrap_kernel<8>, dim3((unsigned)n_slots), dim3(kBootThreads), lds, stream, a);
+    } else if (M == 16) {
+        static std::atomic<bool> done[64] = {};
+        hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&bootstrap_kernel<16>), 160 * 1024, done);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(bootstrap_kernel<16>, dim3((unsigned)n_slots), dim3(kBootThreads), lds, stream, a);
+    } else {
+        return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------

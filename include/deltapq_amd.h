@@ -89,7 +89,12 @@ typedef struct dpq_open_opts {
                                  * node n-1 as a whole-byte depth (>= 16: a stack row out of bounds, undefined); this
                                  * build decodes node n-1 with its real depth and reports it with id n, as the trailing
                                  * rule (h:2949, 2970) does for an index of n codes. */
-    int32_t reserved[2];
+    int32_t bootstrap;          /* threshold bootstrap (an inverted multi-index over the shard's nodes, 12 B per
+                                 * sampled node, that gives every query a tight first threshold): 0 = automatic (on
+                                 * from 256 K nodes per shard), 1 = on (from 16 K nodes), -1 = off (the spread-sample
+                                 * cascade alone).  Results are identical either way.  dpq_soa_build: > 0 = build the
+                                 * multi-index with this sampling stride. */
+    int32_t reserved[1];
 } dpq_open_opts;
 
 typedef struct dpq_info {
@@ -105,6 +110,9 @@ typedef struct dpq_info {
     int32_t max_depth;
     int32_t device;
     int32_t cand_capacity;
+    int64_t bootstrap_bytes;   /* HBM bytes of the threshold-bootstrap multi-index (0 = not in use) */
+    int32_t bootstrap_stride;  /* every bootstrap_stride-th node is in it */
+    int32_t reserved;
 } dpq_info;
 
 /* Per-kernel device time accumulated since the last dpq_profile_reset, measured

@@ -177,3 +177,58 @@ def test_merge_topk_host(lib):
         cand.sort()
         assert [c[1] for c in cand[:k]] == mi[q].tolist()
         assert [c[0] for c in cand[:k]] == md[q].tolist()
+
+
+@pytest.mark.parametrize("stride,shards", [(1, 1), (3, 1), (2, 3)])
+def test_bootstrap_multi_index_layout(lib, stride, shards):
+    """The threshold-bootstrap multi-index: every stride-th local node exactly once, in the cell
+    (code[0], code[1]) of its decoded code, global DFS position attached, DFS order inside a cell."""
+    from deltapq_amd import api, synth
+    n = 6000
+    tree, payload, _ = make_case(n, seed=91)
+    codes = synth.decode_tree_codes(tree)
+    seen = []
+    for r in range(shards):
+        soa = api.HostSoA(payload, n, 8, shard_rank=r, shard_count=shards, multi_index_stride=stride)
+        lo, hi = soa.info["node_lo"], soa.info["node_hi"]
+        want = np.arange(lo, hi, stride)
+        cs, ids, cd = soa.mi_cell_start, soa.mi_id, soa.mi_code.view(np.uint8).reshape(-1, 8)
+        assert len(cs) == 65537 and cs[0] == 0 and cs[-1] == len(ids) == len(want) and np.all(np.diff(cs.astype(np.int64)) >= 0)
+        assert np.array_equal(np.sort(ids), want)
+        assert np.array_equal(cd, codes[ids])
+        cell = cd[:, 0].astype(np.int64) | (cd[:, 1].astype(np.int64) << 8)
+        assert np.all(np.diff(cell) >= 0)                                   # cell-major
+        assert np.array_equal(cs[cell], np.searchsorted(cell, cell, side="left"))
+        same = np.diff(cell) == 0
+        assert np.all(np.diff(ids.astype(np.int64))[same] > 0)              # DFS order inside a cell
+        assert soa.info["bootstrap_stride"] == stride and soa.info["bootstrap_bytes"] == 4 * (65537 + 3 * len(ids))
+        seen.append(ids)
+    assert len(np.unique(np.concatenate(seen))) == sum(len(s) for s in seen)
+
+
+@pytest.mark.parametrize("n_scan", [1, 2, 63, 64, 65, 999, 1000, 2500, 2501])
+def test_prefix_transcode(lib, n_scan):
+    """`-N` below the header's n_codes (h:2825-2829): the image holds the first n_scan nodes of the stream."""
+    from deltapq_amd import api, synth
+    n = 2501
+    tree, payload, _ = make_case(n, seed=17)
+    codes = synth.decode_tree_codes(tree)
+    for shards in (1, 2):
+        got = []
+        for r in range(shards):
+            soa = api.HostSoA(payload, n, 8, shard_rank=r, shard_count=shards, num_codes=n_scan)
+            assert soa.info["n_codes_total"] == n_scan
+            got.append((soa.info["node_lo"], soa.info["node_hi"], decode_soa(soa)))
+        assert got[0][0] == 0 and got[-1][1] == n_scan
+        assert np.array_equal(np.concatenate([g[2] for g in got]), codes[:n_scan])
+    with pytest.raises(api.DpqError):
+        api.HostSoA(payload, n, 8, num_codes=n + 1)
+
+
+def test_header_promising_more_nodes_than_bytes_is_refused(lib):
+    """A corrupt header must not size anything: n_codes far beyond what n_bytes can hold."""
+    from deltapq_amd import api
+    tree, payload, _ = make_case(100, seed=3)
+    with pytest.raises(api.DpqError) as e:
+        api.HostSoA(payload, 2_000_000_000, 8)
+    assert e.value.status in (-3, -1)

@@ -570,3 +570,81 @@ def test_adversarial_table_magnitudes(gpu, oracle):
         assert np.allclose(alld[pos], dists[i], rtol=1e-5, atol=0.0)        # every returned id carries its distance
         exact_rows += int(np.array_equal(dists[i].view(np.uint32), od.view(np.uint32)) and set(ids[i]) == set(oi))
     assert exact_rows >= nq - 2          # in practice still bit-identical almost always
+
+
+# (n_codes, n_queries, top_k, bootstrap option, dup_heavy)
+BOOT_CASES = [(300001, 40, 100, 0, False), (20000, 33, 10, 1, False), (70000, 20, 100, 1, True),
+              (400000, 24, 1000, 0, False), (262144, 16, 2048, 0, False)]
+
+
+@pytest.mark.parametrize("n,nq,k,boot,dup", BOOT_CASES)
+def test_threshold_bootstrap_gives_the_same_answer(gpu, oracle, codebook, n, nq, k, boot, dup):
+    """The first threshold comes from the query's best multi-index cells (bootstrap_kernel) instead of
+    the spread sample: identical results to the oracle and to the spread-sample cascade (bootstrap = -1)."""
+    from deltapq_amd import synth
+    tree, payload, nb = make_case(n, seed=n + 3, dup_heavy=dup)
+    qs = synth.make_queries(nq, 128, seed=n + 4)
+    ids, dists, prof, info = run(gpu, payload, n, codebook, qs, k, bootstrap=boot)
+    assert info["bootstrap_stride"] == 1 and info["bootstrap_bytes"] == 4 * (65537 + 3 * n)
+    ids0, dists0, _, info0 = run(gpu, payload, n, codebook, qs, k, bootstrap=-1)
+    assert info0["bootstrap_bytes"] == 0
+    assert np.array_equal(dists.view(np.uint32), dists0.view(np.uint32))
+    if not dup:
+        assert np.array_equal(ids, ids0)
+    sample = list(range(0, nq, 4))
+    assert_parity(ids[sample], dists[sample], oracle_topk(oracle, payload, n, codebook, qs[sample], k), n)
+    S = 64 * info["chunks_per_segment"]
+    assert prof["scan_node_query_pairs"] == info["n_segments"] * S * nq      # every node filtered exactly once
+
+
+def test_threshold_bootstrap_on_shards_and_plain_index(gpu, oracle, codebook):
+    """Shards carry their own multi-index with global positions; the plain comparator index builds it from the raw codes."""
+    from deltapq_amd import synth
+    n, nq, k = 700000, 16, 100
+    tree, payload, nb = make_case(n, seed=55)
+    qs = synth.make_queries(nq, 128, seed=56)
+    parts = []
+    for r in range(2):
+        ids, dists, _, info = run(gpu, payload, n, codebook, qs, k, shard_rank=r, shard_count=2)
+        assert info["bootstrap_stride"] == 1 and info["node_hi"] - info["node_lo"] >= 262144
+        parts.append((ids, dists))
+    mi, md = gpu.merge_topk_host(np.stack([p[0] for p in parts]), np.stack([p[1] for p in parts]))
+    assert_parity(mi, md, oracle_topk(oracle, payload, n, codebook, qs, k), n)
+    codes = synth.decode_tree_codes(tree)
+    outs = []
+    for boot in (0, -1):
+        with gpu.DeltaPQIndex.open_plain(codes, bootstrap=boot) as idx:
+            idx.set_codebook(codebook)
+            outs.append(idx.query_batch(qs, k) + (idx.info()["bootstrap_bytes"],))
+    assert outs[0][2] > 0 and outs[1][2] == 0
+    assert np.array_equal(outs[0][1].view(np.uint32), outs[1][1].view(np.uint32)) and np.array_equal(outs[0][0], outs[1][0])
+    for i in range(0, nq, 5):
+        lut = oracle.build_lut(codebook, qs[i])
+        oi, od = oracle.pqscan_plain(codes, lut, k)
+        assert np.array_equal(np.sort(outs[0][1][i]).view(np.uint32), np.sort(od).view(np.uint32))
+
+
+@pytest.mark.parametrize("n_scan", [1, 2, 129, 4095, 4096, 20001, 29998])
+def test_prefix_scan_minus_N_below_n_codes(gpu, oracle, codebook, n_scan):
+    """`-N` smaller than the header's n_codes (h:2825-2829).  Odd N: the reference's own result (the oracle
+    restates the loop bounds).  Even N: the reference reads a pair byte as a whole-byte depth (undefined);
+    this build answers like an index holding exactly the first N codes (trailing rule, id N)."""
+    from deltapq_amd import synth
+    n, nq = 30000, 12
+    k = min(10, n_scan)
+    tree, payload, _ = make_case(n, seed=77)
+    qs = synth.make_queries(nq, 128, seed=78)
+    ids, dists, _, info = run(gpu, payload, n, codebook, qs, k, num_codes=n_scan)
+    assert info["node_hi"] == n_scan and info["n_codes_total"] == n_scan
+    if n_scan % 2 == 1:
+        ref = oracle_topk(oracle, payload, n_scan, codebook, qs, k)          # scans the first n_scan codes of the long stream
+    else:
+        sub = dict(root=tree["root"], depths=tree["depths"][:n_scan], masks=tree["masks"][:n_scan], M=8,
+                   deltas=tree["deltas"][:int(sum(bin(int(m)).count("1") for m in tree["masks"][1:n_scan]))])
+        p2, _ = synth.encode_dtc(sub)
+        ref = oracle_topk(oracle, p2, n_scan, codebook, qs, k)
+    assert_parity(ids, dists, ref, n_scan)
+    # two shards of the prefix
+    parts = [run(gpu, payload, n, codebook, qs, k, num_codes=n_scan, shard_rank=r, shard_count=2)[:2] for r in range(2)]
+    mi, md = gpu.merge_topk_host(np.stack([p[0] for p in parts]), np.stack([p[1] for p in parts]))
+    assert_parity(mi, md, ref, n_scan)
