@@ -96,6 +96,7 @@ struct dpq_index {
     // threshold bootstrap: inverted multi-index over the shard's nodes (dpq::SoA::mi_*); boot = it is in use
     uint32_t *d_mi_cell = nullptr, *d_mi_code = nullptr, *d_mi_id = nullptr;
     bool boot = false;
+    unsigned long long* d_boot_stamps = nullptr;  // developer diagnostics (dpq_debug_boot_stamps)
     float* d_codebook = nullptr;
     // workspace, sized for ws_slots padded queries and ws_cap candidates each
     int ws_slots = 0, ws_cap = 0;
@@ -422,6 +423,7 @@ int run_batch(dpq_index* x, const float* d_queries, int nq, int top_k, int32_t* 
     se.n_codes_total = x->plain ? -1 : x->img.n_codes_total;
     se.fp32_accum = x->plain ? 1 : 0;
     se.keep_thr = x->boot ? 1 : 0;
+    se.stamps = x->d_boot_stamps ? x->d_boot_stamps + (size_t)kMaxBatchQueries * 8 : nullptr;
 
     const int64_t S = (int64_t)dpq::kChunk * x->img.chunks_per_segment;
     const size_t n_levels = x->img.n_segments > 0 ? x->level_cnt.size() : 0;
@@ -447,6 +449,7 @@ int run_batch(dpq_index* x, const float* d_queries, int nq, int top_k, int32_t* 
             ba.thr_key = x->d_thr_key;
             ba.cand_count = x->d_cand_count;
             ba.fp32_accum = x->plain ? 1 : 0;
+            ba.stamps = x->d_boot_stamps;
             {
                 Timer t(x, stream, 2);
                 DPQ_HIP(dpq::launch_bootstrap(ba, x->M, nq, stream));
@@ -1206,6 +1209,7 @@ int dpq_close(dpq_index* x) {
     hipFree(x->d_ckpt);
     hipFree(x->d_raw);
     hipFree(x->d_seg_off);
+    hipFree(x->d_boot_stamps);
     hipFree(x->d_mi_cell);
     hipFree(x->d_mi_code);
     hipFree(x->d_mi_id);
@@ -1498,6 +1502,55 @@ int dpq_debug_scan_stamps(dpq_index* x, int nq, int splits, unsigned long long* 
     hipFree(d_st);
     return DPQ_OK;
     });
+}
+
+// Developer hook (not in the public header): phase marks of the bootstrap kernel.  First call arms it
+// (allocates [2048][8] marks); later calls return the mean cycles between consecutive marks over `nq` slots
+// of the last batch: out[0] rank, [1] cell counts + prefix, [2] node evaluation, [3] k-th key select.
+int dpq_debug_boot_stamps(dpq_index* x, int nq, double* out) {
+    if (!x || !out) return fail(DPQ_ERR_ARG, "NULL argument");
+    DPQ_HIP(hipSetDevice(x->device));
+    if (!x->d_boot_stamps) {
+        int rc = dev_alloc(&x->d_boot_stamps, (size_t)kMaxBatchQueries * 16);
+        if (rc) return rc;
+        DPQ_HIP(hipMemset(x->d_boot_stamps, 0, sizeof(unsigned long long) * kMaxBatchQueries * 16));
+        for (int i = 0; i < 8; ++i) out[i] = 0;
+        return DPQ_OK;
+    }
+    DPQ_HIP(hipDeviceSynchronize());
+    std::vector<unsigned long long> h((size_t)kMaxBatchQueries * 16);
+    DPQ_HIP(hipMemcpy(h.data(), x->d_boot_stamps, h.size() * 8, hipMemcpyDeviceToHost));
+    for (int i = 0; i < 8; ++i) out[i] = 0;
+    nq = std::min(nq, kMaxBatchQueries);
+    // out[0..3]: bootstrap (rank, cells, evaluate, select); out[4..7]: the last select launch (gather, k-th key,
+    // winners, sort + output)
+    for (int half = 0; half < 2; ++half) {
+        // blocks on the 100 MHz chip-wide clock: first start -> last end, distribution of lifetimes and start offsets
+        const size_t o = (size_t)half * kMaxBatchQueries * 8;
+        unsigned long long t0 = ~0ull, t1 = 0;
+        std::vector<double> life, start;
+        for (int q = 0; q < nq; ++q) {
+            t0 = std::min(t0, h[o + (size_t)q * 8 + 6]);
+            t1 = std::max(t1, h[o + (size_t)q * 8 + 7]);
+        }
+        for (int q = 0; q < nq; ++q) {
+            life.push_back((double)(h[o + (size_t)q * 8 + 7] - h[o + (size_t)q * 8 + 6]) / 100.0);
+            start.push_back((double)(h[o + (size_t)q * 8 + 6] - t0) / 100.0);
+        }
+        std::sort(life.begin(), life.end());
+        std::sort(start.begin(), start.end());
+        auto pct = [&](const std::vector<double>& v, double p) { return v[(size_t)(p * (v.size() - 1))]; };
+        fprintf(stderr, "%s blocks: span %.2f us; lifetime min %.2f median %.2f p90 %.2f max %.2f us; start offset median %.2f p90 %.2f max %.2f us\n",
+                half ? "select" : "bootstrap", (double)(t1 - t0) / 100.0, life.front(), pct(life, 0.5), pct(life, 0.9), life.back(),
+                pct(start, 0.5), pct(start, 0.9), start.back());
+    }
+    for (int half = 0; half < 2; ++half)
+        for (int q = 0; q < nq; ++q)
+            for (int i = 0; i < 4; ++i) {
+                const size_t o = (size_t)half * kMaxBatchQueries * 8 + (size_t)q * 8;
+                out[4 * half + i] += (double)(h[o + i + 1] - h[o + i]) / nq;
+            }
+    return DPQ_OK;
 }
 
 // Developer hook: time the level-0 select (shared, query-independent candidate list).

@@ -287,19 +287,34 @@ int transcode(const uint8_t* payload, int64_t n_bytes, int64_t n_codes, int M, i
 }
 
 void build_multi_index(const std::vector<uint32_t>& ids, const std::vector<uint8_t>& codes, int M, int stride, SoA* out) {
+    // kBootPairs disjoint classes (sample j belongs to class j % kBootPairs); class p is indexed by the cell
+    // (code[s], code[s + 1]) of ITS sub-space pair, s = bootstrap_pair_subspace(M, p).  Entries are class-major,
+    // cell-major, DFS order inside a cell; cell_start holds absolute entry positions.
     const size_t n = ids.size(), W = (size_t)M / 4;
     out->mi_stride = stride;
-    out->mi_cell_start.assign(65537, 0);
+    out->mi_cell_start.assign((size_t)kBootPairs * 65537, 0);
     out->mi_code.assign(n * W, 0);
     out->mi_id.assign(n, 0);
-    auto cell_of = [&](size_t e) { return (size_t)codes[e * M] | ((size_t)codes[e * M + 1] << 8); };
-    for (size_t e = 0; e < n; ++e) out->mi_cell_start[cell_of(e) + 1]++;
-    for (size_t c = 0; c < 65536; ++c) out->mi_cell_start[c + 1] += out->mi_cell_start[c];
-    std::vector<uint32_t> fill(out->mi_cell_start.begin(), out->mi_cell_start.end() - 1);
+    auto cls = [&](size_t e) { return e % kBootPairs; };
+    auto cell_of = [&](size_t e) {
+        const int s = bootstrap_pair_subspace(M, (int)cls(e));
+        return (size_t)codes[e * M + s] | ((size_t)codes[e * M + s + 1] << 8);
+    };
+    for (size_t e = 0; e < n; ++e) out->mi_cell_start[cls(e) * 65537 + cell_of(e) + 1]++;
+    uint32_t run = 0;
+    for (size_t p = 0; p < (size_t)kBootPairs; ++p) {
+        uint32_t* cs = &out->mi_cell_start[p * 65537];
+        cs[0] = run;  // counts were stored at [cell + 1]
+        for (size_t c = 0; c < 65536; ++c) cs[c + 1] += cs[c];
+        run = cs[65536];
+    }
+    std::vector<uint32_t> fill((size_t)kBootPairs * 65536);
+    for (size_t p = 0; p < (size_t)kBootPairs; ++p)
+        for (size_t c = 0; c < 65536; ++c) fill[p * 65536 + c] = out->mi_cell_start[p * 65537 + c];
     for (size_t e = 0; e < n; ++e) {  // stable: entries of a cell stay in DFS order
-        const size_t p = fill[cell_of(e)]++;
-        out->mi_id[p] = ids[e];
-        memcpy(&out->mi_code[p * W], &codes[e * M], (size_t)M);
+        const size_t pos = fill[cls(e) * 65536 + cell_of(e)]++;
+        out->mi_id[pos] = ids[e];
+        memcpy(&out->mi_code[pos * W], &codes[e * M], (size_t)M);
     }
 }
 

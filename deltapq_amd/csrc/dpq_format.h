@@ -69,11 +69,13 @@ struct SoA {
     std::vector<uint8_t> delta;           // changed bytes, node order, ascending position; 16 bytes of tail padding
     std::vector<uint64_t> seg_delta_off;  // [n_segments + 1]
     std::vector<uint8_t> seg_ckpt;        // [n_segments][levels][M]: ancestor stack at the segment's first node
-    // Threshold bootstrap (DESIGN.md "bootstrap"): an inverted multi-index over every mi_stride-th node,
-    // cell = (code[0], code[1]).  A query evaluates the nodes of its best cells exactly and takes the k-th
-    // key as its first threshold -- as tight as a spread sample of a quarter of the index.  Empty = not built.
+    // Threshold bootstrap (DESIGN.md "bootstrap"): inverted multi-indexes over every mi_stride-th node.  The
+    // sampled nodes are dealt to kBootPairs classes; class p is indexed by cell = (code[s_p], code[s_p + 1]) of
+    // its own sub-space pair.  A query evaluates the nodes of its best cells of every class exactly and takes
+    // the k-th key as its first threshold -- as tight as a spread sample of a quarter of the index, and (four
+    // different pairs) without the heavy tail one pair alone has.  Empty = not built.
     int mi_stride = 0;
-    std::vector<uint32_t> mi_cell_start;  // [65537] first entry of every cell
+    std::vector<uint32_t> mi_cell_start;  // [kBootPairs][65537] absolute position of every cell's first entry
     std::vector<uint32_t> mi_code;        // [entries][M / 4] decoded codes, cell-major
     std::vector<uint32_t> mi_id;          // [entries] global DFS position
     int64_t nodes_per_segment() const { return (int64_t)kChunk * chunks_per_segment; }
@@ -91,6 +93,9 @@ int transcode(const uint8_t* payload, int64_t n_bytes, int64_t n_codes, int M, i
               int chunks_per_segment, SoA* out, std::string* err, int64_t scan_codes = 0, int multi_index_stride = 0);
 // The bootstrap multi-index of a list of (global position, code) pairs: counting sort by cell.
 void build_multi_index(const std::vector<uint32_t>& ids, const std::vector<uint8_t>& codes, int M, int stride, SoA* out);
+constexpr int kBootPairs = 4;
+// first sub-space of class p's pair: (0,1) (2,3) (4,5) (6,7) at M = 8; (0,1) (4,5) (8,9) (12,13) at M = 16
+inline int bootstrap_pair_subspace(int M, int p) { return 2 * p * (M / 8); }
 // Nodes below which the bootstrap is not worth its tables (the spread-sample cascade serves small indexes), and
 // the sampling stride that keeps the multi-index at <= 4 M entries.
 constexpr int64_t kBootstrapMinNodes = 262144;

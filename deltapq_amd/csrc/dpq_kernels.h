@@ -80,11 +80,12 @@ struct SelectArgs {
     int64_t n_codes_total;         // N for the even-N id quirk of the DTC scan; odd (-1) for the plain scan
     int32_t fp32_accum;            // 1: plain-scan rule, distance accumulated in fp32 (h:2658-2662)
     int32_t keep_thr;              // 1: thr_key = min(thr_key, this level's k-th key) (levels after a bootstrap)
+    unsigned long long* stamps;    // developer diagnostics (NULL in product calls): [slots][8] s_memtime marks
 };
 
 // Threshold bootstrap from the inverted multi-index (see bootstrap_kernel).
 struct BootArgs {
-    const uint32_t* cell_start;    // [65537]
+    const uint32_t* cell_start;    // [4 classes][65537] absolute entry positions
     const uint32_t* mi_code;       // [entries][M / 4]
     const uint32_t* mi_id;         // [entries] global DFS positions
     const float* lut32;            // exact tables [query][m][256]
@@ -95,6 +96,7 @@ struct BootArgs {
     uint64_t* thr_key;             // out [slots]
     uint32_t* cand_count;          // [slots][kRegionStride]: region 0 (carried winners) is set to 0
     int32_t fp32_accum;
+    unsigned long long* stamps;    // developer diagnostics (NULL in product calls): [slots][8] s_memtime marks
 };
 
 // Builds the exact tables of queries [0, nq) and clears the candidate counters / overflow flags of

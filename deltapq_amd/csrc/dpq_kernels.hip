@@ -228,15 +228,31 @@ struct WaveDecoder {
         }
     }
 
-    // Decode node `node` (= this lane's node of the chunk).  `carry`: update the
-    // stack for the next chunk of the segment.
-    __device__ __forceinline__ void step(const DeviceImage& img, int64_t node, int lane, uint64_t lt_mask, bool carry,
-                                         uint32_t (&code)[W]) {
-        // depth nibble and mask (coalesced)
-        const uint32_t nb = img.nib[node >> 1];
-        const uint32_t d = (node & 1) ? (nb >> 4) : (nb & 15u);
-        uint32_t mk = M <= 8 ? (uint32_t)img.mask[node] : (uint32_t)reinterpret_cast<const uint16_t*>(img.mask)[node];
-        const uint32_t pc = __popc(mk);
+    // The decode of a 64-node chunk runs in three stages so that the scan can keep the stages of three
+    // consecutive chunks in flight (each of the first two ends in a global-memory round trip):
+    //   load_in   depth nibble and diff mask of the lane's node (coalesced)
+    //   load_delta wave scan of popcount(mask) -> the node's changed bytes (3 aligned dwords) + permute selectors
+    //   finish    scatter to positions, pointer jumping over the in-chunk ancestor chain, apply to the stack
+    struct In {
+        uint32_t nb, mk;
+    };
+    struct Ld {
+        uint32_t d, mk;
+        uint32_t w[W / 2][3], sh[W / 2];
+        uint2 t[W / 2];
+    };
+    __device__ __forceinline__ static In load_in(const DeviceImage& img, int64_t node) {
+        In r;
+        r.nb = img.nib[node >> 1];
+        r.mk = M <= 8 ? (uint32_t)img.mask[node] : (uint32_t)reinterpret_cast<const uint16_t*>(img.mask)[node];
+        return r;
+    }
+    // `at`: running offset of the chunk's first changed byte (advanced past the chunk)
+    __device__ __forceinline__ static Ld load_delta(const DeviceImage& img, const In& in, int64_t node, uint64_t& at) {
+        Ld r;
+        r.d = (node & 1) ? (in.nb >> 4) : (in.nb & 15u);
+        r.mk = in.mk;
+        const uint32_t pc = __popc(in.mk);
         // wave exclusive scan of pc by bit planes: v_mbcnt, no LDS traffic
         uint32_t excl = 0, total = 0;
 #pragma unroll
@@ -245,24 +261,43 @@ struct WaveDecoder {
             excl = mbcnt64(plane, excl << 1);
             total = (total << 1) + (uint32_t)__popcll(plane);
         }
-        // changed bytes at byte granularity, one 8-position group at a time:
-        // 3 aligned dwords + funnel shift, then scatter to positions (a7)
-        uint32_t pv[W];
+        // changed bytes at byte granularity, one 8-position group at a time: 3 aligned dwords (+ funnel shift later)
 #pragma unroll
         for (int h = 0; h < W / 2; ++h) {
-            const uint32_t skip = h == 0 ? 0u : (uint32_t)__popc(mk & 0xffu);
-            const uint8_t* dp = img.delta + doff + excl + skip;
+            const uint32_t skip = h == 0 ? 0u : (uint32_t)__popc(in.mk & 0xffu);
+            const uint8_t* dp = img.delta + at + excl + skip;
             const uintptr_t ua = reinterpret_cast<uintptr_t>(dp);
             const uint32_t* wp = reinterpret_cast<const uint32_t*>(ua & ~(uintptr_t)3);
-            const uint32_t sh = (uint32_t)(ua & 3);
-            const uint32_t w0 = wp[0], w1 = wp[1], w2 = wp[2];
-            const uint32_t raw_lo = __builtin_amdgcn_alignbyte(w1, w0, sh);
-            const uint32_t raw_hi = __builtin_amdgcn_alignbyte(w2, w1, sh);
-            const uint2 t = *reinterpret_cast<const uint2*>(g_dtab.e[(mk >> (8 * h)) & 0xffu]);
-            pv[2 * h] = __builtin_amdgcn_perm(raw_hi, raw_lo, t.x);
-            pv[2 * h + 1] = __builtin_amdgcn_perm(raw_hi, raw_lo, t.y);
+            r.sh[h] = (uint32_t)(ua & 3);
+            r.w[h][0] = wp[0];
+            r.w[h][1] = wp[1];
+            r.w[h][2] = wp[2];
+            r.t[h] = *reinterpret_cast<const uint2*>(g_dtab.e[(in.mk >> (8 * h)) & 0xffu]);
         }
-        doff += total;
+        at += total;
+        return r;
+    }
+
+    // Decode node `node` (= this lane's node of the chunk) in one go.  `carry`: update the
+    // stack for the next chunk of the segment.
+    __device__ __forceinline__ void step(const DeviceImage& img, int64_t node, int lane, uint64_t lt_mask, bool carry,
+                                         uint32_t (&code)[W]) {
+        const In in = load_in(img, node);
+        const Ld ld = load_delta(img, in, node, doff);
+        finish(ld, lane, lt_mask, carry, code);
+    }
+
+    __device__ __forceinline__ void finish(const Ld& ld, int lane, uint64_t lt_mask, bool carry, uint32_t (&code)[W]) {
+        const uint32_t d = ld.d;
+        uint32_t mk = ld.mk;
+        uint32_t pv[W];
+#pragma unroll
+        for (int h = 0; h < W / 2; ++h) {  // scatter the packed changed bytes to their positions (a7)
+            const uint32_t raw_lo = __builtin_amdgcn_alignbyte(ld.w[h][1], ld.w[h][0], ld.sh[h]);
+            const uint32_t raw_hi = __builtin_amdgcn_alignbyte(ld.w[h][2], ld.w[h][1], ld.sh[h]);
+            pv[2 * h] = __builtin_amdgcn_perm(raw_hi, raw_lo, ld.t[h].x);
+            pv[2 * h + 1] = __builtin_amdgcn_perm(raw_hi, raw_lo, ld.t[h].y);
+        }
         // parent = nearest preceding node with depth-1 (h:2888: stack[depth-1])
         uint64_t B[LEVELS];
 #pragma unroll
@@ -636,24 +671,87 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanArgs a) {
     // list entry s -> workgroup s % splits (a short list still reaches every workgroup); inside the
     // workgroup the wavefronts draw their next entry from an LDS counter, so a wavefront that met
     // segments with many filter survivors does not hold the others back
-    for (;;) {
+    auto next_entry = [&]() -> int {  // wave-uniform: the next segment of this wavefront, -1 = the list is used up
         int j = 0;
         if (lane == 0) j = (int)atomicAdd(wg_next, 1u);
         j = __builtin_amdgcn_readfirstlane(j);
         const int s = split + (int)gridDim.x * j;
-        if (s >= a.n_seg_pass) break;
-        const uint32_t seg = (uint32_t)__builtin_amdgcn_readfirstlane(a.seg_list ? (int)a.seg_list[s] : s);
-        if (!PLAIN) dec.begin_segment(a.img, seg, lane);
-        stamp(kStSegment);
-        for (int c = 0; c < cps; ++c) {
-            const int64_t node = ((int64_t)seg * cps + c) * 64 + lane;  // local position
-            uint32_t code[W];
-            if (PLAIN) {  // uncompressed comparator (h:2590-2678): the code is simply there
+        if (s >= a.n_seg_pass) return -1;
+        return __builtin_amdgcn_readfirstlane(a.seg_list ? (int)a.seg_list[s] : s);
+    };
+    // Software pipeline over the chunks this wavefront draws: while chunk A is decoded and filtered, the
+    // changed bytes of chunk B and the nibbles/masks (and segment header) of chunk C are in flight.  Each
+    // stage of the decode ends in a global round trip; with four wavefronts per SIMD they were what a
+    // wavefront spent most of its time on (STAMPS build: decode 47 % of the wave time).
+    struct Chunk {
+        int seg, c;                       // wave-uniform; seg < 0: no chunk
+        typename WaveDecoder<M>::In in;   // stage 1
+        uint64_t h_doff;                  // stage 1, first chunk of a segment: offset of its first changed byte,
+        uint32_t h_stk[W];                //          and the ancestor stack at its first node (lanes 0..LEVELS-1)
+        typename WaveDecoder<M>::Ld ld;   // stage 2
+        uint32_t raw[W];                  // PLAIN: the code itself (stage 1)
+    };
+    auto node_of = [&](const Chunk& k) { return ((int64_t)k.seg * cps + k.c) * 64 + lane; };  // local position
+    auto stage1 = [&](Chunk& k) {
+        if (k.seg < 0) return;
+        const int64_t node = node_of(k);
+        if (PLAIN) {  // uncompressed comparator (h:2590-2678): the code is simply there
 #pragma unroll
-                for (int w = 0; w < W; ++w)
-                    code[w] = reinterpret_cast<const uint32_t*>(a.img.raw)[(size_t)node * W + w];
+            for (int w = 0; w < W; ++w) k.raw[w] = reinterpret_cast<const uint32_t*>(a.img.raw)[(size_t)node * W + w];
+        } else {
+            k.in = WaveDecoder<M>::load_in(a.img, node);
+            if (k.c == 0) {
+                k.h_doff = a.img.seg_delta_off[k.seg];
+#pragma unroll
+                for (int w = 0; w < W; ++w) k.h_stk[w] = 0;
+                if (lane < C::LEVELS) {
+                    const uint32_t* ck = reinterpret_cast<const uint32_t*>(a.img.seg_ckpt) + ((size_t)k.seg * C::LEVELS + lane) * W;
+#pragma unroll
+                    for (int w = 0; w < W; ++w) k.h_stk[w] = ck[w];
+                }
+            }
+        }
+    };
+    uint64_t at = 0;  // running changed-byte offset of the chunk in stage 2
+    auto stage2 = [&](Chunk& k) {
+        if (k.seg < 0 || PLAIN) return;
+        if (k.c == 0) at = k.h_doff;
+        k.ld = WaveDecoder<M>::load_delta(a.img, k.in, node_of(k), at);
+    };
+    auto successor = [&](const Chunk& k) {
+        Chunk n;
+        n.seg = k.seg;
+        n.c = k.c + 1;
+        if (k.seg >= 0 && n.c == cps) {
+            n.seg = next_entry();
+            n.c = 0;
+        }
+        return n;
+    };
+    Chunk A, B, Cn;
+    A.seg = next_entry();
+    A.c = 0;
+    stage1(A);
+    B = successor(A);
+    stage1(B);
+    stage2(A);
+    stamp(kStSegment);
+    while (A.seg >= 0) {
+        Cn = successor(B);
+        stage1(Cn);
+        stage2(B);
+        {
+            const int64_t node = node_of(A);
+            uint32_t code[W];
+            if (PLAIN) {
+#pragma unroll
+                for (int w = 0; w < W; ++w) code[w] = A.raw[w];
             } else {
-                dec.step(a.img, node, lane, lt_mask, c + 1 < cps, code);
+                if (A.c == 0) {
+#pragma unroll
+                    for (int w = 0; w < W; ++w) dec.stk[w] = A.h_stk[w];
+                }
+                dec.finish(A.ld, lane, lt_mask, A.c + 1 < cps, code);
             }
             if constexpr (STAMPS) {
                 st[kStSteps] += 1;
@@ -728,6 +826,8 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanArgs a) {
                 stamp(kStPush);
             }
         }
+        A = B;
+        B = Cn;
     }
     while (rq_n > 0) refine(min(rq_n, 64));
     stamp(kStRefine);
@@ -914,6 +1014,11 @@ __global__ __launch_bounds__(THREADS) void select_kernel(const SelectArgs a) {
     const int tid = threadIdx.x;
     const int q = a.slot_query ? a.slot_query[slot] : slot;
     if (q < 0) return;  // unused slot of a rerun group
+    auto mark = [&](int i) {  // developer diagnostics: phase boundaries
+        if (a.stamps && tid == 0) a.stamps[(size_t)slot * 8 + i] = __builtin_amdgcn_s_memtime();
+    };
+    mark(0);
+    if (a.stamps && tid == 0) a.stamps[(size_t)slot * 8 + 6] = __builtin_amdgcn_s_memrealtime();
     const bool shared = a.shared_id != nullptr;
     uint64_t* cand = a.cand_key + (size_t)slot * a.cand_stride;
     uint32_t* region_n = a.cand_count + (size_t)slot * kRegionStride;
@@ -988,17 +1093,35 @@ __global__ __launch_bounds__(THREADS) void select_kernel(const SelectArgs a) {
         n = (int)rstart[R];
         // keys live in LDS for the usual list sizes, in HBM scratch for huge ones (overflow reruns)
         if (n > kSortMax) keys = a.scratch + (size_t)slot * a.cand_stride;
-        for (int r = tid >> 6; r < R; r += THREADS / 64) {  // one wavefront per region
-            const uint32_t lo = rstart[r], cnt = rstart[r + 1] - lo;
-            const uint64_t* src = cand + (r == 0 ? (size_t)0 : (size_t)a.region_off + (size_t)(r - 1) * a.region_cap);
-            for (uint32_t li = tid & 63; li < cnt; li += 64) keys[lo + li] = src[li];
+        // flat gather: key i of the list sits in the region r with rstart[r] <= i < rstart[r + 1]; every thread
+        // has all its loads in flight at once (a region-by-region copy is a chain of global round trips)
+        for (int i0 = 0; i0 < n; i0 += 4 * THREADS) {
+            uint64_t v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = min(i0 + tid + u * THREADS, n - 1);
+                int lo = 0, hi = R;  // rstart[lo] <= i < rstart[hi]
+                while (hi - lo > 1) {
+                    const int mid = (lo + hi) >> 1;
+                    if (rstart[mid] <= (uint32_t)i) lo = mid; else hi = mid;
+                }
+                const uint64_t* src = cand + (lo == 0 ? (size_t)0 : (size_t)a.region_off + (size_t)(lo - 1) * a.region_cap);
+                v[u] = src[(uint32_t)i - rstart[lo]];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + tid + u * THREADS;
+                if (i < n) keys[i] = v[u];
+            }
         }
     }
     __syncthreads();
+    mark(1);
     const int n_valid = n - (int)counters[1];
     const int kk = min(a.top_k, n_valid);
     uint64_t kth = ~0ull;
     if (kk > 0) kth = block_radix_select(keys, n, kk, hist, bcast, tid, THREADS);
+    mark(2);
 
     // The k-th smallest key seen so far bounds the final k-th key from above
     // (candidates are real nodes), so it is the next level's threshold.
@@ -1024,6 +1147,7 @@ __global__ __launch_bounds__(THREADS) void select_kernel(const SelectArgs a) {
     }
     __syncthreads();
 
+    mark(3);
     if (!a.final_pass) {
         // carry the winners: compact them to the front; the next level appends behind
         for (int i = tid; i < kk; i += THREADS) cand[i] = wkeys[i];
@@ -1031,6 +1155,26 @@ __global__ __launch_bounds__(THREADS) void select_kernel(const SelectArgs a) {
         return;
     }
 
+    if (kk <= 2 * THREADS) {
+        // few winners: a winner's output rank = the number of smaller winners (keys are unique); kk LDS
+        // broadcast reads per thread and no barrier, against the 28+ barriers of a bitonic network
+        for (int i = tid; i < kk; i += THREADS) {
+            const uint64_t mine = wkeys[i];
+            int rank = 0;
+            for (int j = 0; j < kk; ++j) rank += wkeys[j] < mine ? 1 : 0;
+            const size_t o = (size_t)q * a.top_k + rank;
+            a.out_ids[o] = report_id((uint32_t)(mine & 0xffffffffu), a.n_codes_total);
+            a.out_dists[o] = __uint_as_float((uint32_t)(mine >> 32));
+        }
+        for (int r = kk + tid; r < a.top_k; r += THREADS) {
+            const size_t o = (size_t)q * a.top_k + r;
+            a.out_ids[o] = -1;
+            a.out_dists[o] = INFINITY;
+        }
+        mark(4);
+        if (a.stamps && tid == 0) a.stamps[(size_t)slot * 8 + 7] = __builtin_amdgcn_s_memrealtime();
+        return;
+    }
     block_bitonic_sort(wkeys, p2, tid, THREADS);
     for (int r = tid; r < a.top_k; r += THREADS) {
         const size_t o = (size_t)q * a.top_k + r;
@@ -1061,70 +1205,109 @@ __global__ __launch_bounds__(THREADS) void select_kernel(const SelectArgs a) {
 // grid = slots, block = 512 threads.
 // ---------------------------------------------------------------------------
 constexpr int kBootThreads = 512;
-constexpr int kBootCells = 1024;  // cells per round (their prefix sums live in LDS)
+constexpr int kBootCells = 736;  // cells per round (their node prefix, clamped to 16 bits, and first entries live in LDS);
+                                 // 736: the block stays at 40 912 B of LDS at cap = 3072, four blocks per CU
+constexpr int kBootCellsPerThread = 2;
+constexpr int kBootBatch = 6;    // nodes a thread has in flight: cap / threads at the default cap (every step of the chain is a global or LDS round trip)
+constexpr int kBootPairs = 4;    // multi-index classes = sub-space pairs (dpq_format.h)
 
 template <int M>
-__global__ __launch_bounds__(kBootThreads) void bootstrap_kernel(const BootArgs a) {
+// M = 8: four blocks per CU (40 KB of LDS each) = 8 wavefronts per SIMD: the register budget (SGPRs included:
+// 800 per SIMD) must allow it; M = 16: three blocks (48 KB)
+__global__ __launch_bounds__(kBootThreads, M <= 8 ? 8 : 6) void bootstrap_kernel(const BootArgs a) {
     constexpr int W = Cfg<M>::W;
     constexpr int TE = M * 256;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint64_t* keys = reinterpret_cast<uint64_t*>(smem);                                   // [cap]
     float* T = reinterpret_cast<float*>(smem + (size_t)a.cap * 8);                        // [M][256] exact tables
-    uint32_t* pre = reinterpret_cast<uint32_t*>(T + TE);                                  // [kBootCells + 1] node prefix of the round's cells
-    uint16_t* ord = reinterpret_cast<uint16_t*>(pre + kBootCells + 1 + 1);                // [2][256] centroids by rank
-    uint32_t* hist = reinterpret_cast<uint32_t*>(ord + 512);                              // [264] radix-select scratch
+    uint32_t* cstart = reinterpret_cast<uint32_t*>(T + TE);                               // [kBootCells] first multi-index entry of the cell
+    uint16_t* pre = reinterpret_cast<uint16_t*>(cstart + kBootCells);                     // [1024 + 4] node prefix of the round's cells, clamped to 65535
+    uint8_t* ord = reinterpret_cast<uint8_t*>(pre + 1024 + 4);                            // [2 * kBootPairs][256] centroids by rank
+    uint32_t* hist = reinterpret_cast<uint32_t*>(ord + 2 * kBootPairs * 256);             // [264] radix-select scratch
     uint32_t* bcast = hist + 264;                                                         // [2]
     uint32_t* wave_sum = bcast + 2;                                                       // [8]
 
     const int slot = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int q = a.slot_query ? a.slot_query[slot] : slot;
     if (q < 0) return;
+    if (a.stamps && tid == 0) a.stamps[(size_t)slot * 8 + 6] = __builtin_amdgcn_s_memrealtime();  // 100 MHz, chip-wide
     if (tid == 0) a.cand_count[(size_t)slot * kRegionStride] = 0;  // no carried winners: the scan meets every node again
     {
         const float4* src = reinterpret_cast<const float4*>(a.lut32 + (size_t)q * TE);
         for (int i = tid; i < TE / 4; i += kBootThreads) reinterpret_cast<float4*>(T)[i] = src[i];
     }
     __syncthreads();
-    {   // rank the centroids of sub-spaces 0 and 1 (ties by index): thread -> (sub-space, centroid)
-        const int m = tid >> 8, kk = tid & 255;
-        const uint32_t mine = __float_as_uint(T[m * 256 + kk]);  // entries are >= 0 (or +inf beyond K): uint order = float order
-        int rank = 0;
-        for (int j = 0; j < 256; ++j) {
-            const uint32_t o = __float_as_uint(T[m * 256 + j]);
-            rank += (o < mine || (o == mine && j < kk)) ? 1 : 0;
+    auto mark = [&](int i) {  // developer diagnostics: phase boundaries of block 0's first wavefront
+        if (a.stamps && tid == 0) a.stamps[(size_t)slot * 8 + i] = __builtin_amdgcn_s_memtime();
+    };
+    mark(0);
+    {   // Rank the centroids of the 2 * kBootPairs sub-spaces the classes are indexed by: bitonic sorts of 256
+        // keys, one position per thread and four sorts per thread (threads 0..255: sort slots 0..3, 256..511:
+        // slots 4..7; slot s = sub-space `which` = s & 1 of pair s >> 1).  The order only steers which cells are
+        // visited first (any order gives a valid threshold), so the low 8 mantissa bits make room for the
+        // centroid index: keys are unique.  Partners closer than 64 are reached by wave shuffles, the three
+        // stages with distance 64 / 128 through LDS.  (Counting ranks took 256 comparisons per thread: 13 us.)
+        const int h = tid >> 8, i = tid & 255;
+        uint32_t key[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int sl = 4 * h + r, sub = 2 * (sl >> 1) * (M / 8) + (sl & 1);
+            key[r] = (__float_as_uint(T[sub * 256 + i]) & 0xffffff00u) | (uint32_t)i;  // entries >= 0 (or +inf): uint order
         }
-        ord[m * 256 + rank] = (uint16_t)kk;
+        uint32_t* xch = reinterpret_cast<uint32_t*>(keys);  // [4][512] exchange buffer (the key list is empty yet)
+#pragma unroll
+        for (int k = 2; k <= 256; k <<= 1) {
+#pragma unroll
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                uint32_t other[4];
+                if (j >= 64) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) xch[r * kBootThreads + tid] = key[r];
+                    __syncthreads();
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) other[r] = xch[r * kBootThreads + (tid ^ j)];
+                    __syncthreads();
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) other[r] = (uint32_t)__shfl_xor((int)key[r], j, 64);
+                }
+                const bool take_min = ((i & k) == 0) == ((i & j) == 0);  // ascending run and lower position, or neither
+#pragma unroll
+                for (int r = 0; r < 4; ++r) key[r] = take_min ? min(key[r], other[r]) : max(key[r], other[r]);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ord[(4 * h + r) * 256 + i] = (uint8_t)(key[r] & 0xffu);
     }
     __syncthreads();
-
-    // cell u of a round that starts at shell t0: shell t = floor(sqrt(u + t0^2)), position s = u + t0^2 - t^2 in it;
-    // s <= t: (i, j) = (t, s), else (s - t - 1, t)
-    auto cell_of = [&](int u, int t0) -> uint32_t {
-        const int v = u + t0 * t0;
-        int t = (int)sqrtf((float)v);
-        while (t * t > v) --t;
-        while ((t + 1) * (t + 1) <= v) ++t;
-        const int sft = v - t * t;
-        const int i = sft <= t ? t : sft - t - 1, j = sft <= t ? sft : t;
-        return (uint32_t)ord[i] | ((uint32_t)ord[256 + j] << 8);
-    };
+    mark(1);
 
     int have = 0;  // keys so far (block-uniform)
-    int t0 = 0;
-    while (t0 < 256 && have < a.target) {
-        // shells [t0, t1): as many as fit kBootCells cells (one shell alone has at most 511)
-        int t1 = t0 + 1;
-        while (t1 < 256 && (t1 + 1) * (t1 + 1) - t0 * t0 <= kBootCells) ++t1;
-        const int n_cells = t1 * t1 - t0 * t0;
-        // node counts of the round's cells -> exclusive prefix in LDS
-        uint32_t cnt[kBootCells / kBootThreads], mine = 0;
+    // Every class walks its 65536 cells in the order w = 0, 1, ...: shell t = floor(sqrt(w)) (= max of the two
+    // centroid ranks), position s = w - t^2 inside it; s <= t: ranks (i, j) = (t, s), else (s - t - 1, t).  A round
+    // takes the next kBootCells / kBootPairs cells of every class, class-interleaved (u = 4 (w - w0) + p), so that
+    // a cut-off list keeps the best cells of all classes.
+    int w0 = 0;
+    while (w0 < 65536 && have < a.target) {
+        const int n_w = min(kBootCells / kBootPairs, 65536 - w0);
+        const int n_cells = kBootPairs * n_w;
+        uint32_t cnt[kBootCellsPerThread], first[kBootCellsPerThread], mine = 0;
 #pragma unroll
-        for (int r = 0; r < kBootCells / kBootThreads; ++r) {
-            const int u = tid * (kBootCells / kBootThreads) + r;
+        for (int r = 0; r < kBootCellsPerThread; ++r) {  // thread -> cells 2 tid, 2 tid + 1
+            const int u = kBootCellsPerThread * tid + r;
             cnt[r] = 0;
+            first[r] = 0;
             if (u < n_cells) {
-                const uint32_t c = cell_of(u, t0);
-                cnt[r] = a.cell_start[c + 1] - a.cell_start[c];
+                const int p = u & (kBootPairs - 1), v = (u >> 2) + w0;
+                int t = (int)sqrtf((float)v);
+                t -= t * t > v ? 1 : 0;
+                t += (t + 1) * (t + 1) <= v ? 1 : 0;
+                const int sft = v - t * t;
+                const int i = sft <= t ? t : sft - t - 1, j = sft <= t ? sft : t;
+                const uint32_t c = (uint32_t)ord[(2 * p) * 256 + i] | ((uint32_t)ord[(2 * p + 1) * 256 + j] << 8);
+                const uint32_t* cs = a.cell_start + (size_t)p * 65537 + c;
+                first[r] = cs[0];
+                cnt[r] = cs[1] - first[r];
             }
             mine += cnt[r];
         }
@@ -1137,50 +1320,70 @@ __global__ __launch_bounds__(kBootThreads) void bootstrap_kernel(const BootArgs 
         if (lane == 63) wave_sum[wave] = incl;
         __syncthreads();
         uint32_t base = 0, total = 0;
+#pragma unroll
         for (int w = 0; w < kBootThreads / 64; ++w) {
-            if (w < wave) base += wave_sum[w];
-            total += wave_sum[w];
+            const uint32_t ws = wave_sum[w];
+            base += w < wave ? ws : 0u;
+            total += ws;
         }
         uint32_t run = base + incl - mine;
 #pragma unroll
-        for (int r = 0; r < kBootCells / kBootThreads; ++r) {
-            const int u = tid * (kBootCells / kBootThreads) + r;
-            if (u <= n_cells) pre[u] = run;  // pre[n_cells] = total (cnt of u >= n_cells is 0)
+        for (int r = 0; r < kBootCellsPerThread; ++r) {
+            const int u = kBootCellsPerThread * tid + r;
+            // cells beyond n_cells hold `total` (the search never lands on them); what lies beyond 65535 nodes is
+            // never taken (cap <= 16384), so the prefix saturates
+            pre[u] = (uint16_t)min(run, 65535u);
+            if (u < kBootCells) cstart[u] = first[r];
             run += cnt[r];
         }
         __syncthreads();
-        // exact evaluation of the round's nodes, as many as the key list still takes
+        mark(2);
+        // exact evaluation of the round's nodes, as many as the key list still takes; kBootBatch per thread
+        // go through search -> entry loads -> distance together
         const int take = min((int)total, a.cap - have);
-        for (int v = tid; v < take; v += kBootThreads) {
-            int lo = 0, hi = n_cells;  // largest u with pre[u] <= v
-            while (hi - lo > 1) {
-                const int mid = (lo + hi) >> 1;
-                if (pre[mid] <= (uint32_t)v) lo = mid; else hi = mid;
-            }
-            const uint32_t c = cell_of(lo, t0);
-            const size_t e = (size_t)a.cell_start[c] + ((uint32_t)v - pre[lo]);
-            uint32_t code[W];
+        for (int v0 = 0; v0 < take; v0 += kBootThreads * kBootBatch) {
+            uint32_t e[kBootBatch], code[kBootBatch][W], id[kBootBatch];
 #pragma unroll
-            for (int w = 0; w < W; ++w) code[w] = a.mi_code[e * W + w];
-            keys[have + v] = make_key(exact_dist<M>(T, code, a.fp32_accum != 0), a.mi_id[e]);
+            for (int r = 0; r < kBootBatch; ++r) {
+                const int v = min(v0 + tid + r * kBootThreads, take - 1);
+                int pos = 0;  // largest u with pre[u] <= v (pre[0] = 0)
+#pragma unroll
+                for (int step = 512; step > 0; step >>= 1)  // pre[u] = total > v for n_cells <= u < 1024: no guard needed
+                    pos += (uint32_t)pre[pos + step] <= (uint32_t)v ? step : 0;
+                e[r] = cstart[pos] + ((uint32_t)v - pre[pos]);
+            }
+#pragma unroll
+            for (int r = 0; r < kBootBatch; ++r) {
+#pragma unroll
+                for (int w = 0; w < W; ++w) code[r][w] = a.mi_code[(size_t)e[r] * W + w];
+                id[r] = a.mi_id[e[r]];
+            }
+#pragma unroll
+            for (int r = 0; r < kBootBatch; ++r) {
+                const int v = v0 + tid + r * kBootThreads;
+                if (v < take) keys[have + v] = make_key(exact_dist<M>(T, code[r], a.fp32_accum != 0), id[r]);
+            }
         }
         have += take;
-        t0 = t1;
-        __syncthreads();  // pre / wave_sum are rewritten by the next round
+        w0 += n_w;
+        __syncthreads();  // pre / cstart / wave_sum are rewritten by the next round
+        mark(3);
         if (have >= a.cap) break;
     }
     uint64_t kth = ~0ull;  // fewer than k nodes in the whole multi-index: no threshold
     if (have >= a.top_k) kth = block_radix_select(keys, have, a.top_k, hist, bcast, tid, kBootThreads);
     if (tid == 0) a.thr_key[slot] = kth;
+    mark(4);
+    if (a.stamps && tid == 0) a.stamps[(size_t)slot * 8 + 7] = __builtin_amdgcn_s_memrealtime();
 }
 
 size_t bootstrap_lds_bytes(int M, int cap) {
-    return (size_t)cap * 8 + (size_t)M * 256 * 4 + (kBootCells + 2) * 4 + 512 * 2 + (264 + 2 + 8) * 4;
+    return (size_t)cap * 8 + (size_t)M * 256 * 4 + (size_t)kBootCells * 4 + (1024 + 4) * 2 + 2 * kBootPairs * 256 + (264 + 2 + 8) * 4;
 }
 
 hipError_t launch_bootstrap(const BootArgs& a, int M, int n_slots, hipStream_t stream) {
     if (n_slots <= 0) return hipSuccess;
-    if (a.cap < a.top_k || a.cap > 16384 || !a.cell_start) return hipErrorInvalidValue;
+    if (a.cap < a.top_k || a.cap < 1024 || a.cap > 16384 || !a.cell_start) return hipErrorInvalidValue;  // the rank sort borrows 8 KB of the key list
     const size_t lds = bootstrap_lds_bytes(M, a.cap);
     if (M == 8) {
         static std::atomic<bool> done[64] = {};

@@ -181,8 +181,9 @@ def test_merge_topk_host(lib):
 
 @pytest.mark.parametrize("stride,shards", [(1, 1), (3, 1), (2, 3)])
 def test_bootstrap_multi_index_layout(lib, stride, shards):
-    """The threshold-bootstrap multi-index: every stride-th local node exactly once, in the cell
-    (code[0], code[1]) of its decoded code, global DFS position attached, DFS order inside a cell."""
+    """The threshold-bootstrap multi-indexes: every stride-th local node exactly once; sample j in class j % 4,
+    filed under the cell (code[s], code[s + 1]) of its class's sub-space pair (s = 0, 2, 4, 6), global DFS
+    position attached, DFS order inside a cell, absolute entry positions in cell_start."""
     from deltapq_amd import api, synth
     n = 6000
     tree, payload, _ = make_case(n, seed=91)
@@ -192,16 +193,19 @@ def test_bootstrap_multi_index_layout(lib, stride, shards):
         soa = api.HostSoA(payload, n, 8, shard_rank=r, shard_count=shards, multi_index_stride=stride)
         lo, hi = soa.info["node_lo"], soa.info["node_hi"]
         want = np.arange(lo, hi, stride)
-        cs, ids, cd = soa.mi_cell_start, soa.mi_id, soa.mi_code.view(np.uint8).reshape(-1, 8)
-        assert len(cs) == 65537 and cs[0] == 0 and cs[-1] == len(ids) == len(want) and np.all(np.diff(cs.astype(np.int64)) >= 0)
-        assert np.array_equal(np.sort(ids), want)
-        assert np.array_equal(cd, codes[ids])
-        cell = cd[:, 0].astype(np.int64) | (cd[:, 1].astype(np.int64) << 8)
-        assert np.all(np.diff(cell) >= 0)                                   # cell-major
-        assert np.array_equal(cs[cell], np.searchsorted(cell, cell, side="left"))
-        same = np.diff(cell) == 0
-        assert np.all(np.diff(ids.astype(np.int64))[same] > 0)              # DFS order inside a cell
-        assert soa.info["bootstrap_stride"] == stride and soa.info["bootstrap_bytes"] == 4 * (65537 + 3 * len(ids))
+        cs, ids, cd = soa.mi_cell_start.reshape(4, 65537).astype(np.int64), soa.mi_id, soa.mi_code.view(np.uint8).reshape(-1, 8)
+        assert cs[0, 0] == 0 and cs[3, -1] == len(ids) == len(want)
+        assert np.array_equal(np.sort(ids), want) and np.array_equal(cd, codes[ids])
+        for p in range(4):
+            assert np.all(np.diff(cs[p]) >= 0) and (p == 0 or cs[p, 0] == cs[p - 1, -1])
+            sl = slice(cs[p, 0], cs[p, -1])
+            assert np.array_equal(np.sort(ids[sl]), want[p::4])              # class p = samples p, p + 4, ...
+            cell = cd[sl, 2 * p].astype(np.int64) | (cd[sl, 2 * p + 1].astype(np.int64) << 8)
+            assert np.all(np.diff(cell) >= 0)                                  # cell-major
+            assert np.array_equal(cs[p][cell] - cs[p, 0], np.searchsorted(cell, cell, side="left"))
+            same = np.diff(cell) == 0
+            assert np.all(np.diff(ids[sl].astype(np.int64))[same] > 0)        # DFS order inside a cell
+        assert soa.info["bootstrap_stride"] == stride and soa.info["bootstrap_bytes"] == 4 * (4 * 65537 + 3 * len(ids))
         seen.append(ids)
     assert len(np.unique(np.concatenate(seen))) == sum(len(s) for s in seen)
 

@@ -585,7 +585,7 @@ def test_threshold_bootstrap_gives_the_same_answer(gpu, oracle, codebook, n, nq,
     tree, payload, nb = make_case(n, seed=n + 3, dup_heavy=dup)
     qs = synth.make_queries(nq, 128, seed=n + 4)
     ids, dists, prof, info = run(gpu, payload, n, codebook, qs, k, bootstrap=boot)
-    assert info["bootstrap_stride"] == 1 and info["bootstrap_bytes"] == 4 * (65537 + 3 * n)
+    assert info["bootstrap_stride"] == 1 and info["bootstrap_bytes"] == 4 * (4 * 65537 + 3 * n)
     ids0, dists0, _, info0 = run(gpu, payload, n, codebook, qs, k, bootstrap=-1)
     assert info0["bootstrap_bytes"] == 0
     assert np.array_equal(dists.view(np.uint32), dists0.view(np.uint32))
