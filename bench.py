@@ -1,28 +1,32 @@
 #!/usr/bin/env python3
 """bench.py -- queries/s of the DeltaPQ `-task query` hot path on MI355X.
 
-Workload (BASELINE.json configs[1]): SIFT1M-shaped index, N = 1e6 codes, m = 8,
-k = 256, top-k = 100, 1000 queries per step, synthetic data (seeded DeltaTree
-stream + SIFT-shaped codebook/queries, deltapq_amd/synth.py).  A "step" answers
-the whole 1000-query batch: LUT build + delta-decode/ADC scan cascade + select.
-Queries and results stay in HBM (device tensors) inside the timed region.
+Workload at N = 1 (BASELINE.json configs[1]): SIFT1M-shaped index, 1e6 codes, m = 8, k = 256, top-100,
+1000 queries per step, synthetic data made by the build's own pipeline (vectors -> k-means codebook -> PQ
+codes -> DeltaTree -> DTC).  A "step" answers one whole query batch: table build + threshold bootstrap +
+delta-decode/ADC filter scan + select.  Queries and results stay in HBM inside the timed regions.
 
   python bench.py --gpus 1 --steps 20 --warmup 3
-  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
+      bench.py --gpus N --steps K --warmup W
 
-With N > 1 the index is sharded by DFS-position range (byte-balanced), every
-rank answers all queries on its shard, the per-shard partial top-k lists are
-all-gathered over RCCL and merged on the GPU ("scaling": "strong": the
-database and the query batch are fixed as N grows).
+N > 1 (the north-star decomposition, "scaling": "strong"): the index is cut into N DFS-position ranges, one
+per rank; every rank answers the whole batch on its range; ONE all-gather of the partial top-k lists (RCCL)
+and a device merge.  `--data pipeline` builds the same seeded index on every rank and opens the rank's range;
+`--data stream` (indexes too large to build: BASELINE configs[3]/[4], `--codes 100000000` / `1000000000`)
+synthesises only the rank's own range (no rank ever holds N codes).  `--shard query` measures query replicas
+instead (weak scaling; reported under "query_replicas" beside the headline when asked with --also-replicas).
 
-Prints ONE JSON line on rank 0 (contract in the task statement) carrying
-`roofline` (scan kernel, HIP-event timed inside the library on the launch
-stream) and `cpu_baseline` (the oracle restatement timed on this host).
+The timed region of K steps is repeated --reps times (each bracketed by barrier + synchronize); `value` is the
+median repetition, min/max are reported.  Steps rotate over 4 distinct query batches.  Rank 0 prints ONE JSON
+line with `roofline` (binding resource of the scan kernel: LDS gather bandwidth; measured HBM beside it) and
+`cpu_baseline` (the oracle restatement of the reference, timed on this host).
 """
 import argparse
 import json
 import os
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -30,20 +34,26 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
 
-HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
-PMC_SUMMARY = os.path.join(HERE, "profiles", "pmc_summary_default_workload.json")
+HBM_PEAK_GBPS = 8000.0      # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s measured streaming copy)
+LDS_PEAK_GBPS = 157286.4    # 256 CUs x 256 B/clk (ds_read_b128) x 2.4 GHz, MI355X_MICROARCH.md section LDS
+N_BATCHES = 4               # distinct query batches the steps rotate over
 
 
-def measured_traffic(args):
-    """HBM bytes per scan-kernel launch from the committed rocprofv3 --pmc passes
-    (scripts/collect_pmc.sh: FETCH_SIZE and WRITE_SIZE in separate runs, gfx950
-    x2 read correction).  Only valid for the default workload it was taken on."""
-    default = (args.n, args.queries, args.topk, args.m, args.data, args.gpus) == (1_000_000, 1000, 100, 8, "pipeline", 1)
-    if not default or not os.path.exists(PMC_SUMMARY):
-        return None, None
-    with open(PMC_SUMMARY) as f:
-        s = json.load(f)
-    return s.get("scan_kernel_hbm_bytes_per_launch"), s.get("tag")
+def pmc_traffic(args, world):
+    """HBM bytes per scan-kernel launch from the committed rocprofv3 --pmc passes (scripts/collect_pmc.sh:
+    FETCH_SIZE and WRITE_SIZE in separate runs, gfx950 x2 read correction).  Valid for the workload it was
+    taken on: the summary names it."""
+    for name in ("r02_pmc_summary_default.json", "r02_pmc_summary_125M.json"):
+        path = os.path.join(HERE, "profiles", name)
+        if not os.path.exists(path):
+            continue
+        with open(path) as f:
+            s = json.load(f)
+        w = s.get("workload", {})
+        if (w.get("n"), w.get("queries"), w.get("topk"), w.get("m"), w.get("data"), w.get("gpus")) == \
+                (args.n, args.queries, args.topk, args.m, args.data, world):
+            return s.get("scan_kernel_hbm_bytes_per_launch"), s.get("scan_kernel_avg_launch_ms_under_pmc"), name
+    return None, None, None
 
 
 def make_queries(args, seed):
@@ -53,56 +63,119 @@ def make_queries(args, seed):
     return synth.make_queries(args.queries, args.dim, seed=seed)
 
 
-def build_workload(args, device, query_seed=101):
-    """`pipeline` (default): SIFT-shaped vectors (mixture of 20 000 Gaussians, values 0..218) ->
-    k-means codebook -> PQ codes (GPU encoder) -> DeltaTree (host builder, reference method 1) -> DTC.
-    `stream`: random DeltaTree emitted directly as (depth, mask, bytes) triples."""
+def build_workload(args, device, rank, world, by_query):
+    """Returns dict(codebook, payload, n_local, n_bytes_local, open_kwargs, desc).
+    pipeline: the whole seeded index on every rank (cut by the library: shard_rank / shard_count).
+    stream:   only this rank's part, as a self-contained stream with its global position (N > 1, index shards)."""
     from deltapq_amd import api, synth
     t0 = time.time()
     if args.data == "pipeline":
+        if args.n > 8_000_000:
+            raise SystemExit("--data pipeline builds the whole index on every rank: use --data stream beyond 8 M codes")
         base = synth.make_clustered_vectors(args.n, args.dim, seed=100, n_clusters=20000, spread=12.0, centre_seed=7)
-        queries = make_queries(args, query_seed)
         cb = synth.kmeans_codebook(base, args.m, 256, iters=6, seed=102)
         codes = api.encode_pq(base, cb, device=device)
         del base
         tree = api.DeltaTree(codes, codebook=cb, device=device)      # edge search on the GPU, layout on the host
         payload = tree.payload()
-        n_bytes = len(payload)
         uniq = len(np.unique(codes.view("V%d" % args.m))) / args.n
-        desc = "vectors->kmeans->PQ encode->built DeltaTree, %.1f%% unique codes" % (100 * uniq)
         tree.close()
-    else:
-        cb = synth.make_codebook(args.m, 256, args.dim // args.m, seed=100)
-        queries = make_queries(args, query_seed)
-        tree = synth.synth_tree(args.n, args.m, seed=102, mean_diffs=args.mean_diffs)
-        payload, n_bytes = synth.encode_dtc(tree)
-        desc = "random (depth, mask, bytes) stream"
-    return dict(codebook=cb, queries=queries, payload=payload, n_bytes=n_bytes, gen_s=time.time() - t0, desc=desc)
+        kw = dict(shard_rank=0 if by_query else rank, shard_count=1 if by_query else world)
+        return dict(codebook=cb, payload=payload, n_local=args.n, n_bytes_local=len(payload), open_kwargs=kw, offset=0,
+                    whole=True, gen_s=time.time() - t0,
+                    desc="vectors->kmeans->PQ encode->built DeltaTree, %.1f%% unique codes" % (100 * uniq))
+    cb = synth.make_codebook(args.m, 256, args.dim // args.m, seed=100)
+    if by_query or world == 1:
+        tree = synth.synth_tree_large(args.n, args.m, seed=102, mean_diffs=args.mean_diffs)
+        payload, nb = synth.encode_dtc(tree)
+        return dict(codebook=cb, payload=payload, n_local=args.n, n_bytes_local=nb, open_kwargs={}, offset=0, whole=True,
+                    gen_s=time.time() - t0, desc="random (depth, mask, bytes) stream")
+    # index shards of a stream too large to build anywhere: this rank's DFS range only
+    per = args.n // world
+    n_local = per if rank + 1 < world else args.n - per * (world - 1)
+    tree = synth.synth_tree_large(n_local, args.m, seed=102 + 1000 * rank, mean_diffs=args.mean_diffs)
+    payload, nb = synth.encode_dtc(tree)
+    del tree
+    kw = dict(global_offset=rank * per, global_n_codes=args.n)
+    return dict(codebook=cb, payload=payload, n_local=n_local, n_bytes_local=nb, open_kwargs=kw, offset=rank * per,
+                whole=False, gen_s=time.time() - t0,
+                desc="random (depth, mask, bytes) stream, every rank synthesises its own DFS range of %d codes" % per)
 
 
-def cpu_baseline(wl, args):
-    """Oracle (CPU restatement of h:3731-3892) on a bounded sample of the same
-    workload: 1 thread (the reference's parallelism) and all host cores."""
-    from concurrent.futures import ThreadPoolExecutor
+def canon_ids(ids, n):
+    """The even-N id rule (h:2949, 2970) reports the last node as n: fold it back to n - 1 for comparisons
+    between a part of an index and the oracle run on that part alone."""
+    ids = np.asarray(ids).astype(np.int64)
+    return np.where(ids == n, n - 1, ids) if n % 2 == 0 else ids
+
+
+def parity_gate(args, wl, queries, hi, hd, budget_s=25.0):
+    """Oracle check of the first rows of a result (rank 0).  Whole index: the final (merged) lists.  Own part of a
+    larger index: this rank's partial lists against the oracle run on the part."""
     from oracle import dtc_oracle as O
     orc = O.Oracle()
-    cb, qs, payload = wl["codebook"], wl["queries"], wl["payload"]
-    n1 = min(len(qs), args.cpu_queries)
+    n, off, k = wl["n_local"], wl["offset"], args.topk
+    checked, t0 = 0, time.time()
+    for i in range(min(args.check, len(queries))):
+        lut = orc.build_lut(wl["codebook"], queries[i])
+        oi, od, alld, _ = orc.scan_lut(wl["payload"], n, lut, k, want_all=True)
+        if wl["whole"]:
+            ok, msg = O.tie_aware_equal(hi[i], hd[i], oi, od, alld, n)
+        else:
+            mine = canon_ids(hi[i], args.n) - off
+            ok, msg = O.tie_aware_equal(mine, hd[i], canon_ids(oi, n), od, alld, n | 1)
+        if not ok:
+            print("bench.py: PARITY FAILURE on query %d: %s" % (i, msg), file=sys.stderr)
+            sys.exit(4)
+        checked += 1
+        if time.time() - t0 > budget_s:
+            break
+    return checked
+
+
+def cpu_baseline(wl, args, queries):
+    """The oracle (CPU restatement of h:3731-3892, built -O3 like the reference) on a bounded sample of the
+    same workload: 1 thread (the reference's own parallelism, main:328), all host cores (one query per C++
+    thread), and the O_DIRECT variant (what `-task query` literally does: reopen + 4 KB reads per query)."""
+    from oracle import dtc_oracle as O
+    orc = O.Oracle()
+    cb, payload, n, k = wl["codebook"], wl["payload"], wl["n_local"], args.topk
     t0 = time.time()
-    for i in range(n1):
-        orc.query_in_memory(payload, args.n, cb, qs[i], args.topk)
+    orc.query_many(payload, n, cb, queries[:1], k, 1)
+    per_query = max(time.time() - t0, 1e-4)
+    n1 = int(min(len(queries), max(2, args.cpu_seconds / per_query)))
+    t0 = time.time()
+    orc.query_many(payload, n, cb, queries[:n1], k, 1)
     t1 = time.time() - t0
-    cores = os.cpu_count() or 1
-    nall = min(len(qs), max(n1, cores * 8))
-    with ThreadPoolExecutor(cores) as ex:   # ctypes releases the GIL; one query per task
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    nall = int(min(len(queries), max(cores, cores * (args.cpu_seconds / 2) / (t1 / n1))))
+    t0 = time.time()
+    orc.query_many(payload, n, cb, queries[:nall], k, cores)
+    tall = time.time() - t0
+    od = None
+    try:
+        from deltapq_amd import synth
+        d = tempfile.mkdtemp(prefix="dpq_bench_", dir=os.path.join(HERE, "gpurun_out") if os.path.isdir(os.path.join(HERE, "gpurun_out")) else None)
+        path = synth.dtc_file_name(d, args.m, 256, n)
+        synth.write_dtc_file(path, n, payload)
+        honoured = orc.o_direct_supported(path)
+        n_od = int(min(len(queries), max(2, 3.0 / (5 * t1 / n1))))
         t0 = time.time()
-        list(ex.map(lambda i: orc.query_in_memory(payload, args.n, cb, qs[i], args.topk), range(nall)))
-        tall = time.time() - t0
+        for i in range(n_od):
+            orc.query_o_direct(path, n, cb, queries[i], k)
+        tod = time.time() - t0
+        od = {"value": n_od / tod, "ms_per_query": 1e3 * tod / n_od, "queries": n_od, "o_direct_honoured_by_filesystem": honoured}
+        os.remove(path)
+        os.rmdir(d)
+    except Exception as e:  # the baseline leg must not take the bench down
+        od = {"error": repr(e)}
     return {"value": n1 / t1, "unit": "queries/s", "cores": 1, "kind": "port",
-            "sample": "first %d of the %d queries, full N=%d index, in-memory scan (query_im twin), %.1f s"
-                      % (n1, len(qs), args.n, t1),
+            "sample": "first %d of the %d queries of batch 0, %s N=%d index, in-memory scan (query_im twin), %.1f s; oracle built -O3"
+                      % (n1, len(queries), "full" if wl["whole"] else "this rank's part of the", n, t1),
             "ms_per_query": 1e3 * t1 / n1,
-            "all_cores": {"value": nall / tall, "cores": cores, "queries": nall}}
+            "all_cores": {"value": nall / tall, "unit": "queries/s", "cores": cores, "queries": nall,
+                          "how": "one query at a time per std::thread inside liboracle.so"},
+            "o_direct_variant_1_thread": od}
 
 
 def main():
@@ -110,8 +183,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--reps", type=int, default=10, help="repetitions of the timed K-step region (median is the value)")
     ap.add_argument("--n", "--codes", dest="n", type=int, default=1_000_000,
-                    help="codes in the index (under torch.distributed.run use --codes: its parser takes --n for its own)")
+                    help="codes in the whole index (under torch.distributed.run use --codes: its parser takes --n for its own)")
     ap.add_argument("--queries", type=int, default=1000)
     ap.add_argument("--topk", type=int, default=100)
     ap.add_argument("--m", type=int, default=8)
@@ -119,14 +193,15 @@ def main():
     ap.add_argument("--data", choices=["pipeline", "stream"], default="pipeline")
     ap.add_argument("--mean-diffs", type=float, default=3.0, help="changed bytes per node (--data stream)")
     ap.add_argument("--chunks-per-segment", type=int, default=0)
-    ap.add_argument("--cpu-queries", type=int, default=700, help="queries timed on the CPU oracle (1 thread)")
+    ap.add_argument("--bootstrap", type=int, default=0, help="dpq_open_opts.bootstrap: 0 auto, 1 on, -1 off")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU time given to each leg of the oracle baseline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--check", type=int, default=4, help="queries verified against the oracle before timing")
-    ap.add_argument("--shard", choices=["auto", "query", "index"], default="auto",
-                    help="N > 1: 'query' = every GPU holds the whole index and answers its own batch of --queries "
-                         "(independent units, no data-path collective, weak scaling); 'index' = the index is cut into "
-                         "DFS ranges, every GPU answers the one batch on its range, one all-gather + merge (strong "
-                         "scaling; what an index beyond one GPU's HBM needs); auto = query while the index fits")
+    ap.add_argument("--check", type=int, default=64, help="queries verified against the oracle before timing (time-bounded)")
+    ap.add_argument("--shard", choices=["auto", "index", "query"], default="auto",
+                    help="N > 1: 'index' (= auto) cuts the index into DFS ranges, every GPU answers the one batch on its "
+                         "range, one all-gather + merge (strong scaling, the north-star decomposition); 'query' = every GPU "
+                         "holds the whole index and answers its own batch (weak scaling, no collective)")
+    ap.add_argument("--also-replicas", action="store_true", help="N > 1 index shards: also time query replicas afterwards")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="gloo = rehearsal of the N > 1 path on a box with fewer GPUs than ranks (ranks share GPUs)")
     args = ap.parse_args()
@@ -134,6 +209,7 @@ def main():
     import torch
     import torch.distributed as dist
     from deltapq_amd import api
+    from deltapq_amd import dist as dpq_dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -159,123 +235,109 @@ def main():
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    # N > 1 decomposition.  Queries are independent units: while the whole index fits one GPU (4.5 MB at
-    # 1 M codes, 4.5 GB at 1 B codes, of 288 GB) every GPU keeps a replica and answers its own batch --
-    # no data-path collective, per-GPU work fixed ("weak").  Index sharding (DFS ranges, one all-gather
-    # of the partial lists + merge, "strong") is what larger indexes need; it is measured beside it.
-    shard_mode = args.shard
-    if shard_mode == "auto":
-        shard_mode = "query" if (5 * args.n) < (64 << 30) else "index"
-    weak = shard_mode == "query"   # the label the N > 1 runs of this mode carry; at N = 1 both modes are the same run
-    by_query = weak and world > 1
-    wl = build_workload(args, local_rank, query_seed=101 + (rank if by_query else 0))
-    idx = api.DeltaPQIndex.open_memory(wl["payload"], args.n, args.m, 256, device=local_rank,
-                                       shard_rank=0 if by_query else rank, shard_count=1 if by_query else world,
-                                       chunks_per_segment=args.chunks_per_segment)
-    idx.set_codebook(wl["codebook"])
-    info = idx.info()
-    q_dev = torch.from_numpy(wl["queries"]).to(dev)
+    by_query = world > 1 and args.shard == "query"
     nq, k = args.queries, args.topk
+    wl = build_workload(args, local_rank, rank, world, by_query)
+
+    def open_index(**kw):
+        idx = api.DeltaPQIndex.open_memory(wl["payload"], wl["n_local"], args.m, 256, device=local_rank,
+                                           chunks_per_segment=args.chunks_per_segment, bootstrap=args.bootstrap, **kw)
+        idx.set_codebook(wl["codebook"])
+        return idx
+
+    idx = open_index(**wl["open_kwargs"])
+    info = idx.info()
+    # N_BATCHES distinct query batches; index shards answer the SAME batch on every rank, replicas their own
+    batches_np = [make_queries(args, 101 + b + (1000 * rank if by_query else 0)) for b in range(N_BATCHES)]
+    batches = [torch.from_numpy(b).to(dev) for b in batches_np]
     ids = torch.empty((nq, k), dtype=torch.int32, device=dev)
     dists = torch.empty((nq, k), dtype=torch.float32, device=dev)
-    from deltapq_amd import dist as dpq_dist
 
     # Batches that no collective follows are pipelined (dpq_query_batch_device_async): a step enqueues its
     # batch, sync() settles them all (dpq_finish: waits, checks the overflow words, reruns if needed).
-    pipelined = by_query or world == 1
+    sharded = world > 1 and not by_query
+    pipelined = not sharded
 
-    def step():
-        idx.query_batch_torch(q_dev, k, ids, dists, wait=not pipelined)
+    def step(i, index=None):
+        (index or idx).query_batch_torch(batches[i % N_BATCHES], k, ids, dists, wait=not pipelined)
         if pipelined:
             return ids, dists   # this rank's batch; complete after sync()
         # index shards: the path's one exchange step -- all-gather of the partial lists
-        # (nq*k*8 B per rank) over RCCL, then the device merge
+        # (nq * k * 8 B per rank) over RCCL, then the device merge
         return dpq_dist.gather_and_merge(ids, dists)
 
-    def sync():
-        idx.finish()
+    def sync(index=None):
+        (index or idx).finish()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    # correctness gate before timing (rank 0, a few queries, against the oracle)
-    out_ids, out_dists = step()
+    # correctness gate before timing (rank 0, against the oracle)
+    out_ids, out_dists = step(0)
     sync()
-    parity = None
+    parity = 0
     if rank == 0 and args.check > 0:
-        from oracle import dtc_oracle as O
-        orc = O.Oracle()
-        hi, hd = out_ids.cpu().numpy(), out_dists.cpu().numpy()
-        parity = True
-        for i in range(min(args.check, nq)):
-            lut = orc.build_lut(wl["codebook"], wl["queries"][i])
-            oi, od, alld, _ = orc.scan_lut(wl["payload"], args.n, lut, k, want_all=True)
-            ok, msg = O.tie_aware_equal(hi[i], hd[i], oi, od, alld, args.n)
-            if not ok:
-                parity = False
-                print("bench.py: PARITY FAILURE on query %d: %s" % (i, msg), file=sys.stderr)
-        if not parity:
-            sys.exit(4)
+        if wl["whole"]:
+            parity = parity_gate(args, wl, batches_np[0], out_ids.cpu().numpy(), out_dists.cpu().numpy())
+        else:   # own part of a larger index: the rank's partial lists (still in ids / dists) against the oracle on the part
+            parity = parity_gate(args, wl, batches_np[0], ids.cpu().numpy(), dists.cpu().numpy())
+            m_ids = out_ids.cpu().numpy()
+            assert np.all(np.diff(out_dists.cpu().numpy(), axis=1) >= 0) and m_ids.min() >= 0 and m_ids.max() <= args.n
 
-    for _ in range(args.warmup):
-        step()
-    # Timed region: HIP events bracket the scan launches only (the roofline kernel); an event pair
-    # costs ~4 us of stream time, so the other kernels are timed in a short untimed pass afterwards.
+    def timed(index=None, reps=args.reps):
+        """--reps repetitions of the K-step region; returns the per-repetition wall times (max over ranks)."""
+        for i in range(args.warmup):
+            step(i, index)
+        sync(index)
+        times = []
+        for _ in range(max(1, reps)):
+            sync(index)
+            t0 = time.perf_counter()
+            for i in range(args.steps):
+                step(i, index)
+            sync(index)
+            times.append(time.perf_counter() - t0)
+        t = torch.tensor(times, dtype=torch.float64, device=torch.device("cpu") if cpu_coll else dev)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return t.cpu().numpy()
+
+    # HIP events bracket the scan launches only in the timed regions (the roofline kernel; an event pair costs
+    # ~4 us of stream time); the other kernels are timed in a short untimed pass afterwards.
     idx.profile_enable(0 if os.environ.get("DPQ_BENCH_NOPROF") else 2)
     idx.profile_reset()
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    sync()
-    elapsed = time.perf_counter() - t0
+    times = timed()
     prof = idx.profile_read()
     aux_steps = max(1, min(args.steps, 5))
     idx.profile_enable(1)
     idx.profile_reset()
-    for _ in range(aux_steps):
-        step()
+    for i in range(aux_steps):
+        step(i)
     sync()
     prof_aux = idx.profile_read()
     idx.profile_enable(0)
-    prof["exact_checks_per_query"] = prof_aux["exact_checks"] / max(1, aux_steps * args.queries)
-    prof["candidates_per_query"] = prof_aux["candidates"] / max(1, aux_steps * args.queries)
-    prof["select_ms"] = prof_aux["select_ms"] * args.steps / aux_steps
-    prof["lut_ms"] = prof_aux["lut_ms"] * args.steps / aux_steps
+    total_steps = args.steps * max(1, args.reps)
 
-    # N > 1 with replicas: also time the index-sharded decomposition of ONE batch (rank 0's queries), outside
-    # the timed region, so both ways of using the GPUs are on record
-    alt = None
-    if world > 1 and by_query:
-        q0 = torch.from_numpy(make_queries(args, 101)).to(dev)
-        sidx = api.DeltaPQIndex.open_memory(wl["payload"], args.n, args.m, 256, device=local_rank, shard_rank=rank,
-                                            shard_count=world, chunks_per_segment=args.chunks_per_segment)
-        sidx.set_codebook(wl["codebook"])
+    replicas = None
+    if sharded and args.also_replicas and wl["whole"]:
+        ridx = open_index()
+        pipelined = True
+        rt = timed(ridx, reps=3)
+        pipelined = False
+        replicas = {"note": "same GPUs, every rank holds the whole index and answers its own %d-query batch; no collective" % nq,
+                    "value": world * nq * args.steps / float(np.median(rt)), "unit": "queries/s", "scaling": "weak",
+                    "ms_per_step": 1e3 * float(np.median(rt)) / args.steps}
+        ridx.close()
 
-        def sstep():
-            sidx.query_batch_torch(q0, k, ids, dists)
-            return dpq_dist.gather_and_merge(ids, dists)
-
-        m_ids, _ = sstep()
-        for _ in range(args.warmup):
-            sstep()
-        sync()
-        ta = time.perf_counter()
-        for _ in range(args.steps):
-            sstep()
-        sync()
-        alt = time.perf_counter() - ta
-        sidx.close()
-
-    cdev = torch.device("cpu") if cpu_coll else dev
-    t = torch.tensor([elapsed, alt or 0.0], dtype=torch.float64, device=cdev)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed, alt = float(t[0].item()), float(t[1].item())
-    # per-rank scan figures -> rank 0 (sum of algorithmic bytes, max of kernel time)
+    QG = 64 if args.m <= 8 else 16
+    groups = (nq + QG - 1) // QG
+    S = 64 * info["chunks_per_segment"]
+    lds_bytes_step = float(info["n_segments"]) * S * groups * (4 if args.m <= 8 else 2) * args.m * 16   # NG * M * 16 B per node and group
     stats = torch.tensor([prof["scan_ms"], float(prof["scan_launches"]), float(info["algorithmic_bytes"]),
-                          float(info["device_bytes"]), prof["select_ms"], prof["lut_ms"]], dtype=torch.float64,
-                         device=cdev)
+                          float(info["device_bytes"] + info["bootstrap_bytes"]), prof_aux["select_ms"], prof_aux["lut_ms"],
+                          prof_aux["quantise_ms"], lds_bytes_step, float(prof_aux["exact_checks"]), float(prof_aux["candidates"]),
+                          float(info["node_hi"] - info["node_lo"])],
+                         dtype=torch.float64, device=torch.device("cpu") if cpu_coll else dev)
     if world > 1:
         all_stats = [torch.zeros_like(stats) for _ in range(world)]
         dist.all_gather(all_stats, stats)
@@ -284,73 +346,95 @@ def main():
         all_stats = stats.cpu().numpy()[None, :]
 
     if rank == 0:
-        steps = max(1, args.steps)
-        scan_ms_step = float(all_stats[:, 0].max()) / steps              # slowest rank
-        launches_step = float(all_stats[0, 1]) / steps
-        alg_bytes_total = float(all_stats[:, 2].sum())   # index shards: n_bytes of the payload; replicas: world x n_bytes
-        achieved = (nq * alg_bytes_total) / (scan_ms_step * 1e-3) / 1e9 if scan_ms_step > 0 else 0.0
-        peak = HBM_PEAK_GBPS * world
-        traffic, traffic_tag = measured_traffic(args)
+        med = float(np.median(times))
+        scan_ms_step = float(all_stats[:, 0].max()) / total_steps          # slowest rank
+        launches_step = float(all_stats[0, 1]) / total_steps
+        alg_bytes_total = float(all_stats[:, 2].sum())     # index shards: n_bytes of the payload; replicas: world x n_bytes
+        lds_total = float(all_stats[:, 7].sum())
+        lds_gbps = lds_total / (scan_ms_step * 1e-3) / 1e9 if scan_ms_step > 0 else 0.0
+        traffic, pmc_launch_ms, pmc_name = pmc_traffic(args, world)
+        avg_launch_ms = scan_ms_step / launches_step if launches_step else None
+        global_q = (world if by_query else 1) * nq
+        bytes_per_code = float(all_stats[:, 2].sum()) / max(1.0, float(all_stats[:, 10].sum()))
         result = {
             "metric": "queries/sec, SIFT1M-shaped m=%d k=256 topk=%d" % (args.m, k),
-            "value": (world if by_query else 1) * nq * steps / elapsed,
+            "value": global_q * args.steps / med,
             "unit": "queries/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / steps,
+            "ms_per_step": 1e3 * med / args.steps,
             "higher_is_better": True,
-            "scaling": "weak" if weak else "strong",
+            "scaling": "weak" if by_query else "strong",
             "vs_baseline": None,
-            "dtype": "f64-sum-of-f32 (u8 code decode)",
+            "dtype": "f64 sum of f32 table entries (u8 code decode; the reference's incremental f64 stack)",
             "data": "synthetic",
             "config": {
-                "workload": "SIFT1M-shaped synthetic (%s): N=%d m=%d k=256 h=1 topk=%d, %d queries/step, "
-                            "%.2f B/code, %.2f diffs/node" % (wl["desc"], args.n, args.m, k, nq, wl["n_bytes"] / args.n,
-                                                              (wl["n_bytes"] - args.m) / args.n - (1.5 if args.m <= 8 else 2.5)),
-                "n_codes": args.n, "queries_per_step": nq, "topk": k, "n_bytes": int(wl["n_bytes"]),
-                "sharding": ("query replicas x%d: every GPU holds the whole index and answers its own %d-query batch"
-                             % (world, nq)) if weak else "dfs-range index shards x%d, one batch" % world,
-                "global_queries_per_step": (world if by_query else 1) * nq,
-                "queries_per_decode_pass": 64 if args.m <= 8 else 16,
+                "workload": "SIFT1M-shaped synthetic (%s): N=%d m=%d k=256 h=1 topk=%d, %d queries/step, %.2f B/code"
+                            % (wl["desc"], args.n, args.m, k, nq, bytes_per_code),
+                "n_codes": args.n, "queries_per_step": nq, "topk": k,
+                "n_bytes": int(alg_bytes_total if not by_query else alg_bytes_total / world),
+                "sharding": "one GPU, whole index" if world == 1 else
+                            ("query replicas x%d: every GPU holds the whole index and answers its own %d-query batch" % (world, nq)
+                             if by_query else "dfs-range index shards x%d, one %d-query batch, one all-gather + merge" % (world, nq)),
+                "global_queries_per_step": global_q,
+                "query_batches_rotated": N_BATCHES,
+                "queries_per_decode_pass": QG,
+                "threshold_bootstrap": "multi-index, stride %d, %.1f MB" % (info["bootstrap_stride"], info["bootstrap_bytes"] / 1e6)
+                                       if info["bootstrap_bytes"] else "off (spread-sample cascade)",
             },
+            "repetitions": {"count": int(len(times)), "steps_each": args.steps,
+                            "ms_per_step_median": 1e3 * med / args.steps,
+                            "ms_per_step_min": 1e3 * float(times.min()) / args.steps,
+                            "ms_per_step_max": 1e3 * float(times.max()) / args.steps,
+                            "value_min": global_q * args.steps / float(times.max()),
+                            "value_max": global_q * args.steps / float(times.min())},
             "roofline": {
-                "bound": "hbm",
+                "bound": "lds",
                 "kernel": "scan_kernel",
-                "achieved": achieved,
-                "peak": peak,
+                "achieved": lds_gbps,
+                "peak": LDS_PEAK_GBPS * world,
                 "unit": "GB/s",
-                "frac": achieved / peak,
+                "frac": lds_gbps / (LDS_PEAK_GBPS * world),
                 "traffic": traffic,
-                "traffic_note": ("HBM bytes per scan launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
-                                 "passes (%s), 2x gfx950 read correction; compare with algorithmic_bytes_per_launch"
-                                 % traffic_tag) if traffic else "not collected for this workload",
-                "algorithmic_bytes_per_launch": nq * alg_bytes_total / launches_step if launches_step else None,
-                "algorithmic_bytes_per_step": nq * alg_bytes_total,
+                "definition": "achieved = LDS bytes of the ADC table gathers the scan launches issue (per decoded node and "
+                              "64-query group: M x 4 ds_read_b128 = %d B, i.e. %d B per (code, query) pair, padding slots "
+                              "included) / scan-kernel time (HIP events on the launch stream); peak = 256 CUs x 256 B/clk x "
+                              "2.4 GHz.  The scan is a gather/lookup kernel bound by the LDS array (bank-conflict replays and the "
+                              "decode's ds_bpermute traffic come on top of the counted bytes), not by HBM: see `hbm`."
+                              % ((4 if args.m <= 8 else 2) * args.m * 16, args.m if args.m <= 8 else 2 * args.m),
+                "lds_gather_bytes_per_step": lds_total,
+                "hbm": None if traffic is None else {
+                    "achieved": traffic / ((pmc_launch_ms or avg_launch_ms) * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                    "frac": traffic / ((pmc_launch_ms or avg_launch_ms) * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                    "bytes_per_launch": traffic, "source": "profiles/%s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, "
+                                                           "2 x FETCH_SIZE + WRITE_SIZE (gfx950 correction)" % pmc_name},
+                "algorithmic_hbm": {
+                    "GBps": (nq * alg_bytes_total) / (scan_ms_step * 1e-3) / 1e9 if scan_ms_step > 0 else 0.0,
+                    "bytes_per_step": nq * alg_bytes_total,
+                    "note": "SURVEY.md 8(d) figure: queries x DTC payload bytes / scan time.  Every decoded chunk serves %d "
+                            "queries, so this is reuse, not traffic: it is NOT a fraction of the HBM roof" % QG},
                 "launches_per_step": launches_step,
-                "avg_launch_ms": scan_ms_step / launches_step if launches_step else None,
+                "avg_launch_ms": avg_launch_ms,
                 "scan_ms_per_step": scan_ms_step,
-                "select_ms_per_step": float(all_stats[:, 4].max()) / steps,
-                "lut_ms_per_step": float(all_stats[:, 5].max()) / steps,
-                "filter_survivors_per_query": prof["exact_checks_per_query"],
-                "candidates_per_query": prof["candidates_per_query"],
-                "event_note": "timed region: HIP events around the scan launches only; select/lut figures from %d "
-                              "untimed steps run afterwards with events around every kernel" % aux_steps,
-                "note": "achieved = queries x DTC payload bytes / scan-kernel time (HIP events on the launch "
-                        "stream, all cascade levels of a step summed); each decoded chunk serves 64 queries (16 at m=16), so "
-                        "physical traffic is a small fraction of this figure and frac can exceed 1 (see DESIGN.md)",
+                "select_ms_per_step": float(all_stats[:, 4].max()) / aux_steps,
+                "lut_ms_per_step": float(all_stats[:, 5].max()) / aux_steps,
+                "quantise_ms_per_step": float(all_stats[:, 6].max()) / aux_steps,
+                "filter_survivors_per_query": float(all_stats[:, 8].sum()) / max(1, aux_steps * nq),
+                "candidates_per_query": float(all_stats[:, 9].sum()) / max(1, aux_steps * nq),
+                "event_note": "timed regions: HIP events around the scan launches only; select (incl. bootstrap) / lut / quantise "
+                              "figures from %d untimed steps run afterwards with events around every kernel (each event pair adds "
+                              "~4 us of stream time to them)" % aux_steps,
             },
-            "parity_checked_queries": min(args.check, nq) if parity else 0,
+            "parity_checked_queries": parity,
             "index": {"device_bytes_rank0": int(all_stats[0, 3]), "segments_rank0": info["n_segments"],
-                      "gen_seconds": wl["gen_s"]},
+                      "codes_rank0": int(all_stats[0, 10]), "gen_seconds": wl["gen_s"]},
         }
-        if alt:
-            result["index_sharded"] = {
-                "note": "same GPUs, the index cut into %d DFS ranges, ONE %d-query batch answered by all of them "
-                        "(all-gather of the partial lists + merge); %d steps timed after the main region" % (world, nq, steps),
-                "value": nq * steps / alt, "unit": "queries/s", "ms_per_step": 1e3 * alt / steps, "scaling": "strong"}
+        if replicas:
+            result["query_replicas"] = replicas
         if world == 1 and not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(wl, args)
+            result["cpu_baseline"] = cpu_baseline(wl, args, batches_np[0])
+            result["vs_cpu_baseline_1_thread"] = result["value"] / result["cpu_baseline"]["value"]
         print(json.dumps(result))
     idx.close()
     if world > 1:

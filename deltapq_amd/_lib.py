@@ -15,7 +15,8 @@ P = ctypes.POINTER
 
 class OpenOpts(ctypes.Structure):
     _fields_ = [("device", c_i32), ("shard_rank", c_i32), ("shard_count", c_i32), ("chunks_per_segment", c_i32),
-                ("cand_capacity", c_i32), ("num_codes", c_i32), ("bootstrap", c_i32), ("reserved", c_i32 * 1)]
+                ("cand_capacity", c_i32), ("num_codes", c_i32), ("bootstrap", c_i32), ("reserved", c_i32 * 1),
+                ("global_offset", c_i64), ("global_n_codes", c_i64)]
 
 
 class Info(ctypes.Structure):

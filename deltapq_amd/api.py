@@ -215,10 +215,13 @@ class DeltaPQIndex:
 
     @classmethod
     def open_memory(cls, payload, n_codes, M=8, K=256, device=0, shard_rank=0, shard_count=1, chunks_per_segment=0,
-                    cand_capacity=0, num_codes=0, bootstrap=0):
+                    cand_capacity=0, num_codes=0, bootstrap=0, global_offset=0, global_n_codes=0):
+        """global_offset / global_n_codes: the payload is a self-contained part of a larger index (ids are
+        reported as global_offset + local position; dpq_open_opts)."""
         lib = _lib.load()
         pl = np.ascontiguousarray(payload, dtype=np.uint8)
-        opts = OpenOpts(device, shard_rank, shard_count, chunks_per_segment, cand_capacity, num_codes, bootstrap)
+        opts = OpenOpts(device, shard_rank, shard_count, chunks_per_segment, cand_capacity, num_codes, bootstrap,
+                        (0,), global_offset, global_n_codes)
         h = ctypes.c_void_p()
         check(lib.dpq_open_memory(_np_ptr(pl), pl.size, n_codes, M, K, opts, h), "dpq_open_memory")
         return cls(h)

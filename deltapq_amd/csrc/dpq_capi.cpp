@@ -611,6 +611,9 @@ int open_from_payload(const uint8_t* payload, int64_t n_bytes, int64_t n_codes, 
     if (M != 8 && M != 16)
         return fail(DPQ_ERR_ARG, "this build has scan kernels for M = 8 (reference format) and M = 16 (own extension)");
     if (K < 1 || K > 256) return fail(DPQ_ERR_ARG, "K must be in 1..256 (one byte per sub-code)");
+    if (o.global_offset < 0 || o.global_n_codes < 0 ||
+        (o.global_n_codes > 0 && (o.global_offset + n_codes > o.global_n_codes || o.global_n_codes >= (int64_t)INT32_MAX)))
+        return fail(DPQ_ERR_ARG, "global_offset / global_n_codes do not enclose this payload (or ids beyond 2^31)");
     if (o.chunks_per_segment > dpq::kSortMax / dpq::kChunk)
         return fail(DPQ_ERR_ARG, "chunks_per_segment must be <= 64 (a segment is the cascade's level-0 unit)");
     int ndev = 0;
@@ -651,6 +654,8 @@ int open_from_payload(const uint8_t* payload, int64_t n_bytes, int64_t n_codes, 
     if (!rc) rc = up(&x->d_delta, soa.delta.data(), soa.delta.size());
     if (!rc) rc = up(&x->d_seg_off, soa.seg_delta_off.data(), soa.seg_delta_off.size() * 8);
     if (!rc) rc = up(&x->d_ckpt, soa.seg_ckpt.data(), soa.seg_ckpt.size());
+    if (o.global_offset != 0)
+        for (uint32_t& id : soa.mi_id) id += (uint32_t)o.global_offset;
     if (!rc && soa.mi_stride > 0 && (int64_t)soa.mi_id.size() >= 16384) {
         rc = up(&x->d_mi_cell, soa.mi_cell_start.data(), soa.mi_cell_start.size() * 4);
         if (!rc) rc = up(&x->d_mi_code, soa.mi_code.data(), soa.mi_code.size() * 4);
@@ -667,18 +672,18 @@ int open_from_payload(const uint8_t* payload, int64_t n_bytes, int64_t n_codes, 
     x->img.seg_delta_off = x->d_seg_off;
     x->img.seg_ckpt = x->d_ckpt;
     x->img.n_local = soa.node_hi - soa.node_lo;
-    x->img.n_codes_total = soa.n_codes_total;
-    x->img.id_base = (uint32_t)soa.node_lo;
+    x->img.n_codes_total = o.global_n_codes > 0 ? o.global_n_codes : soa.n_codes_total;
+    x->img.id_base = (uint32_t)(o.global_offset + soa.node_lo);
     x->img.n_segments = (int32_t)soa.n_segments;
     x->img.chunks_per_segment = soa.chunks_per_segment;
     x->img.M = M;
     x->img.K = K;
 
     dpq_info& inf = x->info;
-    inf.n_codes_total = soa.n_codes_total;
+    inf.n_codes_total = x->img.n_codes_total;
     inf.n_bytes_total = soa.n_bytes_total;
-    inf.node_lo = soa.node_lo;
-    inf.node_hi = soa.node_hi;
+    inf.node_lo = o.global_offset + soa.node_lo;
+    inf.node_hi = o.global_offset + soa.node_hi;
     inf.algorithmic_bytes = soa.algorithmic_bytes;
     inf.device_bytes = soa.device_bytes();
     inf.bootstrap_bytes = x->boot ? soa.bootstrap_bytes() : 0;

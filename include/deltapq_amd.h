@@ -95,6 +95,10 @@ typedef struct dpq_open_opts {
                                  * cascade alone).  Results are identical either way.  dpq_soa_build: > 0 = build the
                                  * multi-index with this sampling stride. */
     int32_t reserved[1];
+    int64_t global_offset;      /* the payload is a self-contained PART of a larger index (its first node carries a
+                                 * whole code): ids are reported as global_offset + position in this payload */
+    int64_t global_n_codes;     /* 0 = this payload is the whole index; else N of the larger index (the even-N id
+                                 * rule h:2949, 2970 then applies to its last node only) */
 } dpq_open_opts;
 
 typedef struct dpq_info {

@@ -30,7 +30,7 @@
 // stack machine to this build's own format extension (2-byte little-endian
 // masks, 4-bit depth fields) -- a consistency oracle, not a reference one.
 //
-// Build: see oracle/Makefile (g++ -O2 -ffp-contract=off).
+// Build: see oracle/Makefile (g++ -O3 -ffp-contract=off, the reference's optimisation level, CMakeLists.txt:10).
 
 #include <algorithm>
 #include <cerrno>
@@ -41,8 +41,10 @@
 #include <cstring>
 #include <fcntl.h>
 #include <fstream>
+#include <atomic>
 #include <queue>
 #include <string>
+#include <thread>
 #include <unistd.h>
 #include <utility>
 #include <vector>
@@ -228,6 +230,41 @@ int oracle_query_in_memory(const uchar* payload, long long n_bytes, const float*
     MemSource src{payload, 0};
     scan(src, lut.data(), top_k, M, K, num_codes, out_ids, out_dists, nullptr, nullptr);
     return 0;
+}
+
+// CPU baseline helper (bench.py): the in-memory query above for `nq` queries on `n_threads` std::threads,
+// one query at a time per thread (queries are independent; the reference itself is single-threaded, main:328).
+// out_ids / out_dists: [nq][top_k].
+int oracle_query_many(const uchar* payload, long long n_bytes, const float* queries, int nq, int top_k, int M, int K,
+                      int Ds, long long num_codes, const float* codebook, int n_threads, int* out_ids,
+                      float* out_dists) {
+    if (num_codes < top_k || top_k < 1 || nq < 0 || n_threads < 1) return -1;
+    std::atomic<int> next(0);
+    auto work = [&]() {
+        std::vector<float> lut((size_t)M * K);
+        for (;;) {
+            const int q = next.fetch_add(1);
+            if (q >= nq) break;
+            build_lut(codebook, queries + (size_t)q * M * Ds, M, K, Ds, lut.data());
+            MemSource src{payload, 0};
+            scan(src, lut.data(), top_k, M, K, num_codes, out_ids + (size_t)q * top_k, out_dists + (size_t)q * top_k,
+                 nullptr, nullptr);
+        }
+    };
+    (void)n_bytes;
+    std::vector<std::thread> th;
+    for (int t = 1; t < n_threads; ++t) th.emplace_back(work);
+    work();
+    for (auto& t : th) t.join();
+    return 0;
+}
+
+// 1 if the filesystem holding `path` accepts O_DIRECT (what the reference's -task query opens with, h:2818).
+int oracle_o_direct_supported(const char* path) {
+    int fd = open(path, O_DIRECT | O_RDONLY);
+    if (fd < 0) return 0;
+    close(fd);
+    return 1;
 }
 
 // Same scan with a precomputed LUT (lets tests separate a3 from a5/a6) and the

@@ -60,6 +60,9 @@ class Oracle:
                                             ctypes.c_int, ctypes.c_longlong, _c_f, _c_i, _c_f]
         L.oracle_pqscan_plain.argtypes = [_c_u8, ctypes.c_longlong, _c_f, ctypes.c_int, ctypes.c_int,
                                           ctypes.c_int, _c_i, _c_f]
+        L.oracle_query_many.argtypes = [_c_u8, ctypes.c_longlong, _c_f, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                        ctypes.c_int, ctypes.c_int, ctypes.c_longlong, _c_f, ctypes.c_int, _c_i, _c_f]
+        L.oracle_o_direct_supported.argtypes = [ctypes.c_char_p]
         L.oracle_read_codewords.argtypes = [ctypes.c_char_p, _c_i, _c_i, _c_i, _c_f]
         L.oracle_read_vecs.argtypes = [ctypes.c_char_p, ctypes.c_int, _c_i, _c_f, ctypes.c_longlong]
         L.oracle_read_vecs.restype = ctypes.c_longlong
@@ -87,6 +90,23 @@ class Oracle:
         if rc != 0:
             raise ValueError("oracle_query_in_memory rc=%d" % rc)
         return ids, dists
+
+    def query_many(self, payload, n_codes, codebook, queries, top_k, n_threads):
+        """The in-memory query for a batch of queries on n_threads C++ threads (CPU baseline of bench.py)."""
+        cb = np.ascontiguousarray(codebook, dtype=np.float32)
+        M, K, Ds = cb.shape
+        q = np.ascontiguousarray(queries, dtype=np.float32)
+        pl = np.ascontiguousarray(payload, dtype=np.uint8)
+        ids = np.empty((len(q), top_k), dtype=np.int32)
+        dists = np.empty((len(q), top_k), dtype=np.float32)
+        rc = self.lib.oracle_query_many(_p(pl, _c_u8), pl.size, _p(q, _c_f), len(q), top_k, M, K, Ds, n_codes,
+                                        _p(cb, _c_f), n_threads, _p(ids, _c_i), _p(dists, _c_f))
+        if rc != 0:
+            raise ValueError("oracle_query_many rc=%d" % rc)
+        return ids, dists
+
+    def o_direct_supported(self, path):
+        return bool(self.lib.oracle_o_direct_supported(path.encode()))
 
     def scan_lut(self, payload, n_codes, lut, top_k, want_all=False):
         lut = np.ascontiguousarray(lut, dtype=np.float32)

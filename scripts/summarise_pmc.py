@@ -1,26 +1,44 @@
-"""Summarise a scripts/collect_pmc.sh run: kernel stats CSV + per-kernel mean FETCH_SIZE / WRITE_SIZE."""
+"""Summarise a scripts/collect_pmc.sh run: kernel stats CSV + per-kernel mean FETCH_SIZE / WRITE_SIZE + durations."""
 import collections, csv, glob, json, shutil, sys
 out, tag = sys.argv[1], sys.argv[2]
-summary = {"tag": tag, "unit": "FETCH_SIZE / WRITE_SIZE are KiB per dispatch (rocprofv3); bytes = value * 1024",
+line = json.loads(open("%s/bench_line_under_rocprof.json" % out).read().strip().splitlines()[-1])
+cfg = line["config"]
+summary = {"tag": tag,
+           "workload": {"n": cfg["n_codes"], "queries": cfg["queries_per_step"], "topk": cfg["topk"], "gpus": line["n_gpus"],
+                        "m": 8 if "m=8" in line["metric"] else 16, "data": "pipeline" if "DeltaTree" in cfg["workload"] else "stream",
+                        "description": cfg["workload"]},
+           "unit": "FETCH_SIZE / WRITE_SIZE are KiB per dispatch (rocprofv3); bytes = value * 1024",
            "gfx950_correction": "FETCH_SIZE reads 1/2 of a wide coalesced stream (MI355X_MICROARCH.md HBM section): "
                                 "hbm_read_bytes = 2 * FETCH_SIZE * 1024; dword-per-lane loads are uncalibrated",
            "kernels": {}}
+short = lambda n: n.split("(")[0].replace("void ", "")
 for name in ("fetch", "write"):
     f = glob.glob("%s/pmc_%s/*/*_counter_collection.csv" % (out, name))[0]
     agg = collections.defaultdict(list)
+    dur = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
-        agg[(r["Kernel_Name"].split("(")[0].replace("void ", ""), r["Counter_Name"])].append(float(r["Counter_Value"]))
+        agg[(short(r["Kernel_Name"]), r["Counter_Name"])].append(float(r["Counter_Value"]))
+        if "Start_Timestamp" in r and "End_Timestamp" in r:
+            dur[short(r["Kernel_Name"])].append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
     for (k, c), v in agg.items():
         summary["kernels"].setdefault(k, {})[c] = {"dispatches": len(v), "mean_kib": sum(v) / len(v), "max_kib": max(v)}
+    for k, v in dur.items():
+        summary["kernels"].setdefault(k, {})["avg_ns_under_pmc_" + name] = sum(v) / len(v)
 stats = glob.glob("%s/stats/*/*_kernel_stats.csv" % out)[0]
 shutil.copy(stats, "%s/%s_kernel_stats.csv" % (out, tag))
 for r in csv.DictReader(open(stats)):
-    k = r["Name"].split("(")[0].replace("void ", "")
-    summary["kernels"].setdefault(k, {})["stats"] = {"calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"]),
-                                                     "total_ns": int(r["TotalDurationNs"]), "pct": float(r["Percentage"])}
+    summary["kernels"].setdefault(short(r["Name"]), {})["stats"] = {"calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"]),
+                                                                    "total_ns": int(r["TotalDurationNs"]), "pct": float(r["Percentage"])}
 sc = next((v for k, v in summary["kernels"].items() if k.startswith("dpq::scan_kernel")), {})
 if "FETCH_SIZE" in sc and "WRITE_SIZE" in sc:
     summary["scan_kernel_hbm_bytes_per_launch"] = 2 * sc["FETCH_SIZE"]["mean_kib"] * 1024 + sc["WRITE_SIZE"]["mean_kib"] * 1024
     summary["scan_kernel_hbm_bytes_per_launch_uncorrected"] = (sc["FETCH_SIZE"]["mean_kib"] + sc["WRITE_SIZE"]["mean_kib"]) * 1024
+    summary["scan_kernel_avg_launch_ms_under_pmc"] = sc.get("avg_ns_under_pmc_fetch", sc["stats"]["avg_ns"]) / 1e6
+    summary["scan_kernel_avg_launch_ms_kernel_trace"] = sc["stats"]["avg_ns"] / 1e6
+    summary["scan_kernel_hbm_GBps"] = summary["scan_kernel_hbm_bytes_per_launch"] / (summary["scan_kernel_avg_launch_ms_kernel_trace"] * 1e-3) / 1e9
+summary["bench_line_under_rocprof"] = {k: line[k] for k in ("value", "ms_per_step", "repetitions") if k in line}
 json.dump(summary, open("%s/%s_pmc_summary.json" % (out, tag), "w"), indent=1)
-print(json.dumps(summary, indent=1)[:1500])
+print(json.dumps({k: summary[k] for k in summary if k.startswith("scan_kernel")}, indent=1))
+for k, v in summary["kernels"].items():
+    if "stats" in v and k.startswith("dpq::") and "anonymous" not in k:
+        print("%-46s calls %5d avg %9.1f us" % (k[:46], v["stats"]["calls"], v["stats"]["avg_ns"] / 1e3))

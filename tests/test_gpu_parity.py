@@ -354,10 +354,7 @@ def test_two_process_sharded_run_on_one_gpu(gpu, built):
     assert r.returncode == 0 and "DIST_GPU_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
 
 
-@pytest.mark.parametrize("shard", ["query", "index"])
-def test_bench_two_ranks_rehearsal(gpu, built, shard):
-    """bench.py's N > 1 paths end to end (2 ranks on GPU 0, gloo instead of RCCL): query replicas (weak
-    scaling, index-sharded run timed beside it) and index shards (all-gather + merge, strong scaling)."""
+def _run_bench(extra, nproc=2, timeout=900):
     import json
     import socket
     import sys
@@ -365,20 +362,102 @@ def test_bench_two_ranks_rehearsal(gpu, built, shard):
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+    # exactly the driver's command line for N > 1 (torch.distributed.run, one rank per GPU), plus the test's sizes
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
-           "--gpus", "2", "--backend", "gloo", "--shard", shard, "--data", "stream", "--codes", "200000",
-           "--queries", "100", "--steps", "3", "--warmup", "1", "--check", "2", "--no-cpu-baseline"]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ, OMP_NUM_THREADS="1"), cwd=ROOT)
+           "--gpus", str(nproc)] + extra
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=dict(os.environ, OMP_NUM_THREADS="1"), cwd=ROOT)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
-    line = json.loads(r.stdout.strip().splitlines()[-1])
-    assert line["n_gpus"] == 2 and line["parity_checked_queries"] == 2 and line["value"] > 0
-    assert line["roofline"]["frac"] > 0 and line["roofline"]["launches_per_step"] >= 1
-    if shard == "query":
-        assert line["scaling"] == "weak" and line["config"]["global_queries_per_step"] == 200
-        assert line["index_sharded"]["value"] > 0
+    return json.loads(r.stdout.strip().splitlines()[-1])
+
+
+@pytest.mark.parametrize("mode", ["index_stream_parts", "index_pipeline", "query"])
+def test_bench_two_ranks_rehearsal(gpu, built, mode):
+    """bench.py's N > 1 paths end to end, 2 ranks on GPU 0 (gloo instead of RCCL, ranks share the GPU):
+    index shards where every rank synthesises only its own DFS range (configs[3]/[4] scaled down; the default
+    decomposition, strong scaling), index shards of a pipeline-built index, and query replicas (--shard query)."""
+    common = ["--backend", "gloo", "--queries", "100", "--steps", "3", "--warmup", "1", "--reps", "2", "--check", "3",
+              "--no-cpu-baseline"]
+    if mode == "index_stream_parts":
+        line = _run_bench(common + ["--data", "stream", "--codes", "700001"])
+        assert "own DFS range" in line["config"]["workload"] and line["index"]["codes_rank0"] == 350000
+    elif mode == "index_pipeline":
+        line = _run_bench(common + ["--data", "pipeline", "--codes", "120000", "--also-replicas"])
+        assert line["query_replicas"]["value"] > 0 and line["query_replicas"]["scaling"] == "weak"
     else:
-        assert line["scaling"] == "strong" and "index_sharded" not in line
+        line = _run_bench(common + ["--data", "stream", "--codes", "200000", "--shard", "query"])
+    assert line["n_gpus"] == 2 and line["parity_checked_queries"] == 3 and line["value"] > 0
+    assert 0 < line["roofline"]["frac"] <= 1 and line["roofline"]["bound"] == "lds" and line["roofline"]["launches_per_step"] >= 1
+    assert line["repetitions"]["count"] == 2 and line["repetitions"]["ms_per_step_min"] <= line["ms_per_step"] <= line["repetitions"]["ms_per_step_max"]
+    if mode == "query":
+        assert line["scaling"] == "weak" and line["config"]["global_queries_per_step"] == 200
+    else:
+        assert line["scaling"] == "strong" and line["config"]["global_queries_per_step"] == 100
+        assert "index shards x2" in line["config"]["sharding"]
+
+
+def test_bench_two_gpus_over_rccl(gpu, built):
+    """The RCCL branch of the exchange (all_gather_into_tensor on device tensors + device merge): only where two
+    GPUs are visible (the driver's multi-GPU node); the 1-GPU box skips it."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs 2 visible GPUs (RCCL wants one device per rank)")
+    line = _run_bench(["--backend", "nccl", "--data", "pipeline", "--codes", "300000", "--queries", "200", "--steps", "3",
+                       "--warmup", "1", "--reps", "2", "--check", "8", "--no-cpu-baseline"])
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["parity_checked_queries"] == 8
+
+
+def test_part_of_a_larger_index_reports_global_positions(gpu, oracle, codebook):
+    """dpq_open_opts.global_offset / global_n_codes: a self-contained part of a larger index (what a rank of the
+    100 M / 1 B-code runs holds).  ids = offset + local position; the even-N rule applies to the global tail only."""
+    from deltapq_amd import synth
+    n, nq, k, off = 300000, 16, 50, 1_000_000_000 - 300000
+    tree, payload, _ = make_case(n, seed=31)
+    qs = synth.make_queries(nq, 128, seed=32)
+    ids0, d0, _, _ = run(gpu, payload, n, codebook, qs, k)
+    ids_mid, d_mid, _, info = run(gpu, payload, n, codebook, qs, k, global_offset=12_500_000, global_n_codes=1_000_000_000)
+    assert info["node_lo"] == 12_500_000 and info["n_codes_total"] == 1_000_000_000
+    assert np.array_equal(d0.view(np.uint32), d_mid.view(np.uint32))
+    assert np.array_equal(np.where(ids0 == n, n - 1, ids0) + 12_500_000, ids_mid)        # not the global tail: no id N
+    ids_tail, d_tail, _, _ = run(gpu, payload, n, codebook, qs, k, global_offset=off, global_n_codes=1_000_000_000)
+    assert np.array_equal(ids0.astype(np.int64) + off, ids_tail.astype(np.int64))          # local id n <-> global id N
+    assert_parity(ids0, d0, oracle_topk(oracle, payload, n, codebook, qs, k), n)
+
+
+def test_config4_per_gpu_share_125m_codes_bvecs_queries(gpu, oracle, tmp_path):
+    """BASELINE configs[4]: 1 B bvecs-shaped codes over 8 GPUs = 125 M codes per GPU.  One rank's share on one
+    GPU -- a self-contained part with global_offset = 3 x 125 M (rank 3 of 8), u8 queries read through
+    dpq_read_vecs(.bvecs) -- oracle parity on 4 queries, size-independent properties on the whole batch."""
+    import time
+    from deltapq_amd import synth
+    n, nq, k, rank, N = 125_000_000, 128, 100, 3, 1_000_000_000
+    t0 = time.time()
+    tree = synth.synth_tree_large(n, 8, seed=102 + 1000 * rank, mean_diffs=3.0)
+    payload, nb = synth.encode_dtc(tree)
+    del tree
+    cb = synth.make_codebook(8, 256, 16, seed=100)
+    qpath = str(tmp_path / "query.bvecs")
+    synth.write_bvecs(qpath, synth.make_queries(nq, 128, seed=5))
+    qs = gpu.read_vecs(qpath, ext="bvecs")
+    assert qs.shape == (nq, 128) and qs.dtype == np.float32 and np.all(qs == np.rint(qs))
+    with gpu.DeltaPQIndex.open_memory(payload, n, 8, 256, global_offset=rank * n, global_n_codes=N) as idx:
+        idx.set_codebook(cb)
+        idx.profile_enable(True)
+        ids, dists = idx.query_batch(qs, k)
+        prof, info = idx.profile_read(), idx.info()
+    assert info["node_lo"] == rank * n and info["node_hi"] == (rank + 1) * n and info["algorithmic_bytes"] == nb
+    assert info["bootstrap_stride"] >= 16 and info["device_bytes"] > 256 << 20          # beyond L2 + Infinity Cache
+    S = 64 * info["chunks_per_segment"]
+    assert prof["scan_node_query_pairs"] == info["n_segments"] * S * nq               # every node filtered once per query
+    assert np.all(np.diff(dists, axis=1) >= 0)
+    for r in range(nq):
+        assert len(set(ids[r].tolist())) == k and rank * n <= ids[r].min() and ids[r].max() < (rank + 1) * n
+    sample = [0, 41, 83, 127]
+    local = ids[sample].astype(np.int64) - rank * n
+    ref = oracle_topk(oracle, payload, n, cb, qs[sample], k)
+    ref = [(np.where(oi == n, n - 1, oi), od, alld) for oi, od, alld in ref]             # a part, not the tail: no id-N rule
+    assert_parity(local, dists[sample], ref, n | 1)
+    print("config4 share: %.0f s" % (time.time() - t0))
 
 
 M16_SHAPES = [(1, 3, 1), (2, 2, 2), (65, 5, 10), (1000, 20, 10), (10000, 50, 100), (100001, 40, 1000), (300000, 33, 100)]
