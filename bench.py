@@ -148,6 +148,12 @@ def cpu_baseline(wl, args, queries):
     orc.query_many(payload, n, cb, queries[:n1], k, 1)
     t1 = time.time() - t0
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:   # a container's CPU quota caps what the threads can use whatever the affinity mask says
+        q, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        quota = None if q == "max" else float(q) / float(period)
+    except Exception:
+        pass
     nall = int(min(len(queries), max(cores, cores * (args.cpu_seconds / 2) / (t1 / n1))))
     t0 = time.time()
     orc.query_many(payload, n, cb, queries[:nall], k, cores)
@@ -173,7 +179,7 @@ def cpu_baseline(wl, args, queries):
             "sample": "first %d of the %d queries of batch 0, %s N=%d index, in-memory scan (query_im twin), %.1f s; oracle built -O3"
                       % (n1, len(queries), "full" if wl["whole"] else "this rank's part of the", n, t1),
             "ms_per_query": 1e3 * t1 / n1,
-            "all_cores": {"value": nall / tall, "unit": "queries/s", "cores": cores, "queries": nall,
+            "all_cores": {"value": nall / tall, "unit": "queries/s", "cores": cores, "cgroup_cpu_quota": quota, "queries": nall,
                           "how": "one query at a time per std::thread inside liboracle.so"},
             "o_direct_variant_1_thread": od}
 
@@ -289,6 +295,7 @@ def main():
         for i in range(args.warmup):
             step(i, index)
         sync(index)
+        (index or idx).profile_reset()     # the warm-up steps are not part of the kernel-time figures
         times = []
         for _ in range(max(1, reps)):
             sync(index)

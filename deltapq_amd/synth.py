@@ -76,23 +76,6 @@ def kmeans_codebook(vectors, M=8, K=256, iters=8, seed=0, sample=20000):
     return cb
 
 
-def encode_pq_numpy(vectors, codebook):
-    """PQTree::EncodePlain (pq_tree.cpp:215-237) in numpy float32: `diff = v - c;
-    dist += diff * diff` with separately rounded multiply and add, first minimum wins."""
-    v = np.asarray(vectors, dtype=np.float32)
-    cb = np.asarray(codebook, dtype=np.float32)
-    M, K, Ds = cb.shape
-    codes = np.zeros((len(v), M), dtype=np.uint8)
-    for m in range(M):
-        sub = v[:, m * Ds:(m + 1) * Ds]
-        dist = np.zeros((len(v), K), dtype=np.float32)
-        for d in range(Ds):
-            diff = (sub[:, d:d + 1] - cb[m, :, d][None, :]).astype(np.float32)
-            dist = (dist + (diff * diff).astype(np.float32)).astype(np.float32)
-        codes[:, m] = dist.argmin(1)              # argmin returns the first minimum
-    return codes
-
-
 def _depth_chain(n, rng, max_depth, p_child, p_sibling):
     """DFS depth sequence for nodes 1..n-1: d_i in [1, min(d_{i-1}+1, max_depth)]."""
     if n <= 1:

@@ -4,6 +4,7 @@ import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from deltapq_amd import synth
+from oracle import pq_encode_oracle
 
 N, M, K, NQ, TOPK = int(sys.argv[1]) if len(sys.argv) > 1 else 1000000, 8, 256, 24, 100
 t0 = time.time()
@@ -15,7 +16,7 @@ else:
     base = synth.make_clustered_vectors(N, 128, seed=100, n_clusters=20000, spread=12.0, centre_seed=7)
     queries = synth.make_clustered_vectors(NQ, 128, seed=101, n_clusters=20000, spread=12.0, centre_seed=7)
     cb = synth.kmeans_codebook(base, M, 256, iters=6, seed=102)
-    codes = synth.encode_pq_numpy(base, cb)
+    codes = pq_encode_oracle.encode_pq(base, cb)
     del base
     np.savez(cache, cb=cb, codes=codes, queries=queries)
 print("data %.0f s" % (time.time() - t0), flush=True)

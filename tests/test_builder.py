@@ -102,9 +102,10 @@ def test_reference_artefact_files(lib, tmp_path, codebook):
 
 def test_numpy_encoder_reference_is_nearest_centroid():
     from deltapq_amd import synth
+    from oracle import pq_encode_oracle
     v = synth.make_clustered_vectors(300, 128, seed=1, n_clusters=20)
     cb = synth.kmeans_codebook(v, 8, 16, iters=3, seed=2)
-    codes = synth.encode_pq_numpy(v, cb)
+    codes = pq_encode_oracle.encode_pq(v, cb)
     d = ((v.reshape(300, 8, 1, 16).astype(np.float64) - cb[None].astype(np.float64)) ** 2).sum(-1)
     assert (codes == d.argmin(-1)).mean() > 0.99                       # fp32 vs fp64 may differ only on near ties
 
@@ -112,13 +113,14 @@ def test_numpy_encoder_reference_is_nearest_centroid():
 @pytest.mark.gpu
 def test_gpu_pq_encoder_matches_fp32_reference(lib):
     from deltapq_amd import api, synth
+    from oracle import pq_encode_oracle
     if api.device_count() < 1:
         pytest.fail("no GPU")
     v = synth.make_clustered_vectors(20000, 128, seed=3, n_clusters=400)
     cb = synth.kmeans_codebook(v, 8, 256, iters=4, seed=4)
-    assert np.array_equal(api.encode_pq(v, cb), synth.encode_pq_numpy(v, cb))     # bit-for-bit the same argmin
+    assert np.array_equal(api.encode_pq(v, cb), pq_encode_oracle.encode_pq(v, cb))     # bit-for-bit the same argmin
     cb16 = synth.kmeans_codebook(v, 16, 64, iters=2, seed=5)
-    assert np.array_equal(api.encode_pq(v[:3000], cb16), synth.encode_pq_numpy(v[:3000], cb16))
+    assert np.array_equal(api.encode_pq(v[:3000], cb16), pq_encode_oracle.encode_pq(v[:3000], cb16))
 
 
 @pytest.mark.gpu
@@ -148,6 +150,39 @@ def test_end_to_end_vectors_to_query(lib, oracle):
         alld = sum(lut[m, codes[:, m]].astype(np.float64) for m in range(8)).astype(np.float32)
         assert np.array_equal(alld[orig[i]].view(np.uint32), dists[i].view(np.uint32))
         assert np.sort(alld)[k - 1] == dists[i][-1]                     # really the k best of the raw codes
+
+
+@pytest.mark.parametrize("n,M,with_cb", [(1, 8, False), (2, 8, True), (3, 8, True), (700, 8, True), (6000, 8, True),
+                                          (6000, 8, False), (2500, 16, True)])
+def test_host_builder_matches_the_oracle_restatement(lib, n, M, with_cb):
+    """The product's host builder against oracle/builder_oracle.py (an independent numpy restatement of
+    h:445-627, h:1207-1313, h:1334-1487, h:1156-1183): same edges in the same order, same DFS layout, same stream."""
+    from deltapq_amd import api, synth
+    from oracle import builder_oracle
+    codes = clustered_codes(n, M, seed=3 * n + M)
+    cb = synth.make_codebook(M, 256, 4, seed=n) if with_cb else None
+    ref = builder_oracle.build(codes, cb)
+    t = api.DeltaTree(codes, codebook=cb)
+    assert np.array_equal(t.edges, ref["edges"].reshape(-1, 2))
+    assert np.array_equal(t.vec_id, ref["vec_id"]) and np.array_equal(t.depth, ref["depths"])
+    assert np.array_equal(t.mask, ref["masks"]) and np.array_equal(t.deltas, ref["deltas"])
+    assert np.array_equal(t.payload(), synth.encode_dtc(ref)[0])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,M", [(1, 8), (2, 8), (777, 8), (20000, 8), (8000, 16)])
+def test_gpu_builder_matches_the_oracle_restatement(lib, n, M):
+    """dpq_tree_build_gpu (edge search and tree layout on the device) against oracle/builder_oracle.py."""
+    from deltapq_amd import api, synth
+    from oracle import builder_oracle
+    if api.device_count() < 1:
+        pytest.fail("no GPU")
+    codes = clustered_codes(n, M, seed=n + 11)
+    cb = synth.make_codebook(M, 256, 4, seed=n)
+    ref = builder_oracle.build(codes, cb)
+    t = api.DeltaTree(codes, codebook=cb, device=0)
+    assert np.array_equal(t.edges, ref["edges"].reshape(-1, 2))
+    assert np.array_equal(t.vec_id, ref["vec_id"]) and np.array_equal(t.payload(), synth.encode_dtc(ref)[0])
 
 
 @pytest.mark.gpu

@@ -572,6 +572,7 @@ def test_cli_pqscan_and_compressed_query_agree_through_vec_id(gpu, oracle, tmp_p
     """The compressed scan (DFS positions, fp64 rule) and the plain scan (file positions, fp32 rule) find the
     same vectors: map the former through QNode.vec_id (TreeNodesDFS file) and compare as sets."""
     from deltapq_amd import api, synth
+    from oracle import pq_encode_oracle
     d = str(tmp_path)
     n, nq, k = 20001, 16, 10
     base = synth.make_clustered_vectors(n, 128, seed=3, n_clusters=500)
@@ -586,7 +587,7 @@ def test_cli_pqscan_and_compressed_query_agree_through_vec_id(gpu, oracle, tmp_p
     r = subprocess.run([exe, "-task", "encode"] + common, capture_output=True, text=True, timeout=300)   # base.fvecs -> codes
     assert r.returncode == 0, r.stdout + r.stderr
     codes = api.read_codes_plain(os.path.join(d, "codes.bin.plain.M8K256N%d" % n), 8)
-    assert np.array_equal(codes, synth.encode_pq_numpy(base, cb))
+    assert np.array_equal(codes, pq_encode_oracle.encode_pq(base, cb))
     r = subprocess.run([exe, "-task", "approx_tree"] + common, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout
     res = {}
