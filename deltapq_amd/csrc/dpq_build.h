@@ -45,6 +45,10 @@ void position_subsets(int M, int keep, std::vector<std::vector<int>>* out);  // 
 int find_edges_gpu(const uint8_t* codes, int64_t n, int M, int max_height_folds, int device,
                    std::vector<uint32_t>* finalists, std::vector<std::pair<uint32_t, uint32_t>>* edges,
                    std::string* err);
+// Everything after the edge search on the GPU: the same Tree as layout_tree, array for array.
+int layout_tree_gpu(const uint8_t* codes, int64_t n, int M, int K, int max_height_folds, const float* codewords, int Ds,
+                    const std::vector<uint32_t>& finalists, std::vector<std::pair<uint32_t, uint32_t>>* edges, int device,
+                    Tree* out, std::string* err);
 // DTC payload of the tree (qnodes_to_compressed_codes_opt, h:1765-1826).
 int tree_encode(const Tree& t, std::vector<uint8_t>* payload, std::string* err);
 // The reference's artefacts in `dir`: M{M}K{K}H{h}_Approx_Edges_N{N} (h:1326-1327),

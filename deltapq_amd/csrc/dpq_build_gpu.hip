@@ -13,8 +13,8 @@
 //     parent, height / finalist bookkeeping, the others become its children (h:534-600)
 //
 // Sorting and scans use hipCUB (rocPRIM); the grouping is hand-written.  The
-// O(n) tail of the build (adjacency, sibling order, DFS numbering) stays on
-// the host (layout_tree).
+// tail of the build (adjacency, sibling order, DFS numbering, masks and changed
+// bytes) follows below (layout_tree_gpu).
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 
@@ -300,6 +300,368 @@ int find_edges_gpu(const uint8_t* codes, int64_t n, int M, int max_height_folds,
     hipFree(d_fslot); hipFree(d_edges); hipFree(d_finalists); hipFree(d_counters); hipFree(d_num); hipFree(d_perm_a);
     hipFree(d_perm_b); hipFree(d_klo_a); hipFree(d_klo_b); hipFree(d_khi_a); hipFree(d_khi_b); hipFree(d_temp);
     return ok ? DPQ_OK : DPQ_ERR_HIP;
+}
+
+
+// ===========================================================================
+// The rest of the build on the GPU (edges_to_tree_index_approx_dfs_layout,
+// h:1334-1487, and dfs_node_layout, h:1156-1183): adjacency, max_dist /
+// max_dist2p, sibling order, DFS numbering, per-node masks and changed bytes.
+// Same result as layout_tree (dpq_build.cpp), array for array.
+//
+//   parents[child] = parent                                   scatter over the edges
+//   adjacency in edge order                                   stable radix sort of the edges by parent (h:1077)
+//   centroid tables (main:101-118)                            one thread per (m, j, k)
+//   max_dist / max_dist2p over <= 16 ancestors (h:1398-1418)  one thread per node, float max as uint atomicMax
+//   siblings by max_dist2p, descending, ties in edge order    two stable sorts: by ~bits(max_dist2p), then by parent
+//   depth                                                     level by level (a DeltaTree is at most M h levels deep)
+//   subtree sizes                                             levels bottom-up, atomicAdd into the parent
+//   DFS position                                              pos(child) = pos(parent) + 1 + sizes of the siblings
+//                                                             before it (a scan over the sibling-ordered list),
+//                                                             levels top-down
+//   masks / changed bytes                                     popcounts in DFS order -> exclusive scan -> scatter
+// ===========================================================================
+namespace {
+
+__global__ void centroid_table_kernel(const float* __restrict__ cw, int M, int K, int Ds, float* __restrict__ tab) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (int64_t)M * K * K) return;
+    const int k = (int)(t % K), j = (int)((t / K) % K), m = (int)(t / ((int64_t)K * K));
+    float dist = 0.0f;  // main:101-118: `float dist += pow(float - float, 2)`
+    for (int d = 0; d < Ds; ++d) {
+        const float df = __fsub_rn(cw[((size_t)m * K + j) * Ds + d], cw[((size_t)m * K + k) * Ds + d]);
+        dist = (float)__dadd_rn((double)dist, __dmul_rn((double)df, (double)df));
+    }
+    tab[t] = dist;
+}
+
+__global__ void set_parents_kernel(const uint32_t* __restrict__ edges, int64_t n_edges, uint32_t* __restrict__ parents,
+                                   uint32_t* __restrict__ e_parent, uint32_t* __restrict__ e_child) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_edges) return;
+    const uint32_t p = edges[2 * i], c = edges[2 * i + 1];
+    parents[c] = p;
+    e_parent[i] = p;
+    e_child[i] = c;
+}
+
+__global__ void ancestor_dist_kernel(const uint8_t* __restrict__ codes, int M, int K, const uint32_t* __restrict__ parents,
+                                     const float* __restrict__ tab, int64_t n, uint32_t* __restrict__ max_dists,
+                                     uint32_t* __restrict__ max_d2p) {
+    const int64_t vid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (vid >= n) return;
+    uint32_t parent = parents[vid], prev = (uint32_t)vid;
+    for (int depth = 0; depth < 16 && parent != 0xffffffffu; ++depth) {  // h:1403
+        float dist = 0.0f;                                               // cal_distance_by_tables, h:186-194: fp32 sum
+        for (int m = 0; m < M; ++m)
+            dist = __fadd_rn(dist, tab[((size_t)m * K + codes[(size_t)vid * M + m]) * K + codes[(size_t)parent * M + m]]);
+        const uint32_t bits = __float_as_uint(dist);  // distances are >= 0: uint order = float order
+        atomicMax(&max_dists[parent], bits);
+        atomicMax(&max_d2p[prev], bits);
+        prev = parent;
+        parent = parents[parent];
+    }
+}
+
+__global__ void sibling_key_kernel(const uint32_t* __restrict__ e_child, const uint32_t* __restrict__ max_d2p, int64_t n_edges,
+                                   uint32_t* __restrict__ key) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_edges) key[i] = ~max_d2p[e_child[i]];  // ascending ~bits = descending distance
+}
+
+__global__ void count_children_kernel(const uint32_t* __restrict__ e_parent, int64_t n_edges, uint32_t* __restrict__ n_children) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_edges) atomicAdd(&n_children[e_parent[i]], 1u);
+}
+
+// depth[v] = level for the children of nodes at level - 1; counts how many were set
+__global__ void depth_level_kernel(const uint32_t* __restrict__ parents, int64_t n, int level, uint8_t* __restrict__ depth,
+                                   uint32_t* __restrict__ n_set) {
+    const int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n) return;
+    const uint32_t p = parents[v];
+    if (p != 0xffffffffu && depth[v] == 0xff && depth[p] == (uint8_t)(level - 1)) {
+        depth[v] = (uint8_t)level;
+        atomicAdd(n_set, 1u);
+    }
+}
+
+__global__ void subtree_level_kernel(const uint32_t* __restrict__ parents, const uint8_t* __restrict__ depth, int64_t n,
+                                     int level, uint32_t* __restrict__ size) {
+    const int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v < n && depth[v] == (uint8_t)level) atomicAdd(&size[parents[v]], size[v]);
+}
+
+__global__ void gather_sizes_kernel(const uint32_t* __restrict__ s_child, const uint32_t* __restrict__ size, int64_t n_edges,
+                                    uint32_t* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_edges) out[i] = size[s_child[i]];
+}
+
+// pos(child) = pos(parent) + 1 + (sizes of the siblings before it) for children at `level`
+__global__ void position_level_kernel(const uint32_t* __restrict__ s_parent, const uint32_t* __restrict__ s_child,
+                                      const uint32_t* __restrict__ size_scan, const uint32_t* __restrict__ offsets,
+                                      const uint8_t* __restrict__ depth, int64_t n_edges, int level,
+                                      uint32_t* __restrict__ pos) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_edges) return;
+    const uint32_t c = s_child[i];
+    if (depth[c] != (uint8_t)level) return;
+    const uint32_t p = s_parent[i];
+    pos[c] = pos[p] + 1 + (size_scan[i] - size_scan[offsets[p]]);
+}
+
+// per node, at its DFS position: original id, parent position, depth, descendants, mask, popcount, sqrt'ed distances
+__global__ void node_records_kernel(const uint8_t* __restrict__ codes, int M, const uint32_t* __restrict__ parents,
+                                    const uint32_t* __restrict__ pos, const uint8_t* __restrict__ depth,
+                                    const uint32_t* __restrict__ size, const uint32_t* __restrict__ max_dists,
+                                    const uint32_t* __restrict__ max_d2p, int64_t n, uint32_t* __restrict__ vec_id,
+                                    uint32_t* __restrict__ parent_pos, uint8_t* __restrict__ depth_out,
+                                    uint32_t* __restrict__ subtree, uint16_t* __restrict__ mask,
+                                    uint32_t* __restrict__ n_changed, float* __restrict__ md, float* __restrict__ md2p) {
+    const int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n) return;
+    const uint32_t q = pos[v], p = parents[v];
+    vec_id[q] = (uint32_t)v;
+    parent_pos[q] = p == 0xffffffffu ? 0xffffffffu : pos[p];
+    depth_out[q] = depth[v];
+    subtree[q] = size[v] - 1;  // h:1182: node_id - parent_node_id
+    unsigned mk = 0;
+    if (p != 0xffffffffu)
+        for (int m = 0; m < M; ++m)
+            if (codes[(size_t)p * M + m] != codes[(size_t)v * M + m]) mk |= 1u << m;
+    mask[q] = (uint16_t)mk;
+    n_changed[q] = (uint32_t)__popc(mk);
+    if (md) {
+        md[q] = sqrtf(__uint_as_float(max_dists[v]));   // h:1455-1456 (sqrtf is correctly rounded)
+        md2p[q] = sqrtf(__uint_as_float(max_d2p[v]));
+    }
+}
+
+__global__ void changed_bytes_kernel(const uint8_t* __restrict__ codes, int M, const uint32_t* __restrict__ vec_id,
+                                     const uint32_t* __restrict__ parent_pos, const uint16_t* __restrict__ mask,
+                                     const uint32_t* __restrict__ at, int64_t n, uint8_t* __restrict__ deltas,
+                                     uint8_t* __restrict__ delta_from) {
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n || q == 0) return;
+    const uint32_t v = vec_id[q], p = vec_id[parent_pos[q]];
+    uint32_t o = at[q];
+    const unsigned mk = mask[q];
+    for (int m = 0; m < M; ++m)
+        if (mk >> m & 1u) {
+            deltas[o] = codes[(size_t)v * M + m];
+            delta_from[o] = codes[(size_t)p * M + m];
+            ++o;
+        }
+}
+
+}  // namespace
+
+int layout_tree_gpu(const uint8_t* codes, int64_t n, int M, int K, int max_height_folds, const float* codewords, int Ds,
+                    const std::vector<uint32_t>& finalists, std::vector<std::pair<uint32_t, uint32_t>>* edges_in, int device,
+                    Tree* out, std::string* err) {
+    if (!codes || n < 1 || n >= (int64_t)INT32_MAX || M < 1 || M > 16 || K < 1 || K > 256 || !out || finalists.empty()) {
+        if (err) *err = "bad argument to layout_tree_gpu";
+        return DPQ_ERR_ARG;
+    }
+    Tree& t = *out;
+    t = Tree();
+    t.M = M;
+    t.K = K;
+    t.max_height_folds = max_height_folds;
+    t.n = n;
+    t.edges.swap(*edges_in);
+    t.root_id = finalists[0];
+    for (size_t i = 1; i < finalists.size(); ++i) t.edges.emplace_back(t.root_id, finalists[i]);  // h:1297-1313
+    if ((int64_t)t.edges.size() != n - 1) {
+        if (err) *err = "internal: edge count != n - 1";
+        return DPQ_ERR_FORMAT;
+    }
+    t.root_code.assign(codes + (size_t)t.root_id * M, codes + (size_t)t.root_id * M + M);
+    const int levels = M > 8 ? 16 : 8;
+    const size_t N = (size_t)n, E = N - 1;
+    const bool with_cb = codewords && Ds > 0;
+    uint8_t *d_codes = nullptr, *d_depth = nullptr, *d_depth_out = nullptr, *d_deltas = nullptr, *d_from = nullptr;
+    uint32_t *d_edges = nullptr, *d_parents = nullptr, *d_ep = nullptr, *d_ec = nullptr, *d_ep2 = nullptr, *d_ec2 = nullptr,
+             *d_key = nullptr, *d_key2 = nullptr, *d_md = nullptr, *d_md2p = nullptr, *d_nch = nullptr, *d_off = nullptr,
+             *d_size = nullptr, *d_sz_e = nullptr, *d_scan = nullptr, *d_pos = nullptr, *d_vec = nullptr, *d_ppos = nullptr,
+             *d_sub = nullptr, *d_cnt = nullptr, *d_at = nullptr, *d_nset = nullptr;
+    uint16_t* d_mask = nullptr;
+    float *d_cw = nullptr, *d_tab = nullptr, *d_fmd = nullptr, *d_fmd2p = nullptr;
+    void* d_temp = nullptr;
+    size_t temp_bytes = 0;
+    int max_depth = 0;
+    bool too_deep = false;
+
+    auto run = [&]() -> bool {
+    GB_HIP(hipSetDevice(device));
+    GB_HIP(hipMalloc(&d_codes, N * M));
+    GB_HIP(hipMemcpy(d_codes, codes, N * M, hipMemcpyHostToDevice));
+    GB_HIP(hipMalloc(&d_parents, N * 4));
+    GB_HIP(hipMemset(d_parents, 0xff, N * 4));
+    GB_HIP(hipMalloc(&d_md, N * 4));
+    GB_HIP(hipMalloc(&d_md2p, N * 4));
+    GB_HIP(hipMemset(d_md, 0, N * 4));
+    GB_HIP(hipMemset(d_md2p, 0, N * 4));
+    GB_HIP(hipMalloc(&d_nch, (N + 1) * 4));
+    GB_HIP(hipMemset(d_nch, 0, (N + 1) * 4));
+    GB_HIP(hipMalloc(&d_off, (N + 1) * 4));
+    GB_HIP(hipMalloc(&d_depth, N));
+    GB_HIP(hipMemset(d_depth, 0xff, N));
+    GB_HIP(hipMalloc(&d_size, N * 4));
+    GB_HIP(hipMalloc(&d_pos, N * 4));
+    GB_HIP(hipMemset(d_pos, 0, N * 4));
+    GB_HIP(hipMalloc(&d_nset, 4));
+    if (E > 0) {
+        GB_HIP(hipMalloc(&d_edges, E * 8));
+        GB_HIP(hipMemcpy(d_edges, t.edges.data(), E * 8, hipMemcpyHostToDevice));
+        GB_HIP(hipMalloc(&d_ep, E * 4));
+        GB_HIP(hipMalloc(&d_ec, E * 4));
+        GB_HIP(hipMalloc(&d_ep2, E * 4));
+        GB_HIP(hipMalloc(&d_ec2, E * 4));
+        GB_HIP(hipMalloc(&d_key, E * 4));
+        GB_HIP(hipMalloc(&d_key2, E * 4));
+        GB_HIP(hipMalloc(&d_sz_e, E * 4));
+        GB_HIP(hipMalloc(&d_scan, E * 4));
+        size_t a = 0, b = 0;
+        hipcub::DeviceRadixSort::SortPairs(nullptr, a, d_key, d_key2, d_ec, d_ec2, (int)E);
+        hipcub::DeviceScan::ExclusiveSum(nullptr, b, d_nch, d_off, (int)(N + 1));
+        temp_bytes = std::max(a, b) + 256;
+        GB_HIP(hipMalloc(&d_temp, temp_bytes));
+        hipLaunchKernelGGL(set_parents_kernel, dim3(blocks_for((int64_t)E)), dim3(256), 0, 0, d_edges, (int64_t)E, d_parents,
+                           d_ep, d_ec);
+        if (with_cb) {
+            const size_t cwn = (size_t)M * K * Ds, tn = (size_t)M * K * K;
+            GB_HIP(hipMalloc(&d_cw, cwn * 4));
+            GB_HIP(hipMemcpy(d_cw, codewords, cwn * 4, hipMemcpyHostToDevice));
+            GB_HIP(hipMalloc(&d_tab, tn * 4));
+            hipLaunchKernelGGL(centroid_table_kernel, dim3(blocks_for((int64_t)tn)), dim3(256), 0, 0, d_cw, M, K, Ds, d_tab);
+            hipLaunchKernelGGL(ancestor_dist_kernel, dim3(blocks_for(n)), dim3(256), 0, 0, d_codes, M, K, d_parents, d_tab, n,
+                               d_md, d_md2p);
+            // siblings by max_dist2p descending, ties in edge order: stable sort by ~bits, then (below) by parent
+            hipLaunchKernelGGL(sibling_key_kernel, dim3(blocks_for((int64_t)E)), dim3(256), 0, 0, d_ec, d_md2p, (int64_t)E,
+                               d_key);
+            size_t tb = temp_bytes;
+            GB_HIP(hipcub::DeviceRadixSort::SortPairs(d_temp, tb, d_key, d_key2, d_ec, d_ec2, (int)E));
+            tb = temp_bytes;
+            GB_HIP(hipcub::DeviceRadixSort::SortPairs(d_temp, tb, d_key, d_key2, d_ep, d_ep2, (int)E));
+            std::swap(d_ec, d_ec2);
+            std::swap(d_ep, d_ep2);
+        }
+        // stable sort by parent: the adjacency lists (h:1077), each in sibling order
+        size_t tb = temp_bytes;
+        GB_HIP(hipcub::DeviceRadixSort::SortPairs(d_temp, tb, d_ep, d_key2, d_ec, d_ec2, (int)E));
+        std::swap(d_ec, d_ec2);   // d_ec: children, grouped by parent
+        std::swap(d_ep, d_key2);  // d_ep: their parents (sorted)
+        hipLaunchKernelGGL(count_children_kernel, dim3(blocks_for((int64_t)E)), dim3(256), 0, 0, d_ep, (int64_t)E, d_nch);
+        tb = temp_bytes;
+        GB_HIP(hipcub::DeviceScan::ExclusiveSum(d_temp, tb, d_nch, d_off, (int)(N + 1)));
+    }
+    // depth, level by level from the root
+    {
+        const uint8_t zero = 0;
+        GB_HIP(hipMemcpy(d_depth + t.root_id, &zero, 1, hipMemcpyHostToDevice));
+        for (int level = 1; level <= 64; ++level) {
+            GB_HIP(hipMemset(d_nset, 0, 4));
+            hipLaunchKernelGGL(depth_level_kernel, dim3(blocks_for(n)), dim3(256), 0, 0, d_parents, n, level, d_depth, d_nset);
+            uint32_t n_set = 0;
+            GB_HIP(hipMemcpy(&n_set, d_nset, 4, hipMemcpyDeviceToHost));
+            if (n_set == 0) break;
+            max_depth = level;
+            if (level >= levels) {
+                too_deep = true;
+                return true;
+            }
+        }
+    }
+    // subtree sizes bottom-up, DFS positions top-down
+    {
+        std::vector<uint32_t> ones(N, 1u);
+        GB_HIP(hipMemcpy(d_size, ones.data(), N * 4, hipMemcpyHostToDevice));
+    }
+    for (int level = max_depth; level >= 1; --level)
+        hipLaunchKernelGGL(subtree_level_kernel, dim3(blocks_for(n)), dim3(256), 0, 0, d_parents, d_depth, n, level, d_size);
+    if (E > 0) {
+        hipLaunchKernelGGL(gather_sizes_kernel, dim3(blocks_for((int64_t)E)), dim3(256), 0, 0, d_ec, d_size, (int64_t)E, d_sz_e);
+        size_t tb = temp_bytes;
+        GB_HIP(hipcub::DeviceScan::ExclusiveSum(d_temp, tb, d_sz_e, d_scan, (int)E));
+        for (int level = 1; level <= max_depth; ++level)
+            hipLaunchKernelGGL(position_level_kernel, dim3(blocks_for((int64_t)E)), dim3(256), 0, 0, d_ep, d_ec, d_scan, d_off,
+                               d_depth, (int64_t)E, level, d_pos);
+    }
+    // node records in DFS order, then the changed bytes
+    GB_HIP(hipMalloc(&d_vec, N * 4));
+    GB_HIP(hipMalloc(&d_ppos, N * 4));
+    GB_HIP(hipMalloc(&d_depth_out, N));
+    GB_HIP(hipMalloc(&d_sub, N * 4));
+    GB_HIP(hipMalloc(&d_mask, N * 2));
+    GB_HIP(hipMalloc(&d_cnt, (N + 1) * 4));
+    GB_HIP(hipMemset(d_cnt, 0, (N + 1) * 4));
+    GB_HIP(hipMalloc(&d_at, (N + 1) * 4));
+    if (with_cb) {
+        GB_HIP(hipMalloc(&d_fmd, N * 4));
+        GB_HIP(hipMalloc(&d_fmd2p, N * 4));
+    }
+    hipLaunchKernelGGL(node_records_kernel, dim3(blocks_for(n)), dim3(256), 0, 0, d_codes, M, d_parents, d_pos, d_depth, d_size,
+                       d_md, d_md2p, n, d_vec, d_ppos, d_depth_out, d_sub, d_mask, d_cnt, d_fmd, d_fmd2p);
+    {
+        size_t b = 0;
+        hipcub::DeviceScan::ExclusiveSum(nullptr, b, d_cnt, d_at, (int)(N + 1));
+        if (b + 256 > temp_bytes) {
+            hipFree(d_temp);
+            d_temp = nullptr;
+            temp_bytes = b + 256;
+            GB_HIP(hipMalloc(&d_temp, temp_bytes));
+        }
+        size_t tb = temp_bytes;
+        GB_HIP(hipcub::DeviceScan::ExclusiveSum(d_temp, tb, d_cnt, d_at, (int)(N + 1)));
+    }
+    uint32_t n_diffs = 0;
+    GB_HIP(hipMemcpy(&n_diffs, d_at + N, 4, hipMemcpyDeviceToHost));
+    GB_HIP(hipMalloc(&d_deltas, (size_t)n_diffs + 16));
+    GB_HIP(hipMalloc(&d_from, (size_t)n_diffs + 16));
+    hipLaunchKernelGGL(changed_bytes_kernel, dim3(blocks_for(n)), dim3(256), 0, 0, d_codes, M, d_vec, d_ppos, d_mask, d_at, n,
+                       d_deltas, d_from);
+    GB_HIP(hipDeviceSynchronize());
+    t.vec_id.resize(N);
+    t.parent_pos.resize(N);
+    t.subtree.resize(N);
+    t.depth.resize(N);
+    t.mask.resize(N);
+    t.deltas.resize(n_diffs);
+    t.delta_from.resize(n_diffs);
+    GB_HIP(hipMemcpy(t.vec_id.data(), d_vec, N * 4, hipMemcpyDeviceToHost));
+    GB_HIP(hipMemcpy(t.parent_pos.data(), d_ppos, N * 4, hipMemcpyDeviceToHost));
+    GB_HIP(hipMemcpy(t.subtree.data(), d_sub, N * 4, hipMemcpyDeviceToHost));
+    GB_HIP(hipMemcpy(t.depth.data(), d_depth_out, N, hipMemcpyDeviceToHost));
+    GB_HIP(hipMemcpy(t.mask.data(), d_mask, N * 2, hipMemcpyDeviceToHost));
+    if (n_diffs) {
+        GB_HIP(hipMemcpy(t.deltas.data(), d_deltas, n_diffs, hipMemcpyDeviceToHost));
+        GB_HIP(hipMemcpy(t.delta_from.data(), d_from, n_diffs, hipMemcpyDeviceToHost));
+    }
+    if (with_cb) {
+        t.max_dist.resize(N);
+        t.max_dist2p.resize(N);
+        GB_HIP(hipMemcpy(t.max_dist.data(), d_fmd, N * 4, hipMemcpyDeviceToHost));
+        GB_HIP(hipMemcpy(t.max_dist2p.data(), d_fmd2p, N * 4, hipMemcpyDeviceToHost));
+    }
+    t.n_diffs = n_diffs;
+    return true;
+    };
+    const bool ok = run();
+    hipFree(d_codes); hipFree(d_depth); hipFree(d_depth_out); hipFree(d_deltas); hipFree(d_from); hipFree(d_edges);
+    hipFree(d_parents); hipFree(d_ep); hipFree(d_ec); hipFree(d_ep2); hipFree(d_ec2); hipFree(d_key); hipFree(d_key2);
+    hipFree(d_md); hipFree(d_md2p); hipFree(d_nch); hipFree(d_off); hipFree(d_size); hipFree(d_sz_e); hipFree(d_scan);
+    hipFree(d_pos); hipFree(d_vec); hipFree(d_ppos); hipFree(d_sub); hipFree(d_cnt); hipFree(d_at); hipFree(d_nset);
+    hipFree(d_mask); hipFree(d_cw); hipFree(d_tab); hipFree(d_fmd); hipFree(d_fmd2p); hipFree(d_temp);
+    if (!ok) return DPQ_ERR_HIP;
+    if (too_deep) {
+        if (err) *err = "tree is deeper than the DTC depth field allows (lower -h)";
+        return DPQ_ERR_FORMAT;
+    }
+    t.max_depth = max_depth;
+    for (size_t p = 0; p < N; ++p) t.depth_hist[t.depth[p]]++;
+    return DPQ_OK;
 }
 
 }  // namespace dpq

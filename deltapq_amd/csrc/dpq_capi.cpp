@@ -992,7 +992,11 @@ int dpq_tree_build_gpu(const uint8_t* codes, int64_t n_codes, int M, int K, int 
     int rc = dpq::find_edges_gpu(codes, n_codes, M, max_height_folds, device, &finalists, &edges, &err);
     if (rc) return fail(rc, err);
     dpq_tree* t = new dpq_tree();
-    rc = dpq::layout_tree(codes, n_codes, M, K, max_height_folds, codewords, Ds, finalists, &edges, &t->tree, &err);
+    // DPQ_BUILD_LAYOUT=host keeps the layout on the host (A/B for the tests; same tree either way)
+    static const bool host_layout = getenv("DPQ_BUILD_LAYOUT") && std::string(getenv("DPQ_BUILD_LAYOUT")) == "host";
+    rc = host_layout ? dpq::layout_tree(codes, n_codes, M, K, max_height_folds, codewords, Ds, finalists, &edges, &t->tree, &err)
+                     : dpq::layout_tree_gpu(codes, n_codes, M, K, max_height_folds, codewords, Ds, finalists, &edges, device,
+                                            &t->tree, &err);
     if (rc) {
         delete t;
         return fail(rc, err);

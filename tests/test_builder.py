@@ -186,6 +186,29 @@ def test_gpu_builder_matches_the_oracle_restatement(lib, n, M):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n", [1, 2, 5, 30000])
+def test_gpu_layout_writes_the_same_artefact_files(lib, tmp_path, n):
+    """The tree laid out on the GPU (adjacency, max_dist2p sibling order, DFS numbering, masks, changed bytes,
+    sub-tree sizes, sqrt'ed max distances) against the host layout: the three artefact files byte for byte
+    (the 60-byte QNode records carry every field of the layout)."""
+    import filecmp
+    from deltapq_amd import api, synth
+    codes = clustered_codes(n, 8, seed=n + 5)
+    cb = synth.make_codebook(8, 256, 16, seed=n)
+    dh, dd = tmp_path / "host", tmp_path / "dev"
+    dh.mkdir()
+    dd.mkdir()
+    host, dev = api.DeltaTree(codes, codebook=cb), api.DeltaTree(codes, codebook=cb, device=0)
+    host.write_files(str(dh))
+    dev.write_files(str(dd))
+    names = sorted(os.listdir(str(dh)))
+    assert len(names) == 3 and names == sorted(os.listdir(str(dd)))
+    for f in names:
+        assert filecmp.cmp(str(dh / f), str(dd / f), shallow=False), f
+    assert host.stats == dev.stats and np.array_equal(host.parent_pos, dev.parent_pos)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("n,M", [(1, 8), (2, 8), (777, 8), (50000, 8), (20000, 16)])
 def test_gpu_edge_search_builds_the_identical_tree(lib, n, M):
     """SURVEY.md 8f row 1 on the GPU: the sort/group passes over every position subset run on the device
