@@ -225,7 +225,7 @@ int ensure_plan(dpq_index* x, int top_k, int cap, int coarse) {
         // The bootstrap kernel delivers the first threshold (no segments consumed: level 0 is empty), as tight
         // as the k-th of a spread sample of a quarter of a 1 M-node index; the filter levels then cover ALL
         // segments.  One level up to 2 M nodes; beyond, levels growing by 8 (a larger shard's first threshold
-        // admits more nodes in absolute terms).  DPQ_PLAN_RATIOS=a[,b[,c]] forces extra levels for experiments.
+        // admits more nodes in absolute terms); top_k > 512: see below.  DPQ_PLAN_RATIOS=a[,b[,c]] forces levels.
         bounds.push_back(nseg);
         std::vector<int> ratios;
         int forced[3] = {0, 0, 0};
@@ -235,6 +235,11 @@ int ensure_plan(dpq_index* x, int top_k, int cap, int coarse) {
                 if (f >= 2) ratios.push_back(f);
         } else {
             for (int64_t b = nseg; b * S > ((int64_t)2 << 20); b /= 8) ratios.push_back(8);
+            // A large top_k takes its first threshold from a worse quantile of the bootstrap sample (the 1000th of
+            // 8 K nodes): two short levels in front tighten it before the bulk of the index is filtered.  Measured
+            // on 1 M codes (scripts/gpu_sweep_plans.sh): top-1000 1.40 M q/s with 3,3 against 0.95 M with one level
+            // (M = 16: 0.79 M against 0.40 M); top-300 and below are fastest with one level.
+            if (top_k > 512 && ratios.size() < 2) ratios = {3, 3};
         }
         int64_t b = nseg;
         for (int r : ratios) {
