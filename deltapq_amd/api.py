@@ -88,7 +88,7 @@ class HostSoA:
         info = Info()
         check(lib.dpq_soa_info(h, info), "dpq_soa_info")
         self.info = info.as_dict()
-        names = ["nib", "mask", "delta", "seg_delta_off", "seg_ckpt", "mi_cell_start", "mi_code", "mi_id"]
+        names = ["nib", "mask", "delta", "seg_delta_off", "seg_ckpt", "mi_cell_start", "mi_code", "mi_id", "par", "carry"]
         for which, name in enumerate(names):
             ptr, nb = ctypes.c_void_p(), _lib.c_i64()
             check(lib.dpq_soa_array(h, which, ptr, nb), "dpq_soa_array")

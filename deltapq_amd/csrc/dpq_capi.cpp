@@ -90,7 +90,8 @@ struct dpq_index {
     dpq_info info{};
     dpq::DeviceImage img;
     // owned device memory of the image
-    uint8_t *d_nib = nullptr, *d_mask = nullptr, *d_delta = nullptr, *d_ckpt = nullptr, *d_raw = nullptr;
+    uint8_t *d_nib = nullptr, *d_par = nullptr, *d_carry = nullptr, *d_mask = nullptr, *d_delta = nullptr, *d_ckpt = nullptr,
+            *d_raw = nullptr;
     bool plain = false;  // uncompressed comparator index (fp32-accumulate rule, no id quirk)
     uint64_t* d_seg_off = nullptr;
     // threshold bootstrap: inverted multi-index over the shard's nodes (dpq::SoA::mi_*); boot = it is in use
@@ -655,6 +656,8 @@ int open_from_payload(const uint8_t* payload, int64_t n_bytes, int64_t n_codes, 
         return DPQ_OK;
     };
     rc = up(&x->d_nib, soa.nib.data(), soa.nib.size());
+    if (!rc) rc = up(&x->d_par, soa.par.data(), soa.par.size());
+    if (!rc) rc = up(&x->d_carry, soa.carry.data(), soa.carry.size());
     if (!rc) rc = up(&x->d_mask, soa.mask.data(), soa.mask.size());
     if (!rc) rc = up(&x->d_delta, soa.delta.data(), soa.delta.size());
     if (!rc) rc = up(&x->d_seg_off, soa.seg_delta_off.data(), soa.seg_delta_off.size() * 8);
@@ -672,6 +675,8 @@ int open_from_payload(const uint8_t* payload, int64_t n_bytes, int64_t n_codes, 
         return rc;
     }
     x->img.nib = x->d_nib;
+    x->img.par = x->d_par;
+    x->img.carry = x->d_carry;
     x->img.mask = x->d_mask;
     x->img.delta = x->d_delta;
     x->img.seg_delta_off = x->d_seg_off;
@@ -949,7 +954,9 @@ int dpq_soa_array(const dpq_soa* soa, int which, const void** ptr, int64_t* n_by
         case 5: *ptr = s.mi_cell_start.data(); *n_bytes = (int64_t)s.mi_cell_start.size() * 4; break;
         case 6: *ptr = s.mi_code.data(); *n_bytes = (int64_t)s.mi_code.size() * 4; break;
         case 7: *ptr = s.mi_id.data(); *n_bytes = (int64_t)s.mi_id.size() * 4; break;
-        default: return fail(DPQ_ERR_ARG, "which must be 0..7");
+        case 8: *ptr = s.par.data(); *n_bytes = (int64_t)s.par.size(); break;
+        case 9: *ptr = s.carry.data(); *n_bytes = (int64_t)s.carry.size(); break;
+        default: return fail(DPQ_ERR_ARG, "which must be 0..9");
     }
     return DPQ_OK;
     });
@@ -1218,6 +1225,8 @@ int dpq_close(dpq_index* x) {
     for (auto e : x->ev_pool) hipEventDestroy(e);
     free_workspace(x);
     hipFree(x->d_nib);
+    hipFree(x->d_par);
+    hipFree(x->d_carry);
     hipFree(x->d_mask);
     hipFree(x->d_delta);
     hipFree(x->d_ckpt);

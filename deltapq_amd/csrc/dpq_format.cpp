@@ -218,13 +218,16 @@ int transcode(const uint8_t* payload, int64_t n_bytes, int64_t n_codes, int M, i
     o.node_hi = std::min(seg_hi * S, n_scan);
     o.n_segments = seg_hi - seg_lo;
     const int64_t n_pad = o.n_segments * S;
-    o.nib.assign((size_t)(n_pad / 2), 0x11);  // padding nodes: depth 1, no change
+    o.nib.assign((size_t)(n_pad / 2), 0x00);  // padding nodes: children of stack[0] with no change
+    o.par.assign((size_t)n_pad, 0xFF);
+    o.carry.assign((size_t)(n_pad / kChunk) * levels, 0xFF);
     o.mask.assign((size_t)(n_pad * mb), 0);
     o.seg_delta_off.assign((size_t)o.n_segments + 1, 0);
     o.seg_ckpt.assign((size_t)(o.n_segments * levels * M), 0);
     o.delta.reserve((size_t)std::min<int64_t>(n_bytes, (o.node_hi - o.node_lo) * (int64_t)M / 2 + 64));
 
     std::vector<uint8_t> stack((size_t)levels * M, 0);  // vecs_stack (h:2858-2862)
+    int last_lane[16], top_level[64];                   // per chunk: last lane of every depth; per lane: its chain's stack level
     std::vector<uint32_t> mi_ids;   // bootstrap sample: global position and decoded code of every stride-th node
     std::vector<uint8_t> mi_codes;
     if (multi_index_stride > 0) {
@@ -254,11 +257,21 @@ int transcode(const uint8_t* payload, int64_t n_bytes, int64_t n_codes, int M, i
             if (r.mask & (1u << m)) cur[m] = r.deltas[j++];
         if (i >= o.node_lo && i < o.node_hi) {
             const int64_t l = i - o.node_lo;
+            const int lane = (int)(l % kChunk);
+            if (lane == 0)
+                for (int d = 0; d < 16; ++d) last_lane[d] = -1;
+            // parent = the latest node of depth - 1 (h:2888); inside the chunk it is a lane, before it a stack level
+            const int pl = r.depth > 0 ? last_lane[r.depth - 1] : -1;
+            const int level = pl >= 0 ? top_level[pl] : (r.depth > 0 ? r.depth - 1 : 0);
+            top_level[lane] = level;
+            last_lane[r.depth] = lane;
+            o.par[(size_t)l] = pl >= 0 ? (uint8_t)pl : 0xFF;
+            o.carry[(size_t)(l / kChunk) * levels + r.depth] = (uint8_t)lane;
             uint8_t& nb = o.nib[(size_t)(l >> 1)];
             if (l & 1)
-                nb = (uint8_t)((nb & 0x0F) | (r.depth << 4));
+                nb = (uint8_t)((nb & 0x0F) | (level << 4));
             else
-                nb = (uint8_t)((nb & 0xF0) | r.depth);
+                nb = (uint8_t)((nb & 0xF0) | level);
             o.mask[(size_t)(l * mb)] = (uint8_t)(r.mask & 0xFF);
             if (mb == 2) o.mask[(size_t)(l * mb + 1)] = (uint8_t)(r.mask >> 8);
             o.delta.insert(o.delta.end(), r.deltas, r.deltas + r.n_diff);

@@ -64,7 +64,13 @@ struct SoA {
     int64_t algorithmic_bytes = 0;
     int64_t n_diffs = 0;
     int max_depth = 0;
-    std::vector<uint8_t> nib;             // 4-bit depth per local node, node 2j in the low nibble of byte j
+    // The tree topology of a chunk is resolved once, here, instead of by every wavefront that decodes it:
+    std::vector<uint8_t> nib;             // 4 bits per local node (node 2j in the low nibble of byte j): the stack level the
+                                          // node's in-chunk ancestor chain hangs from = depth(topmost in-chunk ancestor) - 1
+    std::vector<uint8_t> par;             // per local node: lane (0..63) of its parent inside its 64-node chunk, 0xFF = the
+                                          // parent precedes the chunk (it is stack[nib])
+    std::vector<uint8_t> carry;           // [chunks][levels]: lane of the chunk's last node of depth D, 0xFF = none (the
+                                          // stack entries a chunk hands to the next one of its segment)
     std::vector<uint8_t> mask;            // mask_bytes per local node (little endian)
     std::vector<uint8_t> delta;           // changed bytes, node order, ascending position; 16 bytes of tail padding
     std::vector<uint64_t> seg_delta_off;  // [n_segments + 1]
@@ -80,7 +86,8 @@ struct SoA {
     std::vector<uint32_t> mi_id;          // [entries] global DFS position
     int64_t nodes_per_segment() const { return (int64_t)kChunk * chunks_per_segment; }
     int64_t device_bytes() const {
-        return (int64_t)(nib.size() + mask.size() + delta.size() + seg_delta_off.size() * 8 + seg_ckpt.size());
+        return (int64_t)(nib.size() + par.size() + carry.size() + mask.size() + delta.size() + seg_delta_off.size() * 8 +
+                         seg_ckpt.size());
     }
     int64_t bootstrap_bytes() const { return (int64_t)((mi_cell_start.size() + mi_code.size() + mi_id.size()) * 4); }
 };

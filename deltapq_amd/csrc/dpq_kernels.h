@@ -19,7 +19,9 @@ inline int queries_per_group(int M) { return M <= 8 ? 64 : 16; }
 
 // The SoA image of one shard in HBM (see DESIGN.md "Data layout").
 struct DeviceImage {
-    const uint8_t* nib = nullptr;             // 4-bit depths
+    const uint8_t* nib = nullptr;             // 4 bits per node: stack level its in-chunk ancestor chain hangs from
+    const uint8_t* par = nullptr;             // per node: lane of its parent in the chunk, 0xFF = precedes the chunk
+    const uint8_t* carry = nullptr;           // [chunks][levels]: lane of the chunk's last node of each depth, 0xFF = none
     const uint8_t* mask = nullptr;            // 1 or 2 bytes per node
     const uint8_t* delta = nullptr;           // changed bytes
     const uint64_t* seg_delta_off = nullptr;  // [n_segments + 1]

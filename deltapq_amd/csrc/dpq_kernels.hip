@@ -234,10 +234,10 @@ struct WaveDecoder {
     //   load_delta wave scan of popcount(mask) -> the node's changed bytes (3 aligned dwords) + permute selectors
     //   finish    scatter to positions, pointer jumping over the in-chunk ancestor chain, apply to the stack
     struct In {
-        uint32_t nb, mk;
+        uint32_t nb, mk, par;
     };
     struct Ld {
-        uint32_t d, mk;
+        uint32_t level, mk, par;
         uint32_t w[W / 2][3], sh[W / 2];
         uint2 t[W / 2];
     };
@@ -245,13 +245,15 @@ struct WaveDecoder {
         In r;
         r.nb = img.nib[node >> 1];
         r.mk = M <= 8 ? (uint32_t)img.mask[node] : (uint32_t)reinterpret_cast<const uint16_t*>(img.mask)[node];
+        r.par = img.par[node];
         return r;
     }
     // `at`: running offset of the chunk's first changed byte (advanced past the chunk)
     __device__ __forceinline__ static Ld load_delta(const DeviceImage& img, const In& in, int64_t node, uint64_t& at) {
         Ld r;
-        r.d = (node & 1) ? (in.nb >> 4) : (in.nb & 15u);
+        r.level = (node & 1) ? (in.nb >> 4) : (in.nb & 15u);
         r.mk = in.mk;
+        r.par = in.par;
         const uint32_t pc = __popc(in.mk);
         // wave exclusive scan of pc by bit planes: v_mbcnt, no LDS traffic
         uint32_t excl = 0, total = 0;
@@ -280,15 +282,16 @@ struct WaveDecoder {
 
     // Decode node `node` (= this lane's node of the chunk) in one go.  `carry`: update the
     // stack for the next chunk of the segment.
-    __device__ __forceinline__ void step(const DeviceImage& img, int64_t node, int lane, uint64_t lt_mask, bool carry,
-                                         uint32_t (&code)[W]) {
+    __device__ __forceinline__ void step(const DeviceImage& img, int64_t node, int lane, bool carry, uint32_t (&code)[W]) {
         const In in = load_in(img, node);
         const Ld ld = load_delta(img, in, node, doff);
-        finish(ld, lane, lt_mask, carry, code);
+        uint32_t cl = 0xffu;
+        if (carry && lane < LEVELS) cl = img.carry[(size_t)(node >> 6) * LEVELS + lane];
+        finish(ld, lane, cl, code);
     }
 
-    __device__ __forceinline__ void finish(const Ld& ld, int lane, uint64_t lt_mask, bool carry, uint32_t (&code)[W]) {
-        const uint32_t d = ld.d;
+    // carry_lane (lanes 0..LEVELS-1): lane of the chunk's last node of depth `lane`, 0xFF = none / no carry wanted
+    __device__ __forceinline__ void finish(const Ld& ld, int lane, uint32_t carry_lane, uint32_t (&code)[W]) {
         uint32_t mk = ld.mk;
         uint32_t pv[W];
 #pragma unroll
@@ -298,51 +301,38 @@ struct WaveDecoder {
             pv[2 * h] = __builtin_amdgcn_perm(raw_hi, raw_lo, ld.t[h].x);
             pv[2 * h + 1] = __builtin_amdgcn_perm(raw_hi, raw_lo, ld.t[h].y);
         }
-        // parent = nearest preceding node with depth-1 (h:2888: stack[depth-1])
-        uint64_t B[LEVELS];
-#pragma unroll
-        for (int D = 0; D < LEVELS; ++D) B[D] = __ballot(d == (uint32_t)D);
-        uint64_t selB = 0;
-#pragma unroll
-        for (int D = 1; D < LEVELS; ++D) selB = (d == (uint32_t)D) ? B[D - 1] : selB;
-        const uint64_t prev = selB & lt_mask;
-        int P = prev ? 63 - __clzll((long long)prev) : -1;  // -1: the parent precedes the chunk
-        uint32_t td = d;                                     // depth of the top of my resolved chain
+        // parent = nearest preceding node with depth - 1 (h:2888: stack[depth-1]); which lane that is was
+        // resolved when the image was built (DeviceImage::par), as was the stack level the chain ends on
+        uint32_t P = ld.par;  // 0xFF: the parent precedes the chunk
         // Pointer jumping: compose patches along the in-chunk ancestor chain.  A patch travels as its
-        // W value dwords plus ONE dword (position mask | parent lane | top depth): the byte selectors that
-        // merge two patches are rebuilt from the position mask (VALU) instead of being carried through
-        // the LDS crossbar -- the scan is bound by LDS cycles.
+        // W value dwords plus ONE dword (position mask | parent lane): the byte selectors that merge two
+        // patches are rebuilt from the position mask (VALU) instead of being carried through the LDS
+        // crossbar -- the scan is bound by LDS cycles.
 #pragma unroll
         for (int s = 0; s < Cfg<M>::JUMPS; ++s) {
-            if (__ballot(P >= 0) == 0) break;  // every chain is resolved (wave-uniform)
-            const int src = P < 0 ? lane : P;
+            if (__ballot(P != 0xffu) == 0) break;  // every chain is resolved (wave-uniform)
+            const int src = P == 0xffu ? lane : (int)P;
             uint32_t q_pv[W];
 #pragma unroll
             for (int w = 0; w < W; ++w) q_pv[w] = bperm(src, pv[w]);
-            const uint32_t q_meta = bperm(src, mk | ((uint32_t)(P & 0xff) << 16) | (td << 24));
-            if (P >= 0) {
+            const uint32_t q_meta = bperm(src, mk | (P << 16));
+            if (P != 0xffu) {
 #pragma unroll
                 for (int w = 0; w < W; ++w) pv[w] = __builtin_amdgcn_perm(q_pv[w], pv[w], own_sel((mk >> (4 * w)) & 15u));
                 mk |= q_meta & 0xffffu;
-                const uint32_t pp = (q_meta >> 16) & 0xffu;
-                P = pp == 0xffu ? -1 : (int)pp;
-                td = q_meta >> 24;
+                P = q_meta >> 16;
             }
         }
         // apply to the ancestor that precedes the chunk
-        const int e = td > 0 ? (int)td - 1 : 0;
 #pragma unroll
-        for (int w = 0; w < W; ++w) code[w] = __builtin_amdgcn_perm(bperm(e, stk[w]), pv[w], own_sel((mk >> (4 * w)) & 15u));
+        for (int w = 0; w < W; ++w)
+            code[w] = __builtin_amdgcn_perm(bperm((int)ld.level, stk[w]), pv[w], own_sel((mk >> (4 * w)) & 15u));
         // carry the stack: stack[D] = code of the last node with depth D
-        if (carry) {
-            int srcl = -1;
-#pragma unroll
-            for (int D = 0; D < LEVELS; ++D)
-                if (B[D]) srcl = lane == D ? 63 - __clzll((long long)B[D]) : srcl;
+        if (__ballot(carry_lane != 0xffu)) {
 #pragma unroll
             for (int w = 0; w < W; ++w) {
-                const uint32_t nv = bperm(srcl < 0 ? lane : srcl, code[w]);
-                if (srcl >= 0) stk[w] = nv;
+                const uint32_t nv = bperm(carry_lane == 0xffu ? lane : (int)carry_lane, code[w]);
+                if (carry_lane != 0xffu) stk[w] = nv;
             }
         }
     }
@@ -357,7 +347,6 @@ __global__ __launch_bounds__(64) void decode_segments_kernel(const DeviceImage i
     constexpr int W = Cfg<M>::W;
     const int lane = threadIdx.x;
     const uint32_t seg = seg_list ? seg_list[blockIdx.x] : blockIdx.x;
-    const uint64_t lt_mask = (1ull << lane) - 1ull;
     const int cps = img.chunks_per_segment;
     WaveDecoder<M> dec;
     if (!img.raw) dec.begin_segment(img, seg, lane);
@@ -368,7 +357,7 @@ __global__ __launch_bounds__(64) void decode_segments_kernel(const DeviceImage i
 #pragma unroll
             for (int w = 0; w < W; ++w) code[w] = reinterpret_cast<const uint32_t*>(img.raw)[(size_t)node * W + w];
         } else {
-            dec.step(img, node, lane, lt_mask, c + 1 < cps, code);
+            dec.step(img, node, lane, c + 1 < cps, code);
         }
         const size_t o = ((size_t)blockIdx.x * cps + c) * 64 + lane;
         out_id[o] = node < img.n_local ? img.id_base + (uint32_t)node : 0xffffffffu;
@@ -600,7 +589,6 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanArgs a) {
     __syncthreads();
     stamp(kStPrologue);
 
-    const uint64_t lt_mask = (1ull << lane) - 1ull;
     const int cps = a.img.chunks_per_segment;
     WaveDecoder<M> dec;
     // bits of a survivor-mask dword that stand for a slot of this configuration
@@ -686,6 +674,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanArgs a) {
     struct Chunk {
         int seg, c;                       // wave-uniform; seg < 0: no chunk
         typename WaveDecoder<M>::In in;   // stage 1
+        uint32_t carry_lane;              // stage 1 (lanes 0..LEVELS-1): the chunk's last node of depth `lane`, 0xFF = none
         uint64_t h_doff;                  // stage 1, first chunk of a segment: offset of its first changed byte,
         uint32_t h_stk[W];                //          and the ancestor stack at its first node (lanes 0..LEVELS-1)
         typename WaveDecoder<M>::Ld ld;   // stage 2
@@ -700,6 +689,8 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanArgs a) {
             for (int w = 0; w < W; ++w) k.raw[w] = reinterpret_cast<const uint32_t*>(a.img.raw)[(size_t)node * W + w];
         } else {
             k.in = WaveDecoder<M>::load_in(a.img, node);
+            k.carry_lane = 0xffu;
+            if (k.c + 1 < cps && lane < C::LEVELS) k.carry_lane = a.img.carry[(size_t)(node >> 6) * C::LEVELS + lane];
             if (k.c == 0) {
                 k.h_doff = a.img.seg_delta_off[k.seg];
 #pragma unroll
@@ -751,7 +742,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanArgs a) {
 #pragma unroll
                     for (int w = 0; w < W; ++w) dec.stk[w] = A.h_stk[w];
                 }
-                dec.finish(A.ld, lane, lt_mask, A.c + 1 < cps, code);
+                dec.finish(A.ld, lane, A.carry_lane, code);
             }
             if constexpr (STAMPS) {
                 st[kStSteps] += 1;

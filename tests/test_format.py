@@ -10,32 +10,49 @@ from conftest import make_case
 
 
 def decode_soa(soa, M=8):
-    """Decode a HostSoA image sequentially per segment: stack = checkpoint, then
-    code(i) = stack[depth-1] patched with the node's changed bytes -- the
-    semantics the scan kernel implements with pointer jumping."""
+    """Decode a HostSoA image the way the scan kernel is specified to: per segment the ancestor stack starts from the
+    checkpoint; inside a 64-node chunk a node's code is its parent's (lane `par` of the chunk, or stack[`nib`] when
+    the parent precedes the chunk -- for a chain of in-chunk ancestors `nib` names the stack level the CHAIN hangs
+    from) patched with the node's changed bytes; after a chunk stack[D] = code of lane carry[chunk][D]."""
     info = soa.info
-    S = 64 * info["chunks_per_segment"]
+    cps = info["chunks_per_segment"]
     n = info["node_hi"] - info["node_lo"]
     levels = 8 if M <= 8 else 16
     out = np.zeros((n, M), np.uint8)
     ck = soa.seg_ckpt.reshape(-1, levels, M)
+    carry = soa.carry.reshape(-1, levels)
     for t in range(info["n_segments"]):
         stack = ck[t].copy()
         off = int(soa.seg_delta_off[t])
-        for j in range(S):
-            l = t * S + j
-            if l >= n:
-                break
-            nb = soa.nib[l >> 1]
-            d = (nb >> 4) if (l & 1) else (nb & 15)
-            mk = int(soa.mask[l]) if M <= 8 else int(soa.mask[2 * l]) | (int(soa.mask[2 * l + 1]) << 8)
-            c = stack[d - 1].copy() if d > 0 else np.zeros(M, np.uint8)
-            for m in range(M):
-                if (mk >> m) & 1:
-                    c[m] = soa.delta[off]
-                    off += 1
-            stack[d] = c
-            out[l] = c
+        for c in range(cps):
+            chunk = t * cps + c
+            codes = np.zeros((64, M), np.uint8)
+            for lane in range(64):
+                l = chunk * 64 + lane
+                if l >= n:
+                    break
+                nb = soa.nib[l >> 1]
+                level = (nb >> 4) if (l & 1) else (nb & 15)
+                mk = int(soa.mask[l]) if M <= 8 else int(soa.mask[2 * l]) | (int(soa.mask[2 * l + 1]) << 8)
+                p = int(soa.par[l])
+                if p == 0xFF:
+                    code = stack[level].copy()
+                else:
+                    assert p < lane
+                    code = codes[p].copy()
+                    # the chain of in-chunk ancestors ends on the same stack level for every node of the chain
+                    pl = chunk * 64 + p
+                    pnb = soa.nib[pl >> 1]
+                    assert ((pnb >> 4) if (pl & 1) else (pnb & 15)) == level
+                for m in range(M):
+                    if (mk >> m) & 1:
+                        code[m] = soa.delta[off]
+                        off += 1
+                codes[lane] = code
+                out[l] = code
+            for d in range(levels):
+                if carry[chunk, d] != 0xFF:
+                    stack[d] = codes[carry[chunk, d]]
         assert off == int(soa.seg_delta_off[t + 1])
     return out
 
@@ -53,7 +70,8 @@ def test_transcode_is_lossless(lib, n, cps):
     # the image costs the DTC payload plus per-segment tables only
     tables = soa.seg_delta_off.nbytes + soa.seg_ckpt.nbytes
     pad = soa.info["n_segments"] * 64 * cps - n
-    assert soa.info["device_bytes"] - tables <= nb + 1 + 1.5 * pad + 40
+    topology = soa.par.nbytes + soa.carry.nbytes                  # resolved tree topology: 1 B per node + 8 B per chunk
+    assert soa.info["device_bytes"] - tables - topology <= nb + 1 + 1.5 * pad + 40
 
 
 @pytest.mark.parametrize("n", [1, 2, 65, 1000, 1001])
