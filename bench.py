@@ -14,8 +14,10 @@ N > 1 (the north-star decomposition, "scaling": "strong"): the index is cut into
 per rank; every rank answers the whole batch on its range; ONE all-gather of the partial top-k lists (RCCL)
 and a device merge.  `--data pipeline` builds the same seeded index on every rank and opens the rank's range;
 `--data stream` (indexes too large to build: BASELINE configs[3]/[4], `--codes 100000000` / `1000000000`)
-synthesises only the rank's own range (no rank ever holds N codes).  `--shard query` measures query replicas
-instead (weak scaling; reported under "query_replicas" beside the headline when asked with --also-replicas).
+synthesises only the rank's own range (no rank ever holds N codes).  Where every rank can hold the whole index
+(`--data pipeline`), the query-replica decomposition (every GPU answers its own batch on a full copy, weak
+scaling, no collective) is timed after the headline run and reported beside it under "query_replicas";
+`--shard query` makes it the headline instead.
 
 The timed region of K steps is repeated --reps times (each bracketed by barrier + synchronize); `value` is the
 median repetition, min/max are reported.  Steps rotate over 4 distinct query batches.  Rank 0 prints ONE JSON
@@ -207,7 +209,8 @@ def main():
                     help="N > 1: 'index' (= auto) cuts the index into DFS ranges, every GPU answers the one batch on its "
                          "range, one all-gather + merge (strong scaling, the north-star decomposition); 'query' = every GPU "
                          "holds the whole index and answers its own batch (weak scaling, no collective)")
-    ap.add_argument("--also-replicas", action="store_true", help="N > 1 index shards: also time query replicas afterwards")
+    ap.add_argument("--no-replicas", action="store_true",
+                    help="N > 1 index shards of an index every rank could hold whole: skip the query-replica run timed beside it")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="gloo = rehearsal of the N > 1 path on a box with fewer GPUs than ranks (ranks share GPUs)")
     args = ap.parse_args()
@@ -326,7 +329,7 @@ def main():
     total_steps = args.steps * max(1, args.reps)
 
     replicas = None
-    if sharded and args.also_replicas and wl["whole"]:
+    if sharded and not args.no_replicas and wl["whole"]:
         ridx = open_index()
         pipelined = True
         rt = timed(ridx, reps=3)

@@ -451,7 +451,8 @@ int run_batch(dpq_index* x, const float* d_queries, int nq, int top_k, int32_t* 
             ba.slot_query = nullptr;
             ba.top_k = top_k;
             ba.cap = cap_env > 0 ? std::max(cap_env, top_k) : std::max(top_k <= 256 ? 3072 : 8192, top_k);
-            ba.target = ba.cap;
+            static const int target_env = getenv("DPQ_BOOT_TARGET") ? atoi(getenv("DPQ_BOOT_TARGET")) : 0;
+            ba.target = target_env > 0 ? std::min(ba.cap, std::max(target_env, top_k)) : ba.cap;
             ba.thr_key = x->d_thr_key;
             ba.cand_count = x->d_cand_count;
             ba.fp32_accum = x->plain ? 1 : 0;

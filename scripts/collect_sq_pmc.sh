@@ -1,30 +1,35 @@
 #!/bin/bash
-# Runs ON THE GPU BOX (via gpurun): SQ / LDS counters of the scan kernel on the default workload,
+# Runs ON THE GPU BOX (via gpurun): SQ / LDS counters of the scan kernel on a bench.py workload,
 # one rocprofv3 --pmc pass per counter group (only --kernel-trace beside it, as the pool requires).
-#   gpurun -- 'bash scripts/collect_sq_pmc.sh r01_sq'
+#   gpurun -- 'bash scripts/collect_sq_pmc.sh r02_sq [bench args]'
 set -o pipefail
-TAG=${1:-sq}
+TAG=${1:-sq}; shift
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 OUT=gpurun_out/$TAG
 rm -rf "$OUT" && mkdir -p "$OUT"
 i=0
-for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS" \
-           "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_WAIT_INST_ANY" \
-           "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_ACTIVE_INST_ANY" \
-           "SQ_INST_CYCLES_VMEM SQ_INSTS_VMEM SQ_WAIT_ANY SQ_INSTS_WAVE32_LDS"; do
+for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_SMEM SQ_INSTS_BRANCH" \
+           "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY" \
+           "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_LDS_CMD_FIFO_FULL SQ_LDS_DATA_FIFO_FULL SQ_INST_CYCLES_SALU SQ_THREAD_CYCLES_VALU SQ_INST_LEVEL_LDS" \
+           "SQ_INSTS_LDS_LOAD SQ_INSTS_LDS_STORE SQ_INSTS_LDS_ATOMIC SQ_INSTS_LDS_LOAD_BANDWIDTH SQ_VMEM_TA_ADDR_FIFO_FULL SQ_VMEM_TA_CMD_FIFO_FULL SQ_INST_LEVEL_VMEM SQ_BUSY_CU_CYCLES"; do
   i=$((i+1))
-  timeout -k 10 300 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $OUT/p$i -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --check 0 > /dev/null 2> $OUT/p$i.err || echo "pass $i failed" >> $OUT/failed.txt
+  timeout -k 10 300 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $OUT/p$i -- python bench.py --steps 3 --warmup 1 --reps 1 --no-cpu-baseline --check 0 "$@" > /dev/null 2> $OUT/p$i.err || echo "pass $i failed" >> $OUT/failed.txt
 done
 python - "$OUT" <<'PY'
 import collections, csv, glob, json, sys
 out = sys.argv[1]
 agg = collections.defaultdict(list)
+dur = []
 for f in glob.glob(out + "/p*/*/*_counter_collection.csv"):
     for r in csv.DictReader(open(f)):
         if "scan_kernel" in r["Kernel_Name"]:
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
-res = {k: {"dispatches": len(v), "max": max(v), "sum": sum(v), "values_last3": v[-3:]} for k, v in agg.items()}
+            if "Start_Timestamp" in r:
+                dur.append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
+res = {k: {"dispatches": len(v), "mean": sum(v) / len(v), "max": max(v)} for k, v in agg.items()}
+res["_scan_kernel_mean_ns_under_pmc"] = sum(dur) / max(1, len(dur))
 json.dump(res, open(out + "/sq_summary.json", "w"), indent=1)
 for k, v in sorted(res.items()):
-    print(k, v["values_last3"])
+    print(k, v if not isinstance(v, dict) else round(v["mean"]))
 PY
+rm -rf $OUT/p?/

@@ -382,7 +382,7 @@ def test_bench_two_ranks_rehearsal(gpu, built, mode):
         line = _run_bench(common + ["--data", "stream", "--codes", "700001"])
         assert "own DFS range" in line["config"]["workload"] and line["index"]["codes_rank0"] == 350000
     elif mode == "index_pipeline":
-        line = _run_bench(common + ["--data", "pipeline", "--codes", "120000", "--also-replicas"])
+        line = _run_bench(common + ["--data", "pipeline", "--codes", "120000"])
         assert line["query_replicas"]["value"] > 0 and line["query_replicas"]["scaling"] == "weak"
     else:
         line = _run_bench(common + ["--data", "stream", "--codes", "200000", "--shard", "query"])
