@@ -74,6 +74,7 @@ SYMBOLS = [
     ("dpq_read_qnode_ids", ctypes.c_int, [ctypes.c_char_p, c_i64, _VP]),
     ("dpq_read_codes_plain", ctypes.c_int, [ctypes.c_char_p, ctypes.c_int, P(c_i64), _VP]),
     ("dpq_write_codes_plain", ctypes.c_int, [ctypes.c_char_p, _VP, c_i64, ctypes.c_int]),
+    ("dpq_read_codes_plain_ex", ctypes.c_int, [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, P(c_i64), _VP, _VP]),
     ("dpq_encode_pq", ctypes.c_int,
      [_VP, c_i64, ctypes.c_int, _VP, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _VP]),
     ("dpq_open_plain_memory", ctypes.c_int, [_VP, c_i64, ctypes.c_int, ctypes.c_int, P(OpenOpts), P(_VP)]),

@@ -183,6 +183,19 @@ def read_codes_plain(path, M):
     return out
 
 
+def read_codes_plain_ex(path, M, K=256, with_id=False):
+    """PQTree::Read's other layouts (pq_tree.cpp:1050-1078): uint16 codes for K > 256, (code, int32 id) records with_id.
+    Returns (codes [N][M] uint8 or uint16, ids int32 [N] or None)."""
+    lib = _lib.load()
+    n = _lib.c_i64()
+    check(lib.dpq_read_codes_plain_ex(path.encode(), M, K, int(with_id), n, None, None), "dpq_read_codes_plain_ex")
+    codes = np.empty((n.value, M), dtype=np.uint16 if K > 256 else np.uint8)
+    ids = np.empty(n.value, dtype=np.int32) if with_id else None
+    check(lib.dpq_read_codes_plain_ex(path.encode(), M, K, int(with_id), n, _np_ptr(codes), None if ids is None else _np_ptr(ids)),
+          "dpq_read_codes_plain_ex")
+    return codes, ids
+
+
 def write_codes_plain(path, codes):
     c = np.ascontiguousarray(codes, dtype=np.uint8)
     check(_lib.load().dpq_write_codes_plain(path.encode(), _np_ptr(c), c.shape[0], c.shape[1]), "dpq_write_codes_plain")

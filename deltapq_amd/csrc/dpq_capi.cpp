@@ -1098,6 +1098,37 @@ int dpq_read_codes_plain(const char* path, int M, int64_t* n_codes, uint8_t* out
     });
 }
 
+int dpq_read_codes_plain_ex(const char* path, int M, int K, int with_id, int64_t* n_codes, uint8_t* codes_out,
+                            int32_t* ids_out) {
+    return guarded([&]() -> int {
+    if (!path || !n_codes || M < 1 || K < 1) return fail(DPQ_ERR_ARG, "bad argument");
+    if (K > 256 && with_id) return fail(DPQ_ERR_ARG, "K > 256 with ids is not implemented in the reference either (pq_tree.cpp:1051-1054)");
+    FILE* f = fopen(path, "rb");
+    if (!f) return fail(DPQ_ERR_IO, std::string("cannot open ") + path);
+    int64_t n = 0;
+    if (fread(&n, sizeof(int64_t), 1, f) != 1 || n < 0 || n > (int64_t)INT32_MAX) {
+        fclose(f);
+        return fail(DPQ_ERR_FORMAT, std::string("bad header in ") + path);
+    }
+    *n_codes = n;
+    int rc = DPQ_OK;
+    if (codes_out || ids_out) {
+        const size_t cb = (size_t)M * (K > 256 ? 2 : 1), rec = cb + (with_id ? 4 : 0);
+        std::vector<uint8_t> buf((size_t)std::min<int64_t>(n, 1 << 16) * rec);
+        for (int64_t base = 0; base < n && !rc; base += 1 << 16) {
+            const size_t m = (size_t)std::min<int64_t>(1 << 16, n - base);
+            if (fread(buf.data(), rec, m, f) != m) rc = fail(DPQ_ERR_IO, std::string("short read on ") + path);
+            for (size_t i = 0; i < m && !rc; ++i) {
+                if (codes_out) memcpy(codes_out + ((size_t)base + i) * cb, buf.data() + i * rec, cb);
+                if (ids_out && with_id) memcpy(ids_out + (size_t)base + i, buf.data() + i * rec + cb, 4);
+            }
+        }
+    }
+    fclose(f);
+    return rc;
+    });
+}
+
 int dpq_write_codes_plain(const char* path, const uint8_t* codes, int64_t n_codes, int M) {
     return guarded([&]() -> int {
     if (!path || (!codes && n_codes > 0) || n_codes < 0 || M < 1) return fail(DPQ_ERR_ARG, "bad argument");

@@ -204,6 +204,13 @@ int dpq_read_qnode_ids(const char* path, int64_t n_codes, uint32_t* vec_ids);
 /* codes.bin.plain.M{M}K{K}N{N}: PQTree::Read / Write (pq_tree.cpp:1011-1081).  out == NULL returns n_codes. */
 int dpq_read_codes_plain(const char* path, int M, int64_t* n_codes, uint8_t* out);
 int dpq_write_codes_plain(const char* path, const uint8_t* codes, int64_t n_codes, int M);
+/* The other record layouts PQTree::Read knows (pq_tree.cpp:1050-1078): K > 256 stores two bytes per position
+ * (little-endian uint16), `with_id` (flag approx_with_id, main:64) appends a 4-byte int id to every M-byte code.
+ * codes_out: n * M * (K > 256 ? 2 : 1) bytes; ids_out: n int32 (with_id only); either may be NULL (first call:
+ * both NULL to learn n).  K > 256 together with with_id is refused, as in the reference (pq_tree.cpp:1051-1054).
+ * The scan engine itself indexes one byte per position (K <= 256), like the DTC format. */
+int dpq_read_codes_plain_ex(const char* path, int M, int K, int with_id, int64_t* n_codes, uint8_t* codes_out,
+                            int32_t* ids_out);
 /* PQ encoding on the GPU: nearest centroid per sub-space in fp32, first minimum wins
  * (PQTree::EncodePlain pq_tree.cpp:215-237; host buffers in/out). */
 int dpq_encode_pq(const float* vectors, int64_t n, int D, const float* codewords, int M, int K, int Ds, int device,

@@ -254,3 +254,29 @@ def test_header_promising_more_nodes_than_bytes_is_refused(lib):
     with pytest.raises(api.DpqError) as e:
         api.HostSoA(payload, 2_000_000_000, 8)
     assert e.value.status in (-3, -1)
+
+
+def test_codes_plain_other_record_layouts(lib, tmp_path):
+    """PQTree::Read (pq_tree.cpp:1032-1081) also knows two-byte codes (K > 256) and (code, int id) records (with_id)."""
+    from deltapq_amd import api
+    rng = np.random.default_rng(4)
+    n, M = 1000, 8
+    codes = rng.integers(0, 256, size=(n, M), dtype=np.uint8)
+    ids = rng.integers(0, 1 << 30, size=n, dtype=np.int32)
+    p1 = str(tmp_path / "with_id")
+    with open(p1, "wb") as f:
+        f.write(np.int64(n).tobytes())
+        rec = np.zeros((n, M + 4), dtype=np.uint8)
+        rec[:, :M] = codes
+        rec[:, M:] = ids.view(np.uint8).reshape(n, 4)
+        f.write(rec.tobytes())
+    c, i = api.read_codes_plain_ex(p1, M, 256, with_id=True)
+    assert np.array_equal(c, codes) and np.array_equal(i, ids)
+    wide = rng.integers(0, 1024, size=(n, M), dtype=np.uint16)
+    p2 = str(tmp_path / "k1024")
+    with open(p2, "wb") as f:
+        f.write(np.int64(n).tobytes() + wide.tobytes())          # PQTree::Write, pq_tree.cpp:1025-1026
+    c, i = api.read_codes_plain_ex(p2, M, 1024)
+    assert i is None and c.dtype == np.uint16 and np.array_equal(c, wide)
+    with pytest.raises(api.DpqError):
+        api.read_codes_plain_ex(p2, M, 1024, with_id=True)
