@@ -97,6 +97,7 @@ struct dpq_index {
     // threshold bootstrap: inverted multi-index over the shard's nodes (dpq::SoA::mi_*); boot = it is in use
     uint32_t *d_mi_cell = nullptr, *d_mi_code = nullptr, *d_mi_id = nullptr;
     bool boot = false;
+    int boot_classes = 0;
     unsigned long long* d_boot_stamps = nullptr;  // developer diagnostics (dpq_debug_boot_stamps)
     float* d_codebook = nullptr;
     // workspace, sized for ws_slots padded queries and ws_cap candidates each
@@ -445,6 +446,7 @@ int run_batch(dpq_index* x, const float* d_queries, int nq, int top_k, int32_t* 
             static const int cap_env = getenv("DPQ_BOOT_CAP") ? atoi(getenv("DPQ_BOOT_CAP")) : 0;
             dpq::BootArgs ba{};
             ba.cell_start = x->d_mi_cell;
+            ba.n_classes = x->boot_classes;
             ba.mi_code = x->d_mi_code;
             ba.mi_id = x->d_mi_id;
             ba.lut32 = x->d_lut32;
@@ -630,7 +632,7 @@ int open_from_payload(const uint8_t* payload, int64_t n_bytes, int64_t n_codes, 
 
     dpq::SoA soa;
     std::string err;
-    // threshold bootstrap: auto = on from 256 K nodes per shard (estimated before the byte-balanced cut)
+    // threshold bootstrap: auto = on from 64 K nodes per shard (estimated before the byte-balanced cut)
     const int64_t n_scan = o.num_codes > 0 ? std::min<int64_t>(o.num_codes, n_codes) : n_codes;
     const int64_t per_shard = n_scan / std::max(1, o.shard_count);
     int mi_stride = o.bootstrap < 0 ? 0 : dpq::bootstrap_stride_for(per_shard);
@@ -670,6 +672,7 @@ int open_from_payload(const uint8_t* payload, int64_t n_bytes, int64_t n_codes, 
         if (!rc) rc = up(&x->d_mi_code, soa.mi_code.data(), soa.mi_code.size() * 4);
         if (!rc) rc = up(&x->d_mi_id, soa.mi_id.data(), soa.mi_id.size() * 4);
         x->boot = !rc;
+        x->boot_classes = soa.mi_classes;
     }
     if (rc) {
         dpq_close(x);
@@ -765,7 +768,7 @@ int open_plain(const uint8_t* codes, int64_t n_codes, int M, int K, const dpq_op
                 ids.push_back((uint32_t)i);
                 cds.insert(cds.end(), codes + (size_t)i * M, codes + (size_t)(i + 1) * M);
             }
-            dpq::build_multi_index(ids, cds, M, mi_stride, &mi);
+            dpq::build_multi_index(ids, cds, M, mi_stride, dpq::bootstrap_classes_for((int64_t)ids.size()), &mi);
             auto upl = [&](uint32_t** d, const std::vector<uint32_t>& v) -> int {
                 int r = dev_alloc(d, v.size() + 16);
                 if (r) return r;
@@ -781,6 +784,7 @@ int open_plain(const uint8_t* codes, int64_t n_codes, int M, int K, const dpq_op
                 return rc;
             }
             x->boot = true;
+            x->boot_classes = mi.mi_classes;
             x->info.bootstrap_bytes = mi.bootstrap_bytes();
             x->info.bootstrap_stride = mi_stride;
         }

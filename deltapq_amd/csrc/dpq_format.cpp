@@ -147,7 +147,8 @@ int validate(const uint8_t* payload, int64_t n_bytes, int64_t n_codes, int M, dp
 }
 
 int transcode(const uint8_t* payload, int64_t n_bytes, int64_t n_codes, int M, int shard_rank, int shard_count,
-              int chunks_per_segment, SoA* out, std::string* err, int64_t scan_codes, int multi_index_stride) {
+              int chunks_per_segment, SoA* out, std::string* err, int64_t scan_codes, int multi_index_stride,
+              int multi_index_classes) {
     int rc = check_args(payload, n_bytes, n_codes, M, err);
     if (rc) return rc;
     if (scan_codes < 0 || scan_codes > n_codes) {
@@ -284,7 +285,9 @@ int transcode(const uint8_t* payload, int64_t n_bytes, int64_t n_codes, int M, i
             }
         }
     }
-    if (multi_index_stride > 0) build_multi_index(mi_ids, mi_codes, M, multi_index_stride, &o);
+    if (multi_index_stride > 0)
+        build_multi_index(mi_ids, mi_codes, M, multi_index_stride,
+                          multi_index_classes > 0 ? multi_index_classes : bootstrap_classes_for((int64_t)mi_ids.size()), &o);
     if (w.done() && w.offset() != n_bytes) {
         if (err) {
             char msg[160];
@@ -299,30 +302,33 @@ int transcode(const uint8_t* payload, int64_t n_bytes, int64_t n_codes, int M, i
     return DPQ_OK;
 }
 
-void build_multi_index(const std::vector<uint32_t>& ids, const std::vector<uint8_t>& codes, int M, int stride, SoA* out) {
-    // kBootPairs disjoint classes (sample j belongs to class j % kBootPairs); class p is indexed by the cell
+void build_multi_index(const std::vector<uint32_t>& ids, const std::vector<uint8_t>& codes, int M, int stride, int classes,
+                       SoA* out) {
+    // `classes` disjoint classes (sample j belongs to class j % classes); class p is indexed by the cell
     // (code[s], code[s + 1]) of ITS sub-space pair, s = bootstrap_pair_subspace(M, p).  Entries are class-major,
     // cell-major, DFS order inside a cell; cell_start holds absolute entry positions.
     const size_t n = ids.size(), W = (size_t)M / 4;
+    const size_t P = (size_t)std::min(std::max(classes, 1), kBootPairs);
     out->mi_stride = stride;
-    out->mi_cell_start.assign((size_t)kBootPairs * 65537, 0);
+    out->mi_classes = (int)P;
+    out->mi_cell_start.assign(P * 65537, 0);
     out->mi_code.assign(n * W, 0);
     out->mi_id.assign(n, 0);
-    auto cls = [&](size_t e) { return e % kBootPairs; };
+    auto cls = [&](size_t e) { return e % P; };
     auto cell_of = [&](size_t e) {
         const int s = bootstrap_pair_subspace(M, (int)cls(e));
         return (size_t)codes[e * M + s] | ((size_t)codes[e * M + s + 1] << 8);
     };
     for (size_t e = 0; e < n; ++e) out->mi_cell_start[cls(e) * 65537 + cell_of(e) + 1]++;
     uint32_t run = 0;
-    for (size_t p = 0; p < (size_t)kBootPairs; ++p) {
+    for (size_t p = 0; p < P; ++p) {
         uint32_t* cs = &out->mi_cell_start[p * 65537];
         cs[0] = run;  // counts were stored at [cell + 1]
         for (size_t c = 0; c < 65536; ++c) cs[c + 1] += cs[c];
         run = cs[65536];
     }
-    std::vector<uint32_t> fill((size_t)kBootPairs * 65536);
-    for (size_t p = 0; p < (size_t)kBootPairs; ++p)
+    std::vector<uint32_t> fill(P * 65536);
+    for (size_t p = 0; p < P; ++p)
         for (size_t c = 0; c < 65536; ++c) fill[p * 65536 + c] = out->mi_cell_start[p * 65537 + c];
     for (size_t e = 0; e < n; ++e) {  // stable: entries of a cell stay in DFS order
         const size_t pos = fill[cls(e) * 65536 + cell_of(e)]++;

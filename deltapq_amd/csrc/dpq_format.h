@@ -14,6 +14,7 @@
 namespace dpq {
 
 constexpr int kChunk = 64;  // nodes per wavefront step
+constexpr int kBootPairs = 4;  // classes of the threshold-bootstrap multi-index (sub-space pairs)
 // chunks per independently decodable segment: 128-node segments balance the scan's wavefronts better than 256
 // (0.431 vs 0.451 ms per 1000-query step at 1 M codes) for 0.56 B/node of checkpoints and offsets
 constexpr int kDefaultChunksPerSegment = 2;
@@ -81,7 +82,8 @@ struct SoA {
     // the k-th key as its first threshold -- as tight as a spread sample of a quarter of the index, and (four
     // different pairs) without the heavy tail one pair alone has.  Empty = not built.
     int mi_stride = 0;
-    std::vector<uint32_t> mi_cell_start;  // [kBootPairs][65537] absolute position of every cell's first entry
+    int mi_classes = 0;                   // kBootPairs, or 1 for shards of 64 K .. 256 K nodes (a class needs about one node per cell)
+    std::vector<uint32_t> mi_cell_start;  // [mi_classes][65537] absolute position of every cell's first entry
     std::vector<uint32_t> mi_code;        // [entries][M / 4] decoded codes, cell-major
     std::vector<uint32_t> mi_id;          // [entries] global DFS position
     int64_t nodes_per_segment() const { return (int64_t)kChunk * chunks_per_segment; }
@@ -95,21 +97,25 @@ struct SoA {
 int validate(const uint8_t* payload, int64_t n_bytes, int64_t n_codes, int M, dpq_dtc_stats* stats, std::string* err);
 // scan_codes > 0: image of the first scan_codes nodes only (the reference's `-N` below the header's n_codes,
 // h:2825-2829); the stream is parsed with the header's n_codes (it decides which node owns a whole depth byte).
-// multi_index_stride > 0: also build the bootstrap multi-index over every multi_index_stride-th local node.
+// multi_index_stride > 0: also build the bootstrap multi-index over every multi_index_stride-th local node, dealt to
+// multi_index_classes classes (0 = chosen by bootstrap_classes_for).
 int transcode(const uint8_t* payload, int64_t n_bytes, int64_t n_codes, int M, int shard_rank, int shard_count,
-              int chunks_per_segment, SoA* out, std::string* err, int64_t scan_codes = 0, int multi_index_stride = 0);
-// The bootstrap multi-index of a list of (global position, code) pairs: counting sort by cell.
-void build_multi_index(const std::vector<uint32_t>& ids, const std::vector<uint8_t>& codes, int M, int stride, SoA* out);
-constexpr int kBootPairs = 4;
+              int chunks_per_segment, SoA* out, std::string* err, int64_t scan_codes = 0, int multi_index_stride = 0,
+              int multi_index_classes = 0);
+// The bootstrap multi-index of a list of (global position, code) pairs: counting sort by class and cell.
+void build_multi_index(const std::vector<uint32_t>& ids, const std::vector<uint8_t>& codes, int M, int stride, int classes,
+                       SoA* out);
 // first sub-space of class p's pair: (0,1) (2,3) (4,5) (6,7) at M = 8; (0,1) (4,5) (8,9) (12,13) at M = 16
 inline int bootstrap_pair_subspace(int M, int p) { return 2 * p * (M / 8); }
-// Nodes below which the bootstrap is not worth its tables (the spread-sample cascade serves small indexes), and
-// the sampling stride that keeps the multi-index at <= 4 M entries.
-constexpr int64_t kBootstrapMinNodes = 262144;
+// Nodes below which the bootstrap is not worth its tables (the spread-sample cascade serves small indexes), the
+// sampling stride that keeps the multi-index at <= 4 M entries, and the number of classes: four different sub-space
+// pairs from 256 K sampled nodes (one node per cell and class), one class (pair 0/1) below.
+constexpr int64_t kBootstrapMinNodes = 65536;
 inline int bootstrap_stride_for(int64_t n_local) {
     if (n_local < kBootstrapMinNodes) return 0;
     return (int)((n_local + (1 << 22) - 1) >> 22);
 }
+inline int bootstrap_classes_for(int64_t n_sampled) { return n_sampled >= 4 * 65536 ? kBootPairs : 1; }
 int encode(const uint8_t* root_code, const uint8_t* depths, const uint16_t* masks, const uint8_t* deltas,
            int64_t n_codes, int M, uint8_t* out, int64_t* n_bytes, std::string* err);
 

@@ -87,7 +87,8 @@ struct SelectArgs {
 
 // Threshold bootstrap from the inverted multi-index (see bootstrap_kernel).
 struct BootArgs {
-    const uint32_t* cell_start;    // [4 classes][65537] absolute entry positions
+    const uint32_t* cell_start;    // [n_classes][65537] absolute entry positions
+    int32_t n_classes;             // 4 (sub-space pairs 0/1 .. 6/7) or 1 (pair 0/1)
     const uint32_t* mi_code;       // [entries][M / 4]
     const uint32_t* mi_id;         // [entries] global DFS positions
     const float* lut32;            // exact tables [query][m][256]

@@ -1276,12 +1276,14 @@ __global__ __launch_bounds__(kBootThreads, M <= 8 ? 8 : 6) void bootstrap_kernel
     int have = 0;  // keys so far (block-uniform)
     // Every class walks its 65536 cells in the order w = 0, 1, ...: shell t = floor(sqrt(w)) (= max of the two
     // centroid ranks), position s = w - t^2 inside it; s <= t: ranks (i, j) = (t, s), else (s - t - 1, t).  A round
-    // takes the next kBootCells / kBootPairs cells of every class, class-interleaved (u = 4 (w - w0) + p), so that
+    // takes the next kBootCells / P cells of every class, class-interleaved (u = P (w - w0) + p), so that
     // a cut-off list keeps the best cells of all classes.
+    const int P = a.n_classes;  // 4 or 1
+    const int p_shift = P == 4 ? 2 : 0;
     int w0 = 0;
     while (w0 < 65536 && have < a.target) {
-        const int n_w = min(kBootCells / kBootPairs, 65536 - w0);
-        const int n_cells = kBootPairs * n_w;
+        const int n_w = min(kBootCells >> p_shift, 65536 - w0);
+        const int n_cells = n_w << p_shift;
         uint32_t cnt[kBootCellsPerThread], first[kBootCellsPerThread], mine = 0;
 #pragma unroll
         for (int r = 0; r < kBootCellsPerThread; ++r) {  // thread -> cells 2 tid, 2 tid + 1
@@ -1289,7 +1291,7 @@ __global__ __launch_bounds__(kBootThreads, M <= 8 ? 8 : 6) void bootstrap_kernel
             cnt[r] = 0;
             first[r] = 0;
             if (u < n_cells) {
-                const int p = u & (kBootPairs - 1), v = (u >> 2) + w0;
+                const int p = u & (P - 1), v = (u >> p_shift) + w0;
                 int t = (int)sqrtf((float)v);
                 t -= t * t > v ? 1 : 0;
                 t += (t + 1) * (t + 1) <= v ? 1 : 0;
@@ -1374,7 +1376,8 @@ size_t bootstrap_lds_bytes(int M, int cap) {
 
 hipError_t launch_bootstrap(const BootArgs& a, int M, int n_slots, hipStream_t stream) {
     if (n_slots <= 0) return hipSuccess;
-    if (a.cap < a.top_k || a.cap < 1024 || a.cap > 16384 || !a.cell_start) return hipErrorInvalidValue;  // the rank sort borrows 8 KB of the key list
+    if (a.cap < a.top_k || a.cap < 1024 || a.cap > 16384 || !a.cell_start || (a.n_classes != 1 && a.n_classes != kBootPairs))
+        return hipErrorInvalidValue;  // the rank sort borrows 8 KB of the key list
     const size_t lds = bootstrap_lds_bytes(M, a.cap);
     if (M == 8) {
         static std::atomic<bool> done[64] = {};

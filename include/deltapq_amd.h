@@ -91,7 +91,7 @@ typedef struct dpq_open_opts {
                                  * rule (h:2949, 2970) does for an index of n codes. */
     int32_t bootstrap;          /* threshold bootstrap (an inverted multi-index over the shard's nodes, 12 B per
                                  * sampled node, that gives every query a tight first threshold): 0 = automatic (on
-                                 * from 256 K nodes per shard), 1 = on (from 16 K nodes), -1 = off (the spread-sample
+                                 * from 64 K nodes per shard), 1 = on (from 16 K nodes), -1 = off (the spread-sample
                                  * cascade alone).  Results are identical either way.  dpq_soa_build: > 0 = build the
                                  * multi-index with this sampling stride. */
     int32_t reserved[1];

@@ -197,13 +197,12 @@ def test_merge_topk_host(lib):
         assert [c[0] for c in cand[:k]] == md[q].tolist()
 
 
-@pytest.mark.parametrize("stride,shards", [(1, 1), (3, 1), (2, 3)])
-def test_bootstrap_multi_index_layout(lib, stride, shards):
+@pytest.mark.parametrize("stride,shards,n", [(1, 1, 6000), (3, 1, 6000), (2, 3, 6000), (1, 1, 270000)])
+def test_bootstrap_multi_index_layout(lib, stride, shards, n):
     """The threshold-bootstrap multi-indexes: every stride-th local node exactly once; sample j in class j % 4,
     filed under the cell (code[s], code[s + 1]) of its class's sub-space pair (s = 0, 2, 4, 6), global DFS
     position attached, DFS order inside a cell, absolute entry positions in cell_start."""
     from deltapq_amd import api, synth
-    n = 6000
     tree, payload, _ = make_case(n, seed=91)
     codes = synth.decode_tree_codes(tree)
     seen = []
@@ -211,19 +210,20 @@ def test_bootstrap_multi_index_layout(lib, stride, shards):
         soa = api.HostSoA(payload, n, 8, shard_rank=r, shard_count=shards, multi_index_stride=stride)
         lo, hi = soa.info["node_lo"], soa.info["node_hi"]
         want = np.arange(lo, hi, stride)
-        cs, ids, cd = soa.mi_cell_start.reshape(4, 65537).astype(np.int64), soa.mi_id, soa.mi_code.view(np.uint8).reshape(-1, 8)
-        assert cs[0, 0] == 0 and cs[3, -1] == len(ids) == len(want)
+        P = 4 if len(want) >= 4 * 65536 else 1       # four sub-space pairs need about one node per cell and class
+        cs, ids, cd = soa.mi_cell_start.reshape(P, 65537).astype(np.int64), soa.mi_id, soa.mi_code.view(np.uint8).reshape(-1, 8)
+        assert cs[0, 0] == 0 and cs[P - 1, -1] == len(ids) == len(want)
         assert np.array_equal(np.sort(ids), want) and np.array_equal(cd, codes[ids])
-        for p in range(4):
+        for p in range(P):
             assert np.all(np.diff(cs[p]) >= 0) and (p == 0 or cs[p, 0] == cs[p - 1, -1])
             sl = slice(cs[p, 0], cs[p, -1])
-            assert np.array_equal(np.sort(ids[sl]), want[p::4])              # class p = samples p, p + 4, ...
+            assert np.array_equal(np.sort(ids[sl]), want[p::P])              # class p = samples p, p + P, ...
             cell = cd[sl, 2 * p].astype(np.int64) | (cd[sl, 2 * p + 1].astype(np.int64) << 8)
             assert np.all(np.diff(cell) >= 0)                                  # cell-major
             assert np.array_equal(cs[p][cell] - cs[p, 0], np.searchsorted(cell, cell, side="left"))
             same = np.diff(cell) == 0
             assert np.all(np.diff(ids[sl].astype(np.int64))[same] > 0)        # DFS order inside a cell
-        assert soa.info["bootstrap_stride"] == stride and soa.info["bootstrap_bytes"] == 4 * (4 * 65537 + 3 * len(ids))
+        assert soa.info["bootstrap_stride"] == stride and soa.info["bootstrap_bytes"] == 4 * (P * 65537 + 3 * len(ids))
         seen.append(ids)
     assert len(np.unique(np.concatenate(seen))) == sum(len(s) for s in seen)
 

@@ -653,7 +653,7 @@ def test_adversarial_table_magnitudes(gpu, oracle):
 
 
 # (n_codes, n_queries, top_k, bootstrap option, dup_heavy)
-BOOT_CASES = [(300001, 40, 100, 0, False), (20000, 33, 10, 1, False), (70000, 20, 100, 1, True),
+BOOT_CASES = [(300001, 40, 100, 0, False), (20000, 33, 10, 1, False), (70000, 20, 100, 0, True), (130000, 24, 100, 0, False),
               (400000, 24, 1000, 0, False), (262144, 16, 2048, 0, False)]
 
 
@@ -665,7 +665,8 @@ def test_threshold_bootstrap_gives_the_same_answer(gpu, oracle, codebook, n, nq,
     tree, payload, nb = make_case(n, seed=n + 3, dup_heavy=dup)
     qs = synth.make_queries(nq, 128, seed=n + 4)
     ids, dists, prof, info = run(gpu, payload, n, codebook, qs, k, bootstrap=boot)
-    assert info["bootstrap_stride"] == 1 and info["bootstrap_bytes"] == 4 * (4 * 65537 + 3 * n)
+    classes = 4 if n >= 4 * 65536 else 1
+    assert info["bootstrap_stride"] == 1 and info["bootstrap_bytes"] == 4 * (classes * 65537 + 3 * n)
     ids0, dists0, _, info0 = run(gpu, payload, n, codebook, qs, k, bootstrap=-1)
     assert info0["bootstrap_bytes"] == 0
     assert np.array_equal(dists.view(np.uint32), dists0.view(np.uint32))
