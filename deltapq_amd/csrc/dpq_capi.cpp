@@ -119,9 +119,26 @@ struct dpq_index {
         int nq, top_k;
         int32_t* d_ids;
         float* d_dists;
-        hipStream_t stream;
+        hipStream_t stream;          // the stream it runs on (the caller's, or one of the two lane streams)
+        hipStream_t user_stream;     // the stream the caller enqueued it on
         int flag_slot;
     };
+    // Pipelined batches alternate between two LANES = two workspaces + two internal streams, so that a batch's
+    // table build runs under the previous batch's scan (the scan fills every CU's LDS and half its wave slots:
+    // the LUT kernel needs neither) and its bootstrap next to the previous batch's select.  The d_* workspace
+    // fields above are the ACTIVE lane's; the other lane is parked here.
+    struct Lane {
+        float *d_lut32 = nullptr, *d_lut_min = nullptr;
+        uint4* d_qtab = nullptr;
+        uint32_t *d_cand_count = nullptr, *d_overflow = nullptr;
+        uint64_t *d_cand_key = nullptr, *d_thr_key = nullptr, *d_scratch = nullptr;
+        int ws_slots = 0, ws_cap = 0;
+    };
+    Lane parked;                     // workspace of the lane that is not active
+    int active_lane = 0;
+    hipStream_t lane_stream[2] = {nullptr, nullptr};
+    hipEvent_t lane_ready[2] = {nullptr, nullptr};   // recorded on the caller's stream: the batch's inputs are there
+    uint64_t async_seq = 0;
     std::vector<Pending> pending;
     // staging for the host-pointer entry point
     float* d_q_stage = nullptr;
@@ -158,6 +175,29 @@ struct dpq_index {
 };
 
 namespace {
+
+void switch_lane(dpq_index* x, int lane) {
+    if (lane == x->active_lane) return;
+    dpq_index::Lane cur;
+    cur.d_lut32 = x->d_lut32; cur.d_lut_min = x->d_lut_min; cur.d_qtab = x->d_qtab;
+    cur.d_cand_count = x->d_cand_count; cur.d_overflow = x->d_overflow;
+    cur.d_cand_key = x->d_cand_key; cur.d_thr_key = x->d_thr_key; cur.d_scratch = x->d_scratch;
+    cur.ws_slots = x->ws_slots; cur.ws_cap = x->ws_cap;
+    const dpq_index::Lane& o = x->parked;
+    x->d_lut32 = o.d_lut32; x->d_lut_min = o.d_lut_min; x->d_qtab = o.d_qtab;
+    x->d_cand_count = o.d_cand_count; x->d_overflow = o.d_overflow;
+    x->d_cand_key = o.d_cand_key; x->d_thr_key = o.d_thr_key; x->d_scratch = o.d_scratch;
+    x->ws_slots = o.ws_slots; x->ws_cap = o.ws_cap;
+    x->parked = cur;
+    x->active_lane = lane;
+}
+
+void free_parked_lane(dpq_index* x) {
+    dpq_index::Lane& o = x->parked;
+    hipFree(o.d_lut32); hipFree(o.d_lut_min); hipFree(o.d_qtab); hipFree(o.d_cand_count); hipFree(o.d_overflow);
+    hipFree(o.d_cand_key); hipFree(o.d_thr_key); hipFree(o.d_scratch);
+    o = dpq_index::Lane();
+}
 
 void free_workspace(dpq_index* x) {
     hipFree(x->d_lut32);
@@ -1260,6 +1300,11 @@ int dpq_close(dpq_index* x) {
     }
     for (auto e : x->ev_pool) hipEventDestroy(e);
     free_workspace(x);
+    free_parked_lane(x);
+    for (int l = 0; l < 2; ++l) {
+        if (x->lane_stream[l]) hipStreamDestroy(x->lane_stream[l]);
+        if (x->lane_ready[l]) hipEventDestroy(x->lane_ready[l]);
+    }
     hipFree(x->d_nib);
     hipFree(x->d_par);
     hipFree(x->d_carry);
@@ -1307,12 +1352,13 @@ int dpq_finish(dpq_index* x) {
     DPQ_HIP(hipSetDevice(x->device));
     std::vector<dpq_index::Pending> todo;
     todo.swap(x->pending);
-    hipStream_t last = nullptr;
-    bool first = true;
-    for (const auto& p : todo) {
-        if (first || p.stream != last) DPQ_HIP(hipStreamSynchronize(p.stream));
-        last = p.stream;
-        first = false;
+    {
+        std::vector<hipStream_t> seen;
+        for (const auto& p : todo)
+            if (std::find(seen.begin(), seen.end(), p.stream) == seen.end()) {
+                DPQ_HIP(hipStreamSynchronize(p.stream));
+                seen.push_back(p.stream);
+            }
     }
     for (const auto& p : todo) {
         if (*reinterpret_cast<volatile uint32_t*>(x->h_any + p.flag_slot) == 0) continue;
@@ -1330,20 +1376,35 @@ int dpq_query_batch_device_async(dpq_index* x, const float* d_queries, int nq, i
     int rc = check_batch_args(x, d_queries, nq, top_k, d_ids, d_dists);
     if (rc || nq == 0) return rc;
     DPQ_HIP(hipSetDevice(x->device));
-    hipStream_t stream = reinterpret_cast<hipStream_t>(hip_stream);
-    // all batches in flight share one workspace (tables, candidate buffers, thresholds): they are ordered
-    // by the stream only.  A batch for another stream first settles what is in flight.
-    if (!x->pending.empty() && x->pending.back().stream != stream && (rc = dpq_finish(x))) return rc;
+    hipStream_t user = reinterpret_cast<hipStream_t>(hip_stream);
+    // Batches in flight are ordered by the caller's stream.  A batch for another stream first settles what is in flight.
+    if (!x->pending.empty() && x->pending.back().user_stream != user && (rc = dpq_finish(x))) return rc;
+    // DPQ_ASYNC_OVERLAP=0: every batch on the caller's stream with one workspace (round 1's behaviour)
+    static const bool overlap = !(getenv("DPQ_ASYNC_OVERLAP") && atoi(getenv("DPQ_ASYNC_OVERLAP")) == 0);
     const int D = x->M * x->Ds;
     for (int base = 0; base < nq; base += kMaxBatchQueries) {
         const int n = std::min(kMaxBatchQueries, nq - base);
         if ((int)x->pending.size() >= dpq_index::kFlagSlots - 1 && (rc = dpq_finish(x))) return rc;
         const int slot = 1 + (int)x->pending.size();
+        hipStream_t stream = user;
+        if (overlap) {
+            // the batch runs on its lane's stream once the caller's stream has reached this point (its inputs are
+            // there); a lane's batches follow each other on the lane's stream, so its workspace is never shared
+            const int lane = (int)(x->async_seq++ & 1);
+            if (!x->lane_stream[lane]) {
+                DPQ_HIP(hipStreamCreateWithFlags(&x->lane_stream[lane], hipStreamNonBlocking));
+                DPQ_HIP(hipEventCreateWithFlags(&x->lane_ready[lane], hipEventDisableTiming));
+            }
+            switch_lane(x, lane);
+            stream = x->lane_stream[lane];
+            DPQ_HIP(hipEventRecord(x->lane_ready[lane], user));
+            DPQ_HIP(hipStreamWaitEvent(stream, x->lane_ready[lane], 0));
+        }
         rc = run_batch(x, d_queries + (size_t)base * D, n, top_k, d_ids + (size_t)base * top_k,
                        d_dists + (size_t)base * top_k, stream, slot);
         if (rc) return rc;
         x->pending.push_back({d_queries + (size_t)base * D, n, top_k, d_ids + (size_t)base * top_k,
-                              d_dists + (size_t)base * top_k, stream, slot});
+                              d_dists + (size_t)base * top_k, stream, user, slot});
     }
     if (x->prof) {
         x->prof_acc.query_batches++;
