@@ -492,7 +492,11 @@ int run_batch(dpq_index* x, const float* d_queries, int nq, int top_k, int32_t* 
             ba.lut32 = x->d_lut32;
             ba.slot_query = nullptr;
             ba.top_k = top_k;
-            ba.cap = cap_env > 0 ? std::max(cap_env, top_k) : std::max(top_k <= 256 ? 3072 : 8192, top_k);
+            // 4-byte keys: up to 6144 of them keep the block at 40 KB of LDS (four blocks per CU).  Measured at top-100
+            // (scripts/gpu_boot_ab.sh): 3072 / 4096 / 6144 nodes -> 727 / 559 / 404 candidates per query and the same
+            // step time within 1.5 % (what the scan saves the bootstrap spends); 3072 is the shortest critical path.
+            ba.cap = std::max(cap_env > 0 ? cap_env : (top_k <= 256 ? 3072 : 8192), std::max(top_k, 2048));
+            ba.cap = (ba.cap + 63) / 64 * 64;
             static const int target_env = getenv("DPQ_BOOT_TARGET") ? atoi(getenv("DPQ_BOOT_TARGET")) : 0;
             ba.target = target_env > 0 ? std::min(ba.cap, std::max(target_env, top_k)) : ba.cap;
             ba.thr_key = x->d_thr_key;

@@ -877,8 +877,19 @@ __device__ __forceinline__ void block_bitonic_sort(uint64_t* v, int n_pow2, int 
 // 3 barriers per pass; the walk stops as soon as the chosen bin holds one key.
 // `ignore` (= ~0) marks padding entries; they sort last and are never selected
 // because rank <= number of valid keys.
-__device__ uint64_t block_radix_select(const uint64_t* keys, int n, int rank, uint32_t* hist, uint32_t* bcast,
+// K = uint64_t (distance bits << 32 | id) or uint32_t (distance bits alone; widened on the fly, 0xffffffff = padding).
+template <class K>
+__device__ uint64_t block_radix_select(const K* keys_in, int n, int rank, uint32_t* hist, uint32_t* bcast,
                                        int tid, int nthreads) {
+    struct Loader {
+        const K* p;
+        __device__ __forceinline__ uint64_t operator[](int i) const {
+            if constexpr (sizeof(K) == 8) return p[i];
+            const uint32_t v = p[i];
+            return v == 0xffffffffu ? ~0ull : (uint64_t)v;
+        }
+    };
+    const Loader keys{keys_in};
     // block min / max of the valid keys (padding = ~0 is excluded from max)
     uint64_t lo = ~0ull, hi = 0ull;
     for (int i = tid; i < n; i += nthreads) {
@@ -1209,8 +1220,8 @@ __global__ __launch_bounds__(kBootThreads, M <= 8 ? 8 : 6) void bootstrap_kernel
     constexpr int W = Cfg<M>::W;
     constexpr int TE = M * 256;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint64_t* keys = reinterpret_cast<uint64_t*>(smem);                                   // [cap]
-    float* T = reinterpret_cast<float*>(smem + (size_t)a.cap * 8);                        // [M][256] exact tables
+    uint32_t* keys = reinterpret_cast<uint32_t*>(smem);                                   // [cap] fp32 distance bits (see below)
+    float* T = reinterpret_cast<float*>(smem + (size_t)a.cap * 4);                        // [M][256] exact tables
     uint32_t* cstart = reinterpret_cast<uint32_t*>(T + TE);                               // [kBootCells] first multi-index entry of the cell
     uint16_t* pre = reinterpret_cast<uint16_t*>(cstart + kBootCells);                     // [1024 + 4] node prefix of the round's cells, clamped to 65535
     uint8_t* ord = reinterpret_cast<uint8_t*>(pre + 1024 + 4);                            // [2 * kBootPairs][256] centroids by rank
@@ -1245,7 +1256,7 @@ __global__ __launch_bounds__(kBootThreads, M <= 8 ? 8 : 6) void bootstrap_kernel
             const int sl = 4 * h + r, sub = 2 * (sl >> 1) * (M / 8) + (sl & 1);
             key[r] = (__float_as_uint(T[sub * 256 + i]) & 0xffffff00u) | (uint32_t)i;  // entries >= 0 (or +inf): uint order
         }
-        uint32_t* xch = reinterpret_cast<uint32_t*>(keys);  // [4][512] exchange buffer (the key list is empty yet)
+        uint32_t* xch = keys;  // [4][512] exchange buffer (the key list is empty yet; cap >= 2048)
 #pragma unroll
         for (int k = 2; k <= 256; k <<= 1) {
 #pragma unroll
@@ -1331,11 +1342,13 @@ __global__ __launch_bounds__(kBootThreads, M <= 8 ? 8 : 6) void bootstrap_kernel
         }
         __syncthreads();
         mark(2);
-        // exact evaluation of the round's nodes, as many as the key list still takes; kBootBatch per thread
-        // go through search -> entry loads -> distance together
+        // Evaluation of the round's nodes, as many as the key list still takes; kBootBatch per thread go through
+        // search -> entry loads -> distance together.  Only an UPPER BOUND of the k-th key has to leave this kernel,
+        // so the distances are plain fp32 sums (relative error < 2^-21 against the exact fp64 sum) and the keys are
+        // their 32 bits: no fp64 adds, no id loads, half the LDS per key; the bound is inflated below.
         const int take = min((int)total, a.cap - have);
         for (int v0 = 0; v0 < take; v0 += kBootThreads * kBootBatch) {
-            uint32_t e[kBootBatch], code[kBootBatch][W], id[kBootBatch];
+            uint32_t e[kBootBatch], code[kBootBatch][W];
 #pragma unroll
             for (int r = 0; r < kBootBatch; ++r) {
                 const int v = min(v0 + tid + r * kBootThreads, take - 1);
@@ -1349,12 +1362,14 @@ __global__ __launch_bounds__(kBootThreads, M <= 8 ? 8 : 6) void bootstrap_kernel
             for (int r = 0; r < kBootBatch; ++r) {
 #pragma unroll
                 for (int w = 0; w < W; ++w) code[r][w] = a.mi_code[(size_t)e[r] * W + w];
-                id[r] = a.mi_id[e[r]];
             }
 #pragma unroll
             for (int r = 0; r < kBootBatch; ++r) {
                 const int v = v0 + tid + r * kBootThreads;
-                if (v < take) keys[have + v] = make_key(exact_dist<M>(T, code[r], a.fp32_accum != 0), id[r]);
+                float d = 0.0f;
+#pragma unroll
+                for (int m = 0; m < M; ++m) d += T[m * 256 + ((code[r][m >> 2] >> (8 * (m & 3))) & 0xffu)];
+                if (v < take) keys[have + v] = __float_as_uint(d);
             }
         }
         have += take;
@@ -1364,19 +1379,26 @@ __global__ __launch_bounds__(kBootThreads, M <= 8 ? 8 : 6) void bootstrap_kernel
         if (have >= a.cap) break;
     }
     uint64_t kth = ~0ull;  // fewer than k nodes in the whole multi-index: no threshold
-    if (have >= a.top_k) kth = block_radix_select(keys, have, a.top_k, hist, bcast, tid, kBootThreads);
+    if (have >= a.top_k) {
+        // k nodes have an fp32-summed distance <= d; their exact distances (fp64 sum rounded once; the plain scan:
+        // fp32 sum in position order) are within 2^-20 of it, so d * (1 + 2^-19), rounded up, with the largest id
+        // is >= the keys of k real nodes: a valid upper bound of the final k-th key.
+        const uint32_t dbits = (uint32_t)block_radix_select(keys, have, a.top_k, hist, bcast, tid, kBootThreads);
+        const float bound = __double2float_ru((double)__uint_as_float(dbits) * (1.0 + 0x1p-19));
+        kth = ((uint64_t)__float_as_uint(bound) << 32) | 0xffffffffull;
+    }
     if (tid == 0) a.thr_key[slot] = kth;
     mark(4);
     if (a.stamps && tid == 0) a.stamps[(size_t)slot * 8 + 7] = __builtin_amdgcn_s_memrealtime();
 }
 
 size_t bootstrap_lds_bytes(int M, int cap) {
-    return (size_t)cap * 8 + (size_t)M * 256 * 4 + (size_t)kBootCells * 4 + (1024 + 4) * 2 + 2 * kBootPairs * 256 + (264 + 2 + 8) * 4;
+    return (size_t)cap * 4 + (size_t)M * 256 * 4 + (size_t)kBootCells * 4 + (1024 + 4) * 2 + 2 * kBootPairs * 256 + (264 + 2 + 8) * 4;
 }
 
 hipError_t launch_bootstrap(const BootArgs& a, int M, int n_slots, hipStream_t stream) {
     if (n_slots <= 0) return hipSuccess;
-    if (a.cap < a.top_k || a.cap < 1024 || a.cap > 16384 || !a.cell_start || (a.n_classes != 1 && a.n_classes != kBootPairs))
+    if (a.cap < a.top_k || a.cap < 2048 || a.cap > 16384 || !a.cell_start || (a.n_classes != 1 && a.n_classes != kBootPairs))
         return hipErrorInvalidValue;  // the rank sort borrows 8 KB of the key list
     const size_t lds = bootstrap_lds_bytes(M, a.cap);
     if (M == 8) {
