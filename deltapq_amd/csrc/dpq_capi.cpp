@@ -479,6 +479,7 @@ int run_batch(dpq_index* x, const float* d_queries, int nq, int top_k, int32_t* 
         DPQ_HIP(dpq::launch_select(se, x->M, nq, stream));
         return DPQ_OK;
     }
+    bool boot_built_tables = false;
     for (size_t l = 0; l < n_levels; ++l) {
         const bool final_pass = l + 1 == n_levels;
         if (l == 0 && x->boot) {
@@ -503,9 +504,15 @@ int run_batch(dpq_index* x, const float* d_queries, int nq, int top_k, int32_t* 
             ba.cand_count = x->d_cand_count;
             ba.fp32_accum = x->plain ? 1 : 0;
             ba.stamps = x->d_boot_stamps;
+            ba.n_queries = nq;
+            // DPQ_FUSE_QUANTISE=0: the first level's tables from quantise_kernel, as for every later level
+            static const bool fuse = !(getenv("DPQ_FUSE_QUANTISE") && atoi(getenv("DPQ_FUSE_QUANTISE")) == 0);
+            ba.qtab = fuse ? x->d_qtab : nullptr;
+            ba.lut_min = x->d_lut_min;
+            boot_built_tables = fuse;
             {
                 Timer t(x, stream, 2);
-                DPQ_HIP(dpq::launch_bootstrap(ba, x->M, nq, stream));
+                DPQ_HIP(dpq::launch_bootstrap(ba, x->M, fuse ? nqp : nq, stream));
             }
             if (x->prof) x->prof_acc.select_launches++;
             continue;
@@ -525,7 +532,7 @@ int run_batch(dpq_index* x, const float* d_queries, int nq, int top_k, int32_t* 
             const Regions rg = regions_for(x, sa.n_seg_pass, ngroups, top_k, cap);
             sa.region_cap = se.region_cap = rg.region_cap;
             se.n_regions = 1 + rg.splits;
-            {
+            if (!(boot_built_tables && l == 1)) {  // the bootstrap kernel wrote the first level's tables itself
                 Timer t(x, stream, 3);
                 DPQ_HIP(dpq::launch_quantise(sa, ngroups, stream));
             }

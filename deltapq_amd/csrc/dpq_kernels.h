@@ -99,6 +99,11 @@ struct BootArgs {
     uint64_t* thr_key;             // out [slots]
     uint32_t* cand_count;          // [slots][kRegionStride]: region 0 (carried winners) is set to 0
     int32_t fp32_accum;
+    int32_t n_queries;             // slots >= n_queries (slot_query == NULL) are padding of the last query group
+    // non-NULL: also write the slot's fields of the first filter level's tables (what quantise_kernel would build
+    // from this threshold); the launch then covers the padding slots too
+    uint4* qtab;
+    const float* lut_min;          // [query][M]
     unsigned long long* stamps;    // developer diagnostics (NULL in product calls): [slots][8] s_memtime marks
 };
 

@@ -406,6 +406,88 @@ __device__ __forceinline__ float exact_dist(const float* __restrict__ T, const u
 // result, and s32 carries a (1 - 2^-20) factor, so every entry is <= the exact real value.
 // grid = (NG * M, groups), block = 256 threads: thread k builds the 16-byte entry (g, m, k).
 // ---------------------------------------------------------------------------
+// Scale and offsets of one slot's filter fields (see the comment above): s32 = QT / (tau' - sum of minima),
+// the additive term of sub-space m, rounded so that every field stays a lower bound.
+struct FilterScale {
+    float s32;      // 0: all fields 0, everything passes the filter
+    uint32_t bias;  // added to the m = 0 fields
+};
+
+template <int M>
+__device__ __forceinline__ FilterScale filter_scale(uint64_t key, const float* __restrict__ mins) {
+    using C = Cfg<M>;
+    FilterScale r{0.0f, 0u};
+    double B = 0.0;
+#pragma unroll
+    for (int mm = 0; mm < M; ++mm) B += (double)mins[mm];
+    const double taup = (double)__uint_as_float((uint32_t)(key >> 32)) * (1.0 + 0x1p-20);
+    const double R = taup - B;
+    if (key != ~0ull && R > 0.0 && R < 1e300) {  // else: no threshold yet (or degenerate), keep everything
+        r.s32 = (float)((double)C::QT / R * (1.0 - 0x1p-20));
+        r.bias = (uint32_t)C::BIAS;
+    }
+    return r;
+}
+
+// entry = fma(T, s32, -off) with off >= min * s32 (rounded up): never above (T - min) * s32.  EB = 8: returns the
+// whole additive term of v_cvt_pk_u8_f32's input (bias of m = 0 and half a unit of slack folded in, rounded DOWN).
+template <int M>
+__device__ __forceinline__ float filter_offset(const FilterScale& fs, float min_m, int m) {
+    const float mn = fs.s32 != 0.0f ? min_m : 0.0f;
+    const double od = (double)mn * (double)fs.s32;
+    float of = (float)od;
+    if ((double)of < od) of = __uint_as_float(__float_as_uint(of) + 1u);  // od >= 0: next float up
+    if constexpr (Cfg<M>::EB == 8) {
+        const double sd = (m == 0 ? (double)fs.bias : 0.0) - 0.5 - (double)of;
+        float sf = (float)sd;
+        if ((double)sf > sd) sf = __uint_as_float(__float_as_uint(sf) + (sf > 0.0f ? -1 : 1));  // next float down
+        of = sf;
+    }
+    return of;
+}
+
+template <int M>
+__device__ __forceinline__ uint32_t filter_field(float tv, float sc, float of, uint32_t bias_m) {
+    using C = Cfg<M>;
+    if constexpr (C::EB == 8) {
+        // v_cvt_pk_u8_f32: float -> u8 clamped to [0, 255].  Half a unit is taken off first (in `of`), so whichever
+        // way the conversion rounds, the byte is <= floor(value): the entry stays a lower bound (negative -> 0;
+        // inf/NaN of centroids beyond K -> SAT by the min).
+        const float fv = fminf(__fmaf_rn(tv, sc, of), (float)C::SAT + (float)bias_m);
+        return __builtin_amdgcn_cvt_pk_u8_f32(fv, 0u, 0u);
+    } else {
+        const float fv = __fmaf_rn(tv, sc, -of);
+        // fv < 0 only by the round-up of `of` (true value 0); NaN/inf (k >= K) saturate
+        const uint32_t v = fv < (float)C::SAT ? (fv > 0.0f ? (uint32_t)fv : 0u) : (uint32_t)C::SAT;
+        return v + bias_m;
+    }
+}
+
+// One slot's fields of its group's filter tables, written field by field (1 or 2 bytes each, 16 bytes apart):
+// T = the slot's exact tables (NULL: an unused slot, every m = 0 field rejects).
+template <int M>
+__device__ __forceinline__ void write_filter_fields(uint4* qtab, int slot, const float* T, float sc, const float* of_m,
+                                                    uint32_t bias, int tid, int nthreads) {
+    using C = Cfg<M>;
+    constexpr int F = C::F, EB = C::EB, QG = C::QG, NG = C::NG, J = C::J;
+    const int group = slot / QG, ls = slot % QG;
+    const int f = (ls % (J * F)) / J, acc = (ls / (J * F)) * EB + ls % J;  // inverse of Cfg::slot_of
+    const int g = acc >> 2, c = acc & 3;
+    unsigned char* base = reinterpret_cast<unsigned char*>(qtab + ((size_t)group * NG + g) * M * 256) + c * 4 + f * (EB / 8);
+    for (int e = tid; e < M * 256; e += nthreads) {
+        const int m = e >> 8;
+        uint32_t v;
+        if (T)
+            v = filter_field<M>(T[e], sc, of_m[m], m == 0 ? bias : 0u);
+        else
+            v = m == 0 ? (uint32_t)C::FIELD_MAX : 0u;
+        if constexpr (EB == 8)
+            base[(size_t)e * 16] = (unsigned char)v;
+        else
+            *reinterpret_cast<uint16_t*>(base + (size_t)e * 16) = (uint16_t)v;
+    }
+}
+
 template <int M>
 __global__ __launch_bounds__(256) void quantise_kernel(const ScanArgs a) {
     using C = Cfg<M>;
@@ -421,37 +503,19 @@ __global__ __launch_bounds__(256) void quantise_kernel(const ScanArgs a) {
         const int ls = C::slot_of(4 * g + c, f);
         const int slot = group * QG + ls;
         int qq = a.slot_query ? a.slot_query[slot] : (slot < a.n_queries ? slot : -1);
-        float s32 = 0.0f;   // 0: all entries 0, everything passes the filter
-        uint32_t bias = 0;
+        FilterScale fs{0.0f, 0u};
         float mn_m = 0.0f;
         if (qq >= 0 && a.debug_pass != 1) {
             uint64_t key = ~0ull;
             if (a.debug_pass != 2) key = a.thr_key[slot];
-            double B = 0.0;
-#pragma unroll
-            for (int mm = 0; mm < M; ++mm) B += (double)a.lut_min[(size_t)qq * M + mm];
-            const double taup = (double)__uint_as_float((uint32_t)(key >> 32)) * (1.0 + 0x1p-20);
-            const double R = taup - B;
-            if (key != ~0ull && R > 0.0 && R < 1e300) {  // else: no threshold yet (or degenerate), keep everything
-                s32 = (float)((double)C::QT / R * (1.0 - 0x1p-20));
-                bias = (uint32_t)C::BIAS;
-                mn_m = a.lut_min[(size_t)qq * M + m];
-            }
+            fs = filter_scale<M>(key, a.lut_min + (size_t)qq * M);
+            mn_m = a.lut_min[(size_t)qq * M + m];
         } else {
             qq = -1;
         }
-        // entry = fma(T, s32, -off) with off >= min*s32 (rounded up): never above (T - min) * s32
-        const double od = (double)mn_m * (double)s32;
-        float of = (float)od;
-        if ((double)of < od) of = __uint_as_float(__float_as_uint(of) + 1u);  // od >= 0: next float up
-        if constexpr (EB == 8) {
-            // added to T * s32 before v_cvt_pk_u8_f32: bias (m = 0) and half a unit of slack against the
-            // conversion's rounding folded in, rounded DOWN
-            const double sd = (m == 0 ? (double)bias : 0.0) - 0.5 - (double)of;
-            float sf = (float)sd;
-            if ((double)sf > sd) sf = __uint_as_float(__float_as_uint(sf) + (sf > 0.0f ? -1 : 1));  // next float down
-            of = sf;
-        }
+        const float s32 = fs.s32;
+        const uint32_t bias = fs.bias;
+        const float of = filter_offset<M>(fs, mn_m, m);
         s_scale[k] = s32;
         s_off[k] = of;
         s_bias[k] = m == 0 ? bias : 0u;
@@ -1230,8 +1294,11 @@ __global__ __launch_bounds__(kBootThreads, M <= 8 ? 8 : 6) void bootstrap_kernel
     uint32_t* wave_sum = bcast + 2;                                                       // [8]
 
     const int slot = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int q = a.slot_query ? a.slot_query[slot] : slot;
-    if (q < 0) return;
+    const int q = a.slot_query ? a.slot_query[slot] : (slot < a.n_queries ? slot : -1);
+    if (q < 0) {  // padding slot of the last query group: its filter-table fields reject everything
+        if (a.qtab) write_filter_fields<M>(a.qtab, slot, nullptr, 0.0f, nullptr, 0u, tid, kBootThreads);
+        return;
+    }
     if (a.stamps && tid == 0) a.stamps[(size_t)slot * 8 + 6] = __builtin_amdgcn_s_memrealtime();  // 100 MHz, chip-wide
     if (tid == 0) a.cand_count[(size_t)slot * kRegionStride] = 0;  // no carried winners: the scan meets every node again
     {
@@ -1389,6 +1456,23 @@ __global__ __launch_bounds__(kBootThreads, M <= 8 ? 8 : 6) void bootstrap_kernel
     }
     if (tid == 0) a.thr_key[slot] = kth;
     mark(4);
+    if (a.qtab) {
+        // The first filter level's table fields of this slot, straight from the tables in LDS (saves the
+        // quantise launch between bootstrap and scan: it sat on the critical path of a pipelined batch).
+        __shared__ float s_of[M];
+        __shared__ float s_scale;
+        __shared__ uint32_t s_bias;
+        if (tid < M) {
+            const FilterScale fs = filter_scale<M>(kth, a.lut_min + (size_t)q * M);
+            s_of[tid] = filter_offset<M>(fs, a.lut_min[(size_t)q * M + tid], tid);
+            if (tid == 0) {
+                s_scale = fs.s32;
+                s_bias = fs.bias;
+            }
+        }
+        __syncthreads();
+        write_filter_fields<M>(a.qtab, slot, T, s_scale, s_of, s_bias, tid, kBootThreads);
+    }
     if (a.stamps && tid == 0) a.stamps[(size_t)slot * 8 + 7] = __builtin_amdgcn_s_memrealtime();
 }
 
@@ -1403,12 +1487,12 @@ hipError_t launch_bootstrap(const BootArgs& a, int M, int n_slots, hipStream_t s
     const size_t lds = bootstrap_lds_bytes(M, a.cap);
     if (M == 8) {
         static std::atomic<bool> done[64] = {};
-        hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&bootstrap_kernel<8>), 160 * 1024, done);
+        hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&bootstrap_kernel<8>), 128 * 1024, done);  // + a few static words
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(bootstrap_kernel<8>, dim3((unsigned)n_slots), dim3(kBootThreads), lds, stream, a);
     } else if (M == 16) {
         static std::atomic<bool> done[64] = {};
-        hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&bootstrap_kernel<16>), 160 * 1024, done);
+        hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&bootstrap_kernel<16>), 128 * 1024, done);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(bootstrap_kernel<16>, dim3((unsigned)n_slots), dim3(kBootThreads), lds, stream, a);
     } else {
