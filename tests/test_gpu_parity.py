@@ -146,6 +146,38 @@ def test_pipelined_batches_match_synchronous_ones(gpu, oracle, codebook):
             idx.finish()
 
 
+def test_pipelined_batches_on_two_lanes_and_streams(gpu, oracle, codebook):
+    """Pipelined batches alternate between two lanes (workspaces + internal streams): many batches
+    in flight on an index with the bootstrap and the fused first-level tables, a batch larger than the internal
+    2048-query split, a second user stream in the middle (settles what is in flight first), ragged sizes so that
+    every batch has padding slots in its last query group."""
+    import torch
+    from deltapq_amd import synth
+    n, k = 300000, 20
+    tree, payload, _ = make_case(n, seed=151)
+    sizes = (70, 1, 64, 2500, 33, 129, 5)
+    batches = [synth.make_queries(nq, 128, seed=160 + i) for i, nq in enumerate(sizes)]
+    with gpu.DeltaPQIndex.open_memory(payload, n, 8, 256) as idx:
+        idx.set_codebook(codebook)
+        assert idx.info()["bootstrap_bytes"] > 0
+        qd = [torch.from_numpy(q).cuda() for q in batches]
+        other = torch.cuda.Stream()
+        outs = []
+        for i, q in enumerate(qd):
+            if i == 4:
+                other.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(other):
+                    outs.append(idx.query_batch_torch(q, k, wait=False))
+            else:
+                outs.append(idx.query_batch_torch(q, k, wait=False))
+        idx.finish()
+        torch.cuda.synchronize()
+        for q, (ids, dists) in zip(batches, outs):
+            rows = list(range(0, len(q), max(1, len(q) // 6)))
+            assert_parity(ids.cpu().numpy()[rows], dists.cpu().numpy()[rows], oracle_topk(oracle, payload, n, codebook, q[rows], k), n)
+            assert np.all(np.diff(dists.cpu().numpy(), axis=1) >= 0) and ids.min().item() >= 0
+
+
 def test_large_batch_is_split_internally(gpu, oracle, codebook):
     from deltapq_amd import synth
     n = 3000
