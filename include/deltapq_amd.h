@@ -248,13 +248,15 @@ int dpq_query_batch(dpq_index* idx, const float* queries, int nq, int top_k, int
  * overflow check at the end of the batch. */
 int dpq_query_batch_device(dpq_index* idx, const float* d_queries, int nq, int top_k, int32_t* d_ids,
                            float* d_dists, void* hip_stream);
-/* Pipelined variant: enqueues the batch on `hip_stream` and returns at once, so consecutive batches run
- * back to back on the GPU (the call above leaves it idle for the ~15 us between the end of a batch and the
- * next enqueue).  Inputs and outputs must stay valid, and the outputs must not be read, until dpq_finish(idx):
- * it waits for every enqueued batch and answers again, synchronously, any batch in which a query overflowed
- * its candidate buffers.  All batches of one index go to the same stream (they share its workspace); up to
- * 63 may be in flight, the 64th call finishes the earlier ones first.  The synchronous entry points finish
- * pending batches before they start. */
+/* Pipelined variant: enqueues the batch and returns at once.  The batch starts once `hip_stream` has reached the
+ * point of this call (an event is recorded on it) and runs on one of two internal streams with its own workspace,
+ * alternately, so that consecutive batches overlap (a batch's table build runs under the previous batch's scan).
+ * Inputs and outputs belong to the library until dpq_finish(idx): they must stay valid, the inputs must not be
+ * changed and the outputs not read before it returns.  dpq_finish waits for every enqueued batch and answers again,
+ * synchronously, any batch in which a query overflowed its candidate buffers.  A call with a different
+ * `hip_stream` first finishes what is in flight; up to 63 batches may be in flight, the 64th call finishes the
+ * earlier ones first.  The synchronous entry points finish pending batches before they start.
+ * (Environment DPQ_ASYNC_OVERLAP=0: every batch on `hip_stream` itself, one workspace.) */
 int dpq_query_batch_device_async(dpq_index* idx, const float* d_queries, int nq, int top_k, int32_t* d_ids,
                                  float* d_dists, void* hip_stream);
 int dpq_finish(dpq_index* idx);
