@@ -298,7 +298,6 @@ def main():
         for i in range(args.warmup):
             step(i, index)
         sync(index)
-        (index or idx).profile_reset()     # the warm-up steps are not part of the kernel-time figures
         times = []
         for _ in range(max(1, reps)):
             sync(index)
@@ -312,21 +311,22 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return t.cpu().numpy()
 
-    # HIP events bracket the scan launches only in the timed regions (the roofline kernel; an event pair costs
-    # ~4 us of stream time); the other kernels are timed in a short untimed pass afterwards.
-    idx.profile_enable(0 if os.environ.get("DPQ_BENCH_NOPROF") else 2)
-    idx.profile_reset()
+    # The timed regions run without any profiling events.  Kernel times (the roofline's scan time among them) come
+    # from a short pass afterwards: synchronous calls (one batch at a time on the caller's stream: with pipelined
+    # batches on two lanes an event interval would include the wait for the other lane's scan) with HIP events
+    # around every kernel.
+    idx.profile_enable(0)
     times = timed()
-    prof = idx.profile_read()
-    aux_steps = max(1, min(args.steps, 5))
+    aux_steps = max(1, min(args.steps, 8))
     idx.profile_enable(1)
     idx.profile_reset()
     for i in range(aux_steps):
-        step(i)
-    sync()
-    prof_aux = idx.profile_read()
+        idx.query_batch_torch(batches[i % N_BATCHES], k, ids, dists, wait=True)
+    torch.cuda.synchronize(dev)
+    prof = idx.profile_read()
+    prof_aux = prof
     idx.profile_enable(0)
-    total_steps = args.steps * max(1, args.reps)
+    total_steps = aux_steps
 
     replicas = None
     if sharded and not args.no_replicas and wl["whole"]:
@@ -432,9 +432,9 @@ def main():
                 "quantise_ms_per_step": float(all_stats[:, 6].max()) / aux_steps,
                 "filter_survivors_per_query": float(all_stats[:, 8].sum()) / max(1, aux_steps * nq),
                 "candidates_per_query": float(all_stats[:, 9].sum()) / max(1, aux_steps * nq),
-                "event_note": "timed regions: HIP events around the scan launches only; select (incl. bootstrap) / lut / quantise "
-                              "figures from %d untimed steps run afterwards with events around every kernel (each event pair adds "
-                              "~4 us of stream time to them)" % aux_steps,
+                "event_note": "kernel times (scan, select incl. bootstrap, lut, quantise) from %d synchronous steps run after the "
+                              "timed regions with HIP events around every kernel on the launch stream; the timed regions carry no "
+                              "events (pipelined batches overlap on two lanes there)" % aux_steps,
             },
             "parity_checked_queries": parity,
             "index": {"device_bytes_rank0": int(all_stats[0, 3]), "segments_rank0": info["n_segments"],

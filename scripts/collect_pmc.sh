@@ -5,6 +5,8 @@
 #   gpurun -- 'bash scripts/collect_pmc.sh r02_125M --codes 125000000 --data stream'
 set -o pipefail
 TAG=${1:-r02}; shift
+# per-kernel figures want one kernel at a time on the GPU: pipelined batches on one lane
+export DPQ_ASYNC_OVERLAP=${DPQ_ASYNC_OVERLAP:-0}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 OUT=gpurun_out/$TAG
 rm -rf "$OUT" && mkdir -p "$OUT"

@@ -4,6 +4,8 @@
 #   gpurun -- 'bash scripts/collect_sq_pmc.sh r02_sq [bench args]'
 set -o pipefail
 TAG=${1:-sq}; shift
+# per-kernel figures want one kernel at a time on the GPU: pipelined batches on one lane
+export DPQ_ASYNC_OVERLAP=${DPQ_ASYNC_OVERLAP:-0}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 OUT=gpurun_out/$TAG
 rm -rf "$OUT" && mkdir -p "$OUT"

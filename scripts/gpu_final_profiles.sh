@@ -3,6 +3,7 @@
 set -o pipefail
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out/r02final
+echo "start bench default" > gpurun_out/r02final/progress.txt
 timeout -k 10 400 python bench.py --steps 20 --warmup 5 > gpurun_out/r02final/bench_default.json 2> gpurun_out/r02final/bench_default.err; echo "default rc=$?"
 bash scripts/collect_pmc.sh r02_default > gpurun_out/r02final/pmc_default.log 2>&1; echo "pmc default rc=$?"
 bash scripts/collect_pmc.sh r02_125M --codes 125000000 --data stream --check 2 > gpurun_out/r02final/pmc_125M.log 2>&1; echo "pmc 125M rc=$?"

@@ -3,6 +3,8 @@
 set -o pipefail
 TAG=$1; shift
 for kv in "$@"; do export "$kv"; done
+# per-kernel figures want one kernel at a time on the GPU: pipelined batches on one lane
+export DPQ_ASYNC_OVERLAP=${DPQ_ASYNC_OVERLAP:-0}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 OUT=gpurun_out/kstats_$TAG
 rm -rf $OUT && mkdir -p $OUT
