@@ -91,6 +91,7 @@ SYMBOLS = [
     ("dpq_merge_topk_host", ctypes.c_int, [_VP, _VP, ctypes.c_int, ctypes.c_int, ctypes.c_int, _VP, _VP]),
     ("dpq_merge_topk_device", ctypes.c_int,
      [_VP, _VP, ctypes.c_int, ctypes.c_int, ctypes.c_int, _VP, _VP, ctypes.c_int, _VP]),
+    ("dpq_merge_topk_device_packed", ctypes.c_int, [_VP, ctypes.c_int, ctypes.c_int, ctypes.c_int, _VP, _VP, ctypes.c_int, _VP]),
     ("dpq_profile_enable", ctypes.c_int, [_VP, ctypes.c_int]),
     ("dpq_profile_reset", ctypes.c_int, [_VP]),
     ("dpq_profile_read", ctypes.c_int, [_VP, P(Profile)]),

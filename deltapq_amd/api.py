@@ -352,6 +352,21 @@ def merge_topk_torch(ids, dists):
     return oi, od
 
 
+def merge_topk_packed_torch(gathered, k):
+    """Device merge straight from the all-gathered tensor [n_lists][nq][2k] int32 (ids | distance bits)."""
+    import torch
+    lib = _lib.load()
+    assert gathered.is_cuda and gathered.is_contiguous() and gathered.dtype == torch.int32 and gathered.shape[2] == 2 * k
+    n_lists, nq = gathered.shape[0], gathered.shape[1]
+    oi = torch.empty((nq, k), dtype=torch.int32, device=gathered.device)
+    od = torch.empty((nq, k), dtype=torch.float32, device=gathered.device)
+    stream = torch.cuda.current_stream(gathered.device).cuda_stream
+    check(lib.dpq_merge_topk_device_packed(ctypes.c_void_p(gathered.data_ptr()), n_lists, nq, k, ctypes.c_void_p(oi.data_ptr()),
+                                           ctypes.c_void_p(od.data_ptr()), gathered.device.index or 0, ctypes.c_void_p(stream)),
+          "dpq_merge_topk_device_packed")
+    return oi, od
+
+
 # ---------------------------------------------------------------------------
 # Reference-named conveniences (one call per query, like main:328-339).
 # ---------------------------------------------------------------------------

@@ -1531,8 +1531,21 @@ int dpq_merge_topk_device(const int32_t* d_ids, const float* d_dists, int n_list
         return fail(DPQ_ERR_ARG, "bad merge argument");
     if ((int64_t)n_lists * top_k > 16384) return fail(DPQ_ERR_ARG, "n_lists * top_k exceeds 16384");
     DPQ_HIP(hipSetDevice(device));
-    DPQ_HIP(dpq::launch_merge(d_ids, d_dists, n_lists, nq, top_k, d_out_ids, d_out_dists,
+    DPQ_HIP(dpq::launch_merge(d_ids, d_dists, n_lists, nq, top_k, top_k, d_out_ids, d_out_dists,
                               reinterpret_cast<hipStream_t>(hip_stream)));
+    return DPQ_OK;
+    });
+}
+
+int dpq_merge_topk_device_packed(const int32_t* d_packed, int n_lists, int nq, int top_k, int32_t* d_out_ids,
+                                 float* d_out_dists, int device, void* hip_stream) {
+    return guarded([&]() -> int {
+    if (!d_packed || !d_out_ids || !d_out_dists || n_lists < 1 || nq < 0 || top_k < 1)
+        return fail(DPQ_ERR_ARG, "bad merge argument");
+    if ((int64_t)n_lists * top_k > 16384) return fail(DPQ_ERR_ARG, "n_lists * top_k exceeds 16384");
+    DPQ_HIP(hipSetDevice(device));
+    DPQ_HIP(dpq::launch_merge(d_packed, reinterpret_cast<const float*>(d_packed + top_k), n_lists, nq, top_k, 2 * top_k,
+                              d_out_ids, d_out_dists, reinterpret_cast<hipStream_t>(hip_stream)));
     return DPQ_OK;
     });
 }

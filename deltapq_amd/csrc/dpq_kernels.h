@@ -122,8 +122,9 @@ size_t qtab_bytes_per_group(int M);
 int scan_stamp_count();
 hipError_t launch_select(const SelectArgs& a, int M, int n_slots, hipStream_t stream);
 hipError_t launch_bootstrap(const BootArgs& a, int M, int n_slots, hipStream_t stream);
-hipError_t launch_merge(const int32_t* d_ids, const float* d_dists, int n_lists, int nq, int top_k, int32_t* d_out_ids,
-                        float* d_out_dists, hipStream_t stream);
+// row_stride: elements between consecutive (list, query) rows of d_ids / d_dists (top_k, or 2 * top_k for the packed tensor)
+hipError_t launch_merge(const int32_t* d_ids, const float* d_dists, int n_lists, int nq, int top_k, int row_stride,
+                        int32_t* d_out_ids, float* d_out_dists, hipStream_t stream);
 // PQ encoding: codes[n][M] = argmin_k |v_m - c[m][k]|^2 in fp32.
 hipError_t launch_encode_pq(const float* d_vectors, int64_t n, int D, const float* d_codebook, int M, int K, int Ds,
                             uint8_t* d_codes, hipStream_t stream);

@@ -1502,39 +1502,50 @@ hipError_t launch_bootstrap(const BootArgs& a, int M, int n_slots, hipStream_t s
 }
 
 // ---------------------------------------------------------------------------
-// 8e: merge of n_lists partial top-k lists per query.  grid = nq
+// 8e: merge of n_lists partial top-k lists per query.  grid = nq.
+// Every partial list arrives sorted (ascending (distance bits, id) keys, padding rows last) and the lists are
+// disjoint (shards), so a key's place in the merged list is the number of smaller keys: its position in its own
+// list plus, per other list, a binary search.  One barrier; a bitonic sort of n_lists * k keys took 55 of them.
+// List l, query q, rank r: ids[((l * nq + q) * row_stride) + r], dists likewise -- row_stride = top_k for two
+// separate arrays, 2 * top_k for the packed [n_lists][nq][2k] tensor of the all-gather (dists = ids + top_k).
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(kSelectThreads) void merge_kernel(const int32_t* __restrict__ ids,
                                                                 const float* __restrict__ dists, int n_lists, int nq,
-                                                                int top_k, int32_t* __restrict__ out_ids,
+                                                                int top_k, int row_stride, int32_t* __restrict__ out_ids,
                                                                 float* __restrict__ out_dists) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint64_t* v = reinterpret_cast<uint64_t*>(smem);
+    uint64_t* v = reinterpret_cast<uint64_t*>(smem);  // [n_lists][top_k]
     const int q = blockIdx.x, tid = threadIdx.x;
     const int n = n_lists * top_k;
-    int p2 = 1;
-    while (p2 < n) p2 <<= 1;
-    for (int i = tid; i < p2; i += kSelectThreads) {
-        uint64_t key = ~0ull;
-        if (i < n) {
-            const int l = i / top_k, r = i % top_k;
-            const size_t o = ((size_t)l * nq + q) * top_k + r;
-            const int32_t id = ids[o];
-            if (id >= 0) key = make_key(dists[o], (uint32_t)id);
-        }
-        v[i] = key;
+    for (int i = tid; i < n; i += kSelectThreads) {
+        const int l = i / top_k, r = i % top_k;
+        const size_t o = ((size_t)l * nq + q) * row_stride + r;
+        const int32_t id = ids[o];
+        v[i] = id >= 0 ? make_key(dists[o], (uint32_t)id) : ~0ull;
+    }
+    for (int r = tid; r < top_k; r += kSelectThreads) {  // rows the lists cannot fill stay padding
+        out_ids[(size_t)q * top_k + r] = -1;
+        out_dists[(size_t)q * top_k + r] = INFINITY;
     }
     __syncthreads();
-    block_bitonic_sort(v, p2, tid, kSelectThreads);
-    for (int r = tid; r < top_k; r += kSelectThreads) {
-        const uint64_t key = v[r];
-        const size_t o = (size_t)q * top_k + r;
-        if (key != ~0ull) {
-            out_ids[o] = (int32_t)(key & 0xffffffffu);
-            out_dists[o] = __uint_as_float((uint32_t)(key >> 32));
-        } else {
-            out_ids[o] = -1;
-            out_dists[o] = INFINITY;
+    for (int i = tid; i < n; i += kSelectThreads) {
+        const uint64_t key = v[i];
+        if (key == ~0ull) continue;
+        const int own = i / top_k;
+        int rank = i % top_k;
+        for (int l = 0; l < n_lists && rank < top_k; ++l) {
+            if (l == own) continue;
+            const uint64_t* lst = v + (size_t)l * top_k;
+            int lo = 0, hi = top_k;  // first position whose key is not below `key` (padding = ~0 sorts last)
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (lst[mid] < key) lo = mid + 1; else hi = mid;
+            }
+            rank += lo;
+        }
+        if (rank < top_k) {
+            out_ids[(size_t)q * top_k + rank] = (int32_t)(key & 0xffffffffu);
+            out_dists[(size_t)q * top_k + rank] = __uint_as_float((uint32_t)(key >> 32));
         }
     }
 }
@@ -1705,18 +1716,16 @@ hipError_t launch_select(const SelectArgs& a, int M, int n_slots, hipStream_t st
     return hipErrorInvalidValue;
 }
 
-hipError_t launch_merge(const int32_t* d_ids, const float* d_dists, int n_lists, int nq, int top_k,
+hipError_t launch_merge(const int32_t* d_ids, const float* d_dists, int n_lists, int nq, int top_k, int row_stride,
                         int32_t* d_out_ids, float* d_out_dists, hipStream_t stream) {
     if (nq <= 0) return hipSuccess;
-    int n = n_lists * top_k, p2 = 1;
-    while (p2 < n) p2 <<= 1;
-    const size_t lds = (size_t)p2 * sizeof(uint64_t);
-    if (lds > 128 * 1024) return hipErrorInvalidValue;
+    const size_t lds = (size_t)n_lists * top_k * sizeof(uint64_t);
+    if (lds > 128 * 1024 || row_stride < top_k) return hipErrorInvalidValue;
     static std::atomic<bool> done[64] = {};
     hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&merge_kernel), 128 * 1024, done);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(merge_kernel, dim3((unsigned)nq), dim3(kSelectThreads), lds, stream, d_ids, d_dists, n_lists,
-                       nq, top_k, d_out_ids, d_out_dists);
+                       nq, top_k, row_stride, d_out_ids, d_out_dists);
     return hipGetLastError();
 }
 

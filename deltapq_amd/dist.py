@@ -54,7 +54,7 @@ def gather_and_merge(ids, dists, group=None):
         # latency-bound: nq * k * 8 B per rank)
         gathered = torch.empty((world, nq, 2 * k), dtype=torch.int32, device=ids.device)
         dist.all_gather_into_tensor(gathered, pack_lists(ids, dists), group=group)
-        return api.merge_topk_torch(*unpack_lists(gathered, k))
+        return api.merge_topk_packed_torch(gathered, k)     # the merge kernel reads the packed rows as they are
     if ids.is_cuda:
         # rehearsal mode (gloo with device tensors, e.g. several ranks sharing one GPU):
         # exchange through host memory, merge on the device as the RCCL path does
@@ -62,7 +62,8 @@ def gather_and_merge(ids, dists, group=None):
         h_dists = torch.empty((world, nq, k), dtype=dists.dtype)
         dist.all_gather(list(h_ids.unbind(0)), ids.cpu().contiguous(), group=group)
         dist.all_gather(list(h_dists.unbind(0)), dists.cpu().contiguous(), group=group)
-        return api.merge_topk_torch(h_ids.to(ids.device), h_dists.to(dists.device))
+        packed = torch.cat((h_ids, h_dists.view(torch.int32)), dim=2).contiguous().to(ids.device)   # the RCCL path's layout
+        return api.merge_topk_packed_torch(packed, k)
     g_ids = torch.empty((world, nq, k), dtype=ids.dtype)
     g_dists = torch.empty((world, nq, k), dtype=dists.dtype)
     dist.all_gather(list(g_ids.unbind(0)), ids.contiguous(), group=group)

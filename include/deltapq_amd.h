@@ -267,6 +267,10 @@ int dpq_merge_topk_host(const int32_t* ids, const float* dists, int n_lists, int
                         float* out_dists);
 int dpq_merge_topk_device(const int32_t* d_ids, const float* d_dists, int n_lists, int nq, int top_k,
                           int32_t* d_out_ids, float* d_out_dists, int device, void* hip_stream);
+/* The same on the tensor the one all-gather of the path delivers: d_packed[n_lists][nq][2 * top_k] int32, a row =
+ * top_k ids followed by the bit patterns of the top_k fp32 distances (what every rank contributes in ONE collective). */
+int dpq_merge_topk_device_packed(const int32_t* d_packed, int n_lists, int nq, int top_k, int32_t* d_out_ids,
+                                 float* d_out_dists, int device, void* hip_stream);
 
 /* ---- measurement -------------------------------------------------------- */
 int dpq_profile_enable(dpq_index* idx, int on);  /* 0 off, 1 every kernel, 2 scan launches only (less event overhead) */
