@@ -262,21 +262,27 @@ def main():
     ids = torch.empty((nq, k), dtype=torch.int32, device=dev)
     dists = torch.empty((nq, k), dtype=torch.float32, device=dev)
 
-    # Batches that no collective follows are pipelined (dpq_query_batch_device_async): a step enqueues its
-    # batch, sync() settles them all (dpq_finish: waits, checks the overflow words, reruns if needed).
+    # Batches that no collective follows are pipelined (dpq_query_batch_device_async: two lanes); sync() settles them
+    # (dpq_finish: waits, checks the overflow words, reruns if needed).  Index shards consume the partial lists on
+    # the device in stream order (select -> pack -> all-gather -> merge: dpq_query_batch_device_ordered), so a step
+    # needs no host round trip either; if dpq_finish had to answer a batch again (a query overflowed its candidate
+    # buffers: the merged list of that step was built from an incomplete partial list) the region is repeated with
+    # one synchronous call per step.
     sharded = world > 1 and not by_query
     pipelined = not sharded
+    state = {"ordered": sharded, "reruns": 0}
 
     def step(i, index=None):
-        (index or idx).query_batch_torch(batches[i % N_BATCHES], k, ids, dists, wait=not pipelined)
         if pipelined:
+            (index or idx).query_batch_torch(batches[i % N_BATCHES], k, ids, dists, wait=False)
             return ids, dists   # this rank's batch; complete after sync()
         # index shards: the path's one exchange step -- all-gather of the partial lists
         # (nq * k * 8 B per rank) over RCCL, then the device merge
+        (index or idx).query_batch_torch(batches[i % N_BATCHES], k, ids, dists, wait=not state["ordered"], ordered=state["ordered"])
         return dpq_dist.gather_and_merge(ids, dists)
 
     def sync(index=None):
-        (index or idx).finish()
+        state["reruns"] += (index or idx).finish()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(dev)
@@ -316,7 +322,14 @@ def main():
     # batches on two lanes an event interval would include the wait for the other lane's scan) with HIP events
     # around every kernel.
     idx.profile_enable(0)
+    state["reruns"] = 0
     times = timed()
+    if sharded:   # did any rank answer a batch again?  Then its merged lists were stale: repeat with synchronous steps
+        flag = torch.tensor([state["reruns"]], dtype=torch.int64, device=torch.device("cpu") if cpu_coll else dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        if int(flag.item()) > 0:
+            state["ordered"] = False
+            times = timed()
     aux_steps = max(1, min(args.steps, 8))
     idx.profile_enable(1)
     idx.profile_reset()
@@ -334,6 +347,7 @@ def main():
         pipelined = True
         rt = timed(ridx, reps=3)
         pipelined = False
+        ridx.finish()
         replicas = {"note": "same GPUs, every rank holds the whole index and answers its own %d-query batch; no collective" % nq,
                     "value": world * nq * args.steps / float(np.median(rt)), "unit": "queries/s", "scaling": "weak",
                     "ms_per_step": 1e3 * float(np.median(rt)) / args.steps}
@@ -389,6 +403,9 @@ def main():
                              if by_query else "dfs-range index shards x%d, one %d-query batch, one all-gather + merge" % (world, nq)),
                 "global_queries_per_step": global_q,
                 "query_batches_rotated": N_BATCHES,
+                "step_pipelining": "two lanes (dpq_query_batch_device_async)" if pipelined or not sharded else
+                                   ("stream-ordered steps (dpq_query_batch_device_ordered), no host round trip; no batch had to be answered again"
+                                    if state["ordered"] else "one synchronous call per step (a batch overflowed in the stream-ordered run)"),
                 "queries_per_decode_pass": QG,
                 "threshold_bootstrap": "multi-index, stride %d, %.1f MB" % (info["bootstrap_stride"], info["bootstrap_bytes"] / 1e6)
                                        if info["bootstrap_bytes"] else "off (spread-sample cascade)",

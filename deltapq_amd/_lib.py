@@ -87,6 +87,8 @@ SYMBOLS = [
     ("dpq_query_batch", ctypes.c_int, [_VP, _VP, ctypes.c_int, ctypes.c_int, _VP, _VP]),
     ("dpq_query_batch_device", ctypes.c_int, [_VP, _VP, ctypes.c_int, ctypes.c_int, _VP, _VP, _VP]),
     ("dpq_query_batch_device_async", ctypes.c_int, [_VP, _VP, ctypes.c_int, ctypes.c_int, _VP, _VP, _VP]),
+    ("dpq_query_batch_device_ordered", ctypes.c_int, [_VP, _VP, ctypes.c_int, ctypes.c_int, _VP, _VP, _VP]),
+    ("dpq_finish_count", ctypes.c_int, [_VP, P(c_i32)]),
     ("dpq_finish", ctypes.c_int, [_VP]),
     ("dpq_merge_topk_host", ctypes.c_int, [_VP, _VP, ctypes.c_int, ctypes.c_int, ctypes.c_int, _VP, _VP]),
     ("dpq_merge_topk_device", ctypes.c_int,

@@ -273,10 +273,12 @@ class DeltaPQIndex:
               "dpq_query_batch")
         return ids, dists
 
-    def query_batch_torch(self, queries, top_k, out_ids=None, out_dists=None, wait=True):
+    def query_batch_torch(self, queries, top_k, out_ids=None, out_dists=None, wait=True, ordered=False):
         """Device tensors in/out on torch's current stream (no host copies).  wait=False
         (dpq_query_batch_device_async) only enqueues the batch: keep the tensors alive and do
-        not read the results before finish()."""
+        not read the results before finish().  wait=False, ordered=True (dpq_query_batch_device_ordered):
+        enqueued on the current stream itself, later work on that stream sees the result unless
+        finish() reports a rerun."""
         import torch
         assert queries.is_cuda and queries.dtype == torch.float32 and queries.is_contiguous()
         nq = queries.shape[0]
@@ -285,15 +287,19 @@ class DeltaPQIndex:
         if out_dists is None:
             out_dists = torch.empty((nq, top_k), dtype=torch.float32, device=queries.device)
         stream = torch.cuda.current_stream(queries.device).cuda_stream
-        fn = self._lib.dpq_query_batch_device if wait else self._lib.dpq_query_batch_device_async
+        fn = self._lib.dpq_query_batch_device if wait else (
+            self._lib.dpq_query_batch_device_ordered if ordered else self._lib.dpq_query_batch_device_async)
         check(fn(self._h, ctypes.c_void_p(queries.data_ptr()), nq, top_k, ctypes.c_void_p(out_ids.data_ptr()),
                  ctypes.c_void_p(out_dists.data_ptr()), ctypes.c_void_p(stream)),
               "dpq_query_batch_device" if wait else "dpq_query_batch_device_async")
         return out_ids, out_dists
 
     def finish(self):
-        """Wait for the batches enqueued with wait=False and settle their overflow checks (dpq_finish)."""
-        check(self._lib.dpq_finish(self._h), "dpq_finish")
+        """Wait for the batches enqueued with wait=False and settle their overflow checks (dpq_finish).
+        Returns the number of batches that had to be answered again."""
+        n = _lib.c_i32()
+        check(self._lib.dpq_finish_count(self._h, n), "dpq_finish_count")
+        return n.value
 
     def profile_enable(self, on=True):
         check(self._lib.dpq_profile_enable(self._h, int(on)), "dpq_profile_enable")

@@ -139,6 +139,7 @@ struct dpq_index {
     hipStream_t lane_stream[2] = {nullptr, nullptr};
     hipEvent_t lane_ready[2] = {nullptr, nullptr};   // recorded on the caller's stream: the batch's inputs are there
     uint64_t async_seq = 0;
+    int64_t finish_reruns = 0;       // batches dpq_finish had to answer again (a query overflowed its candidate buffers)
     std::vector<Pending> pending;
     // staging for the host-pointer entry point
     float* d_q_stage = nullptr;
@@ -1374,6 +1375,7 @@ int dpq_finish(dpq_index* x) {
     for (const auto& p : todo) {
         if (*reinterpret_cast<volatile uint32_t*>(x->h_any + p.flag_slot) == 0) continue;
         // a query of this batch dropped candidates: answer the batch again, synchronously (it reruns what overflows)
+        x->finish_reruns++;
         int rc = run_batch(x, p.d_queries, p.nq, p.top_k, p.d_ids, p.d_dists, p.stream);
         if (rc) return rc;
     }
@@ -1381,9 +1383,35 @@ int dpq_finish(dpq_index* x) {
     });
 }
 
+namespace {
+int enqueue_async(dpq_index* x, const float* d_queries, int nq, int top_k, int32_t* d_ids, float* d_dists, void* hip_stream,
+                  bool allow_lanes);
+}
+
 int dpq_query_batch_device_async(dpq_index* x, const float* d_queries, int nq, int top_k, int32_t* d_ids,
                                  float* d_dists, void* hip_stream) {
+    return guarded([&]() -> int { return enqueue_async(x, d_queries, nq, top_k, d_ids, d_dists, hip_stream, true); });
+}
+
+int dpq_query_batch_device_ordered(dpq_index* x, const float* d_queries, int nq, int top_k, int32_t* d_ids,
+                                   float* d_dists, void* hip_stream) {
+    return guarded([&]() -> int { return enqueue_async(x, d_queries, nq, top_k, d_ids, d_dists, hip_stream, false); });
+}
+
+int dpq_finish_count(dpq_index* x, int32_t* rerun_batches) {
     return guarded([&]() -> int {
+    if (!x) return fail(DPQ_ERR_ARG, "NULL index");
+    const int64_t before = x->finish_reruns;
+    int rc = dpq_finish(x);
+    if (rerun_batches) *rerun_batches = (int32_t)(x->finish_reruns - before);
+    return rc;
+    });
+}
+
+namespace {
+int enqueue_async(dpq_index* x, const float* d_queries, int nq, int top_k, int32_t* d_ids, float* d_dists, void* hip_stream,
+                  bool allow_lanes) {
+    {
     int rc = check_batch_args(x, d_queries, nq, top_k, d_ids, d_dists);
     if (rc || nq == 0) return rc;
     DPQ_HIP(hipSetDevice(x->device));
@@ -1391,7 +1419,12 @@ int dpq_query_batch_device_async(dpq_index* x, const float* d_queries, int nq, i
     // Batches in flight are ordered by the caller's stream.  A batch for another stream first settles what is in flight.
     if (!x->pending.empty() && x->pending.back().user_stream != user && (rc = dpq_finish(x))) return rc;
     // DPQ_ASYNC_OVERLAP=0: every batch on the caller's stream with one workspace (round 1's behaviour)
-    static const bool overlap = !(getenv("DPQ_ASYNC_OVERLAP") && atoi(getenv("DPQ_ASYNC_OVERLAP")) == 0);
+    static const bool overlap_env = !(getenv("DPQ_ASYNC_OVERLAP") && atoi(getenv("DPQ_ASYNC_OVERLAP")) == 0);
+    const bool overlap = overlap_env && allow_lanes;
+    // a stream-ordered batch uses the active workspace on the caller's stream: batches still running on a lane's
+    // own stream are settled first (a laned batch after ordered ones is safe: it waits for the caller's stream)
+    if (!overlap && !x->pending.empty() && x->pending.back().stream != x->pending.back().user_stream && (rc = dpq_finish(x)))
+        return rc;
     const int D = x->M * x->Ds;
     for (int base = 0; base < nq; base += kMaxBatchQueries) {
         const int n = std::min(kMaxBatchQueries, nq - base);
@@ -1422,8 +1455,9 @@ int dpq_query_batch_device_async(dpq_index* x, const float* d_queries, int nq, i
         x->prof_acc.queries += nq;
     }
     return DPQ_OK;
-    });
+    }
 }
+}  // namespace
 
 int dpq_query_batch_device(dpq_index* x, const float* d_queries, int nq, int top_k, int32_t* d_ids, float* d_dists,
                            void* hip_stream) {

@@ -272,6 +272,15 @@ int dpq_merge_topk_device(const int32_t* d_ids, const float* d_dists, int n_list
 int dpq_merge_topk_device_packed(const int32_t* d_packed, int n_lists, int nq, int top_k, int32_t* d_out_ids,
                                  float* d_out_dists, int device, void* hip_stream);
 
+/* Stream-ordered variant for callers that consume the result ON THE DEVICE, in stream order (the sharded driver:
+ * select -> pack -> all-gather -> merge without a host round trip per batch): the batch is enqueued on `hip_stream`
+ * itself; work enqueued on that stream afterwards sees the result -- PROVIDED no query of the batch overflowed its
+ * candidate buffers, which only dpq_finish can tell (it answers such a batch again; whatever consumed the first
+ * answer must then be redone).  dpq_finish_count reports how many batches that happened to. */
+int dpq_query_batch_device_ordered(dpq_index* idx, const float* d_queries, int nq, int top_k, int32_t* d_ids,
+                                   float* d_dists, void* hip_stream);
+int dpq_finish_count(dpq_index* idx, int32_t* rerun_batches);
+
 /* ---- measurement -------------------------------------------------------- */
 int dpq_profile_enable(dpq_index* idx, int on);  /* 0 off, 1 every kernel, 2 scan launches only (less event overhead) */
 int dpq_profile_reset(dpq_index* idx);

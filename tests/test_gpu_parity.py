@@ -178,6 +178,34 @@ def test_pipelined_batches_on_two_lanes_and_streams(gpu, oracle, codebook):
             assert np.all(np.diff(dists.cpu().numpy(), axis=1) >= 0) and ids.min().item() >= 0
 
 
+def test_stream_ordered_batches_feed_device_consumers(gpu, oracle, codebook):
+    """dpq_query_batch_device_ordered: the result is consumed on the device in stream order (here: copied by a torch
+    op enqueued right behind it, as the sharded driver's pack + all-gather are), no host round trip; finish() reports
+    how many batches had to be answered again (none with the default buffers, every one with tiny buffers)."""
+    import torch
+    from deltapq_amd import synth
+    n, k = 200000, 30
+    tree, payload, _ = make_case(n, seed=171)
+    batches = [synth.make_queries(nq, 128, seed=180 + i) for i, nq in enumerate((90, 64, 200))]
+    for kw, expect_reruns in (({}, False), ({"cand_capacity": 64, "bootstrap": -1}, True)):
+        with gpu.DeltaPQIndex.open_memory(payload, n, 8, 256, **kw) as idx:
+            idx.set_codebook(codebook)
+            ids = torch.empty((200, k), dtype=torch.int32, device="cuda")
+            dists = torch.empty((200, k), dtype=torch.float32, device="cuda")
+            copies = []
+            for q in batches:
+                qd = torch.from_numpy(q).cuda()
+                idx.query_batch_torch(qd, k, ids[:len(q)], dists[:len(q)], wait=False, ordered=True)
+                copies.append((qd, ids[:len(q)].clone(), dists[:len(q)].clone()))     # consumers in stream order; buffers reused
+            reruns = idx.finish()
+            torch.cuda.synchronize()
+            assert (reruns > 0) == expect_reruns
+            if not expect_reruns:
+                for q, (_, ci, cd) in zip(batches, copies):
+                    rows = list(range(0, len(q), 17))
+                    assert_parity(ci.cpu().numpy()[rows], cd.cpu().numpy()[rows], oracle_topk(oracle, payload, n, codebook, q[rows], k), n)
+
+
 def test_large_batch_is_split_internally(gpu, oracle, codebook):
     from deltapq_amd import synth
     n = 3000
