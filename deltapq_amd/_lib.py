@@ -7,7 +7,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libdeltapq_amd.so")
+LIB_PATH = os.environ.get("DPQ_LIB_PATH") or os.path.join(_HERE, "csrc", "libdeltapq_amd.so")   # DPQ_LIB_PATH: developer A/B builds
 
 c_i32, c_i64, c_f32 = ctypes.c_int32, ctypes.c_int64, ctypes.c_float
 P = ctypes.POINTER

@@ -165,6 +165,9 @@ struct Cfg {
     static constexpr int QG = NA * F;                 // queries per scan workgroup: 64 (M = 8), 16 (M = 16)
     static constexpr int J = NA < EB ? NA : EB;       // accumulator dwords folded into one survivor-mask dword
     static constexpr int MD = (NA + EB - 1) / EB;     // survivor-mask dwords per lane
+    // 8-bit geometry re-swept on the GPU with bootstrap thresholds (QT/SAT -> exact checks per query, scan ms per
+    // 1000 queries): 32/20 5644 0.198, 40/21 3848 0.178, 48/22 3004 0.169, 56/23 2585 0.165, 64/24 2413 0.163,
+    // 80/26 2474 0.164, 90/26 3129 0.170, 100/27 3756 0.178, 120/30 4789 0.189 -- saturation costs more than resolution
     static constexpr int QT = M <= 8 ? 80 : 3700;     // filter units that span (tau - sum of minima)
     static constexpr int SAT = M <= 8 ? 26 : 2279;    // entry saturation
     // added to every m = 0 entry: field sum >= 2^(EB-1) (its top bit) <=> sum of entries > QT + 1
