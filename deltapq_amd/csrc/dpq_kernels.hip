@@ -6,35 +6,41 @@
 //
 //   lut_build_kernel        a3: T[m][k] = sum_d (c[m][k][d] - q[m*Ds+d])^2 with the
 //                           reference's mixed fp32/fp64 arithmetic (h:2841-2849).
+//   bootstrap_kernel        the first threshold of a query (shards >= 64 K nodes): the nodes of
+//                           the query's best cells of an inverted multi-index over sub-space
+//                           pairs, evaluated in fp32; an upper bound of the k-th key; also writes
+//                           the slot's fields of the first filter level's tables.
+//   quantise_kernel         conservative 8-bit (16-bit at M = 16) lower-bound tables of a query
+//                           group for one filter level, once per group (later levels, reruns).
 //   scan_kernel             a5 + most of a6: delta decode + ADC filter + exact check.
-//                           One wavefront = one 64-node chunk per step; child codes
-//                           are rebuilt from parent + packed deltas by pointer jumping
-//                           over ds_bpermute; lower-bound distances are LDS table
-//                           gathers (a lookup workload: no MFMA).  A workgroup keeps
-//                           the filter tables of 64 queries in LDS (16 at M = 16) and
-//                           decodes every chunk once for all of them.  What the filter
-//                           lets through is queued per wavefront and checked exactly
-//                           (the reference's distance, whole (distance, id) keys)
-//                           against the query's threshold key; what passes is a
-//                           candidate key in the workgroup's own region of the
-//                           query's buffer (no global atomics).
-//   decode_segments_kernel  the same decode, writing plain codes (cascade level 0
-//                           is query independent).
-//   select_kernel           the rest of a6: level 0 evaluated exactly, later levels'
-//                           candidate regions gathered; k-th smallest (distance, id)
-//                           key = next threshold, winners carried to the next level;
-//                           on the last level the sorted top-k.
+//                           One wavefront = one 64-node chunk per step, three chunks in flight
+//                           (software pipeline over the decode's two global round trips); child
+//                           codes are rebuilt from parent + packed deltas by pointer jumping over
+//                           ds_bpermute along parent lanes resolved at load; lower-bound
+//                           distances are LDS table gathers (a lookup workload: no MFMA).  A
+//                           workgroup keeps the filter tables of 64 queries in LDS (16 at
+//                           M = 16) and decodes every chunk once for all of them.  Nodes the
+//                           filter lets through for some query are queued per wavefront and
+//                           checked exactly (the reference's distance, whole (distance, id)
+//                           keys) against the query's threshold key; what passes is a candidate
+//                           key in the workgroup's own region of the query's buffer (no global
+//                           atomics).
+//   decode_segments_kernel  the same decode, writing plain codes (small shards: cascade level 0
+//                           is a query-independent spread sample).
+//   select_kernel           the rest of a6: candidate regions gathered; k-th smallest
+//                           (distance, id) key = next threshold, winners carried to the next
+//                           level; on the last level the sorted top-k.
 //   merge_kernel            8e: merge of per-shard partial top-k lists.
 //
 // Top-k strategy (replaces the sequential size-k max-heap, h:2851-2853,
-// 2909-2914): a progressive threshold cascade.  Segments are visited in a
-// low-discrepancy order, every segment exactly once; level l keeps the nodes
-// whose key is <= the k-th best key of everything seen before, which is the key
-// of a real node and therefore a valid upper bound of the final k-th key.  The
+// 2909-2914): thresholds that are valid upper bounds of the final k-th key.
+// The first one comes from the bootstrap (or, on small shards, from a spread
+// sample evaluated exactly); filter levels then visit the segments in a
+// low-discrepancy order, every segment exactly once, and keep the nodes whose
+// key is <= the current threshold; a level's k-th best key tightens it.  The
 // in-scan filter is a CONSERVATIVE LOWER BOUND of the distance in 8-bit fixed
-// point (16-bit at M = 16; tables quantised per query in the scan prologue,
-// scaled to its threshold, rounded down, saturated), so it never drops a node
-// the exact rule would keep.
+// point (16-bit at M = 16; scaled to the query's threshold, rounded down,
+// saturated), so it never drops a node the exact rule would keep.
 #include "dpq_kernels.h"
 
 #include <atomic>
