@@ -99,6 +99,7 @@ struct dpq_index {
     bool boot = false;
     int boot_classes = 0;
     unsigned long long* d_boot_stamps = nullptr;  // developer diagnostics (dpq_debug_boot_stamps)
+    uint8_t* d_nbr = nullptr;        // [8][256][256] centroid neighbour lists of the bootstrap's sub-spaces (dpq_set_codebook)
     float* d_codebook = nullptr;
     // workspace, sized for ws_slots padded queries and ws_cap candidates each
     int ws_slots = 0, ws_cap = 0;
@@ -488,6 +489,8 @@ int run_batch(dpq_index* x, const float* d_queries, int nq, int top_k, int32_t* 
             static const int cap_env = getenv("DPQ_BOOT_CAP") ? atoi(getenv("DPQ_BOOT_CAP")) : 0;
             dpq::BootArgs ba{};
             ba.cell_start = x->d_mi_cell;
+            static const bool full_sort = getenv("DPQ_BOOT_FULLSORT") && atoi(getenv("DPQ_BOOT_FULLSORT")) != 0;  // developer A/B
+            ba.nbr = full_sort ? nullptr : x->d_nbr;
             ba.n_classes = x->boot_classes;
             ba.mi_code = x->d_mi_code;
             ba.mi_id = x->d_mi_id;
@@ -1285,6 +1288,36 @@ int dpq_set_codebook(dpq_index* x, const float* codewords, int Ds) {
     DPQ_HIP(hipMemcpy(x->d_codebook, codewords, n * sizeof(float), hipMemcpyHostToDevice));
     x->Ds = Ds;
     x->info.Ds = Ds;
+    if (x->boot) {
+        // neighbour lists of the bootstrap's 8 sort slots (slot s: sub-space 2 (s / 2) (M / 8) + (s & 1)): for every
+        // centroid all centroids of its sub-space, nearest first (ties by index; centroids beyond K last)
+        std::vector<uint8_t> nbr((size_t)8 * 256 * 256);
+        std::vector<std::pair<double, int>> row(256);
+        for (int sl = 0; sl < 8; ++sl) {
+            const int sub = 2 * (sl >> 1) * (x->M / 8) + (sl & 1);
+            const float* cw = codewords + (size_t)sub * x->K * Ds;
+            for (int c = 0; c < 256; ++c) {
+                for (int o = 0; o < 256; ++o) {
+                    double d2 = 1e300;  // beyond K: last
+                    if (c < x->K && o < x->K) {
+                        d2 = 0;
+                        for (int d = 0; d < Ds; ++d) {
+                            const double df = (double)cw[(size_t)c * Ds + d] - (double)cw[(size_t)o * Ds + d];
+                            d2 += df * df;
+                        }
+                    }
+                    row[(size_t)o] = {d2, o};
+                }
+                std::sort(row.begin(), row.end());
+                for (int o = 0; o < 256; ++o) nbr[((size_t)sl * 256 + c) * 256 + o] = (uint8_t)row[(size_t)o].second;
+            }
+        }
+        hipFree(x->d_nbr);
+        x->d_nbr = nullptr;
+        rc = dev_alloc(&x->d_nbr, nbr.size());
+        if (rc) return rc;
+        DPQ_HIP(hipMemcpy(x->d_nbr, nbr.data(), nbr.size(), hipMemcpyHostToDevice));
+    }
     return DPQ_OK;
     });
 }
@@ -1326,6 +1359,7 @@ int dpq_close(dpq_index* x) {
     hipFree(x->d_raw);
     hipFree(x->d_seg_off);
     hipFree(x->d_boot_stamps);
+    hipFree(x->d_nbr);
     hipFree(x->d_mi_cell);
     hipFree(x->d_mi_code);
     hipFree(x->d_mi_id);

@@ -87,6 +87,7 @@ struct SelectArgs {
 
 // Threshold bootstrap from the inverted multi-index (see bootstrap_kernel).
 struct BootArgs {
+    const uint8_t* nbr;            // [8 sort slots][256][256]: per centroid of the slot's sub-space, all centroids nearest first
     const uint32_t* cell_start;    // [n_classes][65537] absolute entry positions
     int32_t n_classes;             // 4 (sub-space pairs 0/1 .. 6/7) or 1 (pair 0/1)
     const uint32_t* mi_code;       // [entries][M / 4]

@@ -1319,7 +1319,42 @@ __global__ __launch_bounds__(kBootThreads, M <= 8 ? 8 : 6) void bootstrap_kernel
         if (a.stamps && tid == 0) a.stamps[(size_t)slot * 8 + i] = __builtin_amdgcn_s_memtime();
     };
     mark(0);
-    {   // Rank the centroids of the 2 * kBootPairs sub-spaces the classes are indexed by: bitonic sorts of 256
+    if (a.nbr) {
+        // Visiting order of the centroids of the 2 * kBootPairs sub-spaces the classes are indexed by: wavefront s
+        // serves sort slot s (sub-space `which` = s & 1 of pair s >> 1).  Sorting all 256 table entries of the 8
+        // sub-spaces cost 9 us per block; the first rounds only ask for the ~14 best, which lie among the
+        // neighbours of the nearest centroid: find it (wave arg-min), take ITS 64 nearest centroids (a table built at
+        // dpq_set_codebook), sort those 64 exactly by the query's table row (one key per lane, 21 shuffle stages),
+        // and let the other 192 follow in neighbour order.  Any order gives a valid threshold; this one gives
+        // 11 % more candidates than the exact order (scripts/sim_bootstrap3.py) for a sixth of the work.
+        const int sl = wave;  // kBootThreads / 64 == 2 * kBootPairs
+        const int sub = 2 * (sl >> 1) * (M / 8) + (sl & 1);
+        const float* row = T + sub * 256;
+        uint32_t best = 0xffffffffu;  // (entry bits with the low 8 mantissa bits cleared) | centroid: unique keys
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            best = min(best, (__float_as_uint(row[lane + 64 * j]) & 0xffffff00u) | (uint32_t)(lane + 64 * j));
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) best = min(best, (uint32_t)__shfl_xor((int)best, off, 64));
+        const uint8_t* nb = a.nbr + ((size_t)sl * 256 + (best & 0xffu)) * 256;  // its neighbours, nearest first
+        uint32_t cand[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) cand[j] = nb[lane + 64 * j];
+        uint32_t key = (__float_as_uint(row[cand[0]]) & 0xffffff00u) | cand[0];
+#pragma unroll
+        for (int k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                const uint32_t other = (uint32_t)__shfl_xor((int)key, j, 64);
+                const bool take_min = ((lane & k) == 0) == ((lane & j) == 0);
+                key = take_min ? min(key, other) : max(key, other);
+            }
+        }
+        ord[sl * 256 + lane] = (uint8_t)(key & 0xffu);
+#pragma unroll
+        for (int j = 1; j < 4; ++j) ord[sl * 256 + lane + 64 * j] = (uint8_t)cand[j];
+    } else {
+        // Exact order (no neighbour table): bitonic sorts of 256
         // keys, one position per thread and four sorts per thread (threads 0..255: sort slots 0..3, 256..511:
         // slots 4..7; slot s = sub-space `which` = s & 1 of pair s >> 1).  The order only steers which cells are
         // visited first (any order gives a valid threshold), so the low 8 mantissa bits make room for the
