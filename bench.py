@@ -353,7 +353,7 @@ def main():
                     "ms_per_step": 1e3 * float(np.median(rt)) / args.steps}
         ridx.close()
 
-    QG = 64 if args.m <= 8 else 16
+    QG = 64 if args.m <= 8 else 32   # queries served by one decode pass (8-bit filter entries: 128 KB of LDS tables)
     groups = (nq + QG - 1) // QG
     S = 64 * info["chunks_per_segment"]
     lds_bytes_step = float(info["n_segments"]) * S * groups * (4 if args.m <= 8 else 2) * args.m * 16   # NG * M * 16 B per node and group
@@ -425,11 +425,11 @@ def main():
                 "frac": lds_gbps / (LDS_PEAK_GBPS * world),
                 "traffic": traffic,
                 "definition": "achieved = LDS bytes of the ADC table gathers the scan launches issue (per decoded node and "
-                              "64-query group: M x 4 ds_read_b128 = %d B, i.e. %d B per (code, query) pair, padding slots "
+                              "%d-query group: M x %d ds_read_b128 = %d B, i.e. %d B per (code, query) pair, padding slots "
                               "included) / scan-kernel time (HIP events on the launch stream); peak = 256 CUs x 256 B/clk x "
                               "2.4 GHz.  The scan is a gather/lookup kernel bound by the LDS array (bank-conflict replays and the "
                               "decode's ds_bpermute traffic come on top of the counted bytes), not by HBM: see `hbm`."
-                              % ((4 if args.m <= 8 else 2) * args.m * 16, args.m if args.m <= 8 else 2 * args.m),
+                              % (QG, 4 if args.m <= 8 else 2, (4 if args.m <= 8 else 2) * args.m * 16, args.m),
                 "lds_gather_bytes_per_step": lds_total,
                 "hbm": None if traffic is None else {
                     "achieved": traffic / ((pmc_launch_ms or avg_launch_ms) * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",

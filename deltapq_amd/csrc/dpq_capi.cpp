@@ -497,10 +497,15 @@ int run_batch(dpq_index* x, const float* d_queries, int nq, int top_k, int32_t* 
             ba.lut32 = x->d_lut32;
             ba.slot_query = nullptr;
             ba.top_k = top_k;
-            // 4-byte keys: up to 6144 of them keep the block at 40 KB of LDS (four blocks per CU).  Measured at top-100
-            // (scripts/gpu_boot_ab.sh): 3072 / 4096 / 6144 nodes -> 727 / 559 / 404 candidates per query and the same
-            // step time within 1.5 % (what the scan saves the bootstrap spends); 3072 is the shortest critical path.
-            ba.cap = std::max(cap_env > 0 ? cap_env : (top_k <= 256 ? 3072 : 8192), std::max(top_k, 2048));
+            // 4-byte keys: up to 6144 of them keep the block at 40 KB of LDS (four blocks per CU).  Measured at top-100,
+            // M = 8 (scripts/gpu_boot_ab.sh): 3072 / 4096 / 6144 nodes -> 727 / 559 / 404 candidates per query and the
+            // same step time within 1.5 % (what the scan saves the bootstrap spends); 3072 is the shortest critical path.
+            // M = 16 (a class sees 2 of 16 sub-spaces: weaker cells; a check costs 16 gathers): 3072 / 6144 / 8192 ->
+            // 3003 / 1373 / 1021 candidates, 1.77 / 1.99 / 2.00 M q/s (scripts/gpu_m16_boot.sh).  top_k > 256
+            // (scripts/gpu_boot_cap1000.sh, top-1000): 8192 / 12288 / 16384 -> M = 8 1.81 / 1.83 / 1.81, M = 16
+            // 1.05 / 1.10 / 1.00 M q/s.
+            const int cap_auto = top_k <= 256 ? (x->M <= 8 ? 3072 : 6144) : 12288;
+            ba.cap = std::max(std::min(cap_env > 0 ? cap_env : cap_auto, 16384), std::max(top_k, 2048));
             ba.cap = (ba.cap + 63) / 64 * 64;
             static const int target_env = getenv("DPQ_BOOT_TARGET") ? atoi(getenv("DPQ_BOOT_TARGET")) : 0;
             ba.target = target_env > 0 ? std::min(ba.cap, std::max(target_env, top_k)) : ba.cap;

@@ -15,7 +15,7 @@ constexpr int kRegionStride = 1 + kMaxSplits;    // candidate-count words per sl
 constexpr int kLevel0Nodes = 3840;               // level-0 list: its select block (keys + exact tables) stays under 40 KB of LDS
 constexpr int kSortMax = 4096;  // candidate keys the select kernel holds in LDS; more -> radix select on the HBM list
 // queries per scan workgroup = what 128 KB of filter tables hold: 8-bit entries for M = 8, 16-bit for M = 16
-inline int queries_per_group(int M) { return M <= 8 ? 64 : 16; }
+inline int queries_per_group(int M) { return M <= 8 ? 64 : 32; }
 
 // The SoA image of one shard in HBM (see DESIGN.md "Data layout").
 struct DeviceImage {

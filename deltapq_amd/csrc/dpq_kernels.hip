@@ -164,30 +164,59 @@ struct Cfg {
     static constexpr int JUMPS = M <= 8 ? 3 : 4;      // pointer-jumping rounds: 2^JUMPS > deepest in-chunk chain
     static constexpr int PLANES = M <= 8 ? 4 : 5;     // bits of popcount(mask)
     // ---- filter tables of the scan ----
-    static constexpr int EB = M <= 8 ? 8 : 16;        // bits per table entry
-    static constexpr int F = 32 / EB;                 // entries (= queries) per dword
+    static constexpr int EB = 8;                      // bits per table entry (4 queries per table dword)
+    static constexpr int AB = M <= 8 ? 8 : 16;        // bits per field of the accumulators the entries are summed in
+    static constexpr int R = AB / EB;                 // accumulator dwords per table dword
+    static constexpr int F = 32 / AB;                 // fields (= queries) per accumulator dword
     static constexpr int NG = M <= 8 ? 4 : 2;         // 16-byte entries per (m, code): NG * M * 256 * 16 B = 128 KB
-    static constexpr int NA = NG * 4;                 // accumulator dwords per node
-    static constexpr int QG = NA * F;                 // queries per scan workgroup: 64 (M = 8), 16 (M = 16)
-    static constexpr int J = NA < EB ? NA : EB;       // accumulator dwords folded into one survivor-mask dword
-    static constexpr int MD = (NA + EB - 1) / EB;     // survivor-mask dwords per lane
+    static constexpr int NA = NG * 4 * R;             // accumulator dwords per node
+    static constexpr int QG = NA * F;                 // queries per scan workgroup: 64 (M = 8), 32 (M = 16)
+    static constexpr int J = NA < AB ? NA : AB;       // accumulator dwords folded into one survivor-mask dword
+    static constexpr int MD = (NA + AB - 1) / AB;     // survivor-mask dwords per lane
     // 8-bit geometry re-swept on the GPU with bootstrap thresholds (QT/SAT -> exact checks per query, scan ms per
     // 1000 queries): 32/20 5644 0.198, 40/21 3848 0.178, 48/22 3004 0.169, 56/23 2585 0.165, 64/24 2413 0.163,
     // 80/26 2474 0.164, 90/26 3129 0.170, 100/27 3756 0.178, 120/30 4789 0.189 -- saturation costs more than resolution
-    static constexpr int QT = M <= 8 ? 80 : 3700;     // filter units that span (tau - sum of minima)
-    static constexpr int SAT = M <= 8 ? 26 : 2279;    // entry saturation
-    // added to every m = 0 entry: field sum >= 2^(EB-1) (its top bit) <=> sum of entries > QT + 1
-    static constexpr int BIAS = (1 << (EB - 1)) - 1 - (QT + 1);
+    // M = 16: sixteen byte entries at that resolution do not fit a byte sum (QT 110 / SAT 31 with the top bits set
+    // aside every four sub-spaces: 3.3 x the exact checks of 16-bit entries and a slower scan), and 16-bit ENTRIES
+    // (round 1) serve 16 queries per decode pass at 32 LDS bytes per pair.  So the entries are bytes, summed four
+    // sub-spaces at a time as bytes (4 * SAT <= 255) and then widened into 16-bit accumulator fields: 32 queries
+    // per pass, 16 LDS bytes per pair.  Swept on the GPU (entries summed as bytes / SAT / QT -> exact checks per
+    // query, M q/s at top-1000 and top-100; 16-bit entries: 7775, 0.995, 1.32): 4/63/160 17766 0.91 1.67,
+    // 4/63/200 15134 0.99 1.77, 4/63/250 13776 1.04 1.79, 4/63/300 14271 1.02 1.75, 4/63/400 22002 0.81 1.46,
+    // 2/127/200 15075 0.95 1.58, 1/255/320 11686 0.97 1.47, 1/255/400 10710 0.99 1.47 -- every unit of bound an
+    // entry loses to rounding lets more of a concentrated 16-sub-space distance distribution through, but the
+    // widening instructions of the finer geometries cost as much as the checks they save.
+#ifndef DPQ_QT16
+#define DPQ_QT16 250
+#define DPQ_SAT16 63
+#define DPQ_PRE16 4
+#endif
+    static constexpr int QT = M <= 8 ? 80 : DPQ_QT16;   // filter units that span (tau - sum of minima)
+    static constexpr int SAT = M <= 8 ? 26 : DPQ_SAT16; // entry saturation
+    // field sum >= 2^(AB-1) (its top bit) <=> sum of entries > QT + 1.  R = 1: added to every m = 0 entry;
+    // R = 2: the accumulator fields start from it.
+    static constexpr int BIAS = (1 << (AB - 1)) - 1 - (QT + 1);
     static constexpr int FIELD_MAX = (1 << EB) - 1;
-    static_assert(M * SAT + BIAS <= FIELD_MAX, "a field sum must not carry into its neighbour");
-    static constexpr uint32_t LOW = EB == 8 ? 0x01010101u : 0x00010001u;  // bit 0 of every field
+    static_assert(BIAS >= 0 && M * SAT + BIAS < (1 << AB), "a field sum must not carry into its neighbour");
+    static constexpr int PRE = R == 1 ? M : DPQ_PRE16;  // entries summed as bytes before they are widened
+    static_assert(R == 1 || (PRE * SAT <= FIELD_MAX && M * SAT > QT + 1 && M % PRE == 0), "byte sums of PRE entries; all-SAT rejects");
+    static constexpr uint32_t LOW = AB == 8 ? 0x01010101u : 0x00010001u;  // bit 0 of every accumulator field
+    // local slot of field f of accumulator dword acc: survivor-mask dword acc / AB, bit AB * f + acc % AB
+    __host__ __device__ static constexpr int slot_of(int acc, int f) { return (acc / AB) * (J * F) + f * J + acc % AB; }
+    // byte tb of dword c of 16-byte entry g of the tables <-> local slot: its accumulator is (4 g + c) R + tb % R
+    // (R = 2: even bytes widen into one accumulator, odd bytes into the next), field tb / R
+    __host__ __device__ static constexpr int slot_of_table(int g, int c, int tb) {
+        return slot_of((4 * g + c) * R + tb % R, tb / R);
+    }
+    // the table entry of a slot nobody asks for: its field sum rejects every node
+    __host__ __device__ static constexpr uint32_t reject_entry(int m) {
+        return R == 1 ? (m == 0 ? (uint32_t)FIELD_MAX : 0u) : (uint32_t)SAT;
+    }
     // refine queue of a wavefront: one entry per node with filter survivors = (code, id, survivor mask);
     // 1920 B per wavefront (16 of them share what the 128 KB of tables leave of the 160 KB)
     static constexpr int QE_BYTES = 4 * W + 4 + 4 * MD;
     static constexpr int QCAP = 1920 / QE_BYTES;      // 96 entries (M = 8), 80 (M = 16)
     static_assert(QCAP >= 64 + 16, "a step pushes up to 64 entries");
-    // local slot of field f of accumulator dword acc: survivor-mask dword acc / EB, bit EB * f + acc % EB
-    __host__ __device__ static constexpr int slot_of(int acc, int f) { return (acc / EB) * (J * F) + f * J + acc % EB; }
 };
 
 // a7: the reference's decoder[256] (main:312-325) as byte-permute selectors.
@@ -433,7 +462,7 @@ __device__ __forceinline__ FilterScale filter_scale(uint64_t key, const float* _
     const double R = taup - B;
     if (key != ~0ull && R > 0.0 && R < 1e300) {  // else: no threshold yet (or degenerate), keep everything
         r.s32 = (float)((double)C::QT / R * (1.0 - 0x1p-20));
-        r.bias = (uint32_t)C::BIAS;
+        r.bias = C::R == 1 ? (uint32_t)C::BIAS : 0u;  // R = 2: the accumulators carry it
     }
     return r;
 }
@@ -446,70 +475,53 @@ __device__ __forceinline__ float filter_offset(const FilterScale& fs, float min_
     const double od = (double)mn * (double)fs.s32;
     float of = (float)od;
     if ((double)of < od) of = __uint_as_float(__float_as_uint(of) + 1u);  // od >= 0: next float up
-    if constexpr (Cfg<M>::EB == 8) {
-        const double sd = (m == 0 ? (double)fs.bias : 0.0) - 0.5 - (double)of;
-        float sf = (float)sd;
-        if ((double)sf > sd) sf = __uint_as_float(__float_as_uint(sf) + (sf > 0.0f ? -1 : 1));  // next float down
-        of = sf;
-    }
-    return of;
+    const double sd = (m == 0 ? (double)fs.bias : 0.0) - 0.5 - (double)of;
+    float sf = (float)sd;
+    if ((double)sf > sd) sf = __uint_as_float(__float_as_uint(sf) + (sf > 0.0f ? -1 : 1));  // next float down
+    return sf;
 }
 
 template <int M>
 __device__ __forceinline__ uint32_t filter_field(float tv, float sc, float of, uint32_t bias_m) {
     using C = Cfg<M>;
-    if constexpr (C::EB == 8) {
-        // v_cvt_pk_u8_f32: float -> u8 clamped to [0, 255].  Half a unit is taken off first (in `of`), so whichever
-        // way the conversion rounds, the byte is <= floor(value): the entry stays a lower bound (negative -> 0;
-        // inf/NaN of centroids beyond K -> SAT by the min).
-        const float fv = fminf(__fmaf_rn(tv, sc, of), (float)C::SAT + (float)bias_m);
-        return __builtin_amdgcn_cvt_pk_u8_f32(fv, 0u, 0u);
-    } else {
-        const float fv = __fmaf_rn(tv, sc, -of);
-        // fv < 0 only by the round-up of `of` (true value 0); NaN/inf (k >= K) saturate
-        const uint32_t v = fv < (float)C::SAT ? (fv > 0.0f ? (uint32_t)fv : 0u) : (uint32_t)C::SAT;
-        return v + bias_m;
-    }
+    // v_cvt_pk_u8_f32: float -> u8 clamped to [0, 255].  Half a unit is taken off first (in `of`), so whichever
+    // way the conversion rounds, the byte is <= floor(value): the entry stays a lower bound (negative -> 0;
+    // inf/NaN of centroids beyond K -> SAT by the min).
+    const float fv = fminf(__fmaf_rn(tv, sc, of), (float)C::SAT + (float)bias_m);
+    return __builtin_amdgcn_cvt_pk_u8_f32(fv, 0u, 0u);
 }
 
-// One slot's fields of its group's filter tables, written field by field (1 or 2 bytes each, 16 bytes apart):
-// T = the slot's exact tables (NULL: an unused slot, every m = 0 field rejects).
+// One slot's fields of its group's filter tables, written byte by byte (16 bytes apart):
+// T = the slot's exact tables (NULL: an unused slot, its entries reject).
 template <int M>
 __device__ __forceinline__ void write_filter_fields(uint4* qtab, int slot, const float* T, float sc, const float* of_m,
                                                     uint32_t bias, int tid, int nthreads) {
     using C = Cfg<M>;
-    constexpr int F = C::F, EB = C::EB, QG = C::QG, NG = C::NG, J = C::J;
+    constexpr int F = C::F, AB = C::AB, R = C::R, QG = C::QG, NG = C::NG, J = C::J;
     const int group = slot / QG, ls = slot % QG;
-    const int f = (ls % (J * F)) / J, acc = (ls / (J * F)) * EB + ls % J;  // inverse of Cfg::slot_of
-    const int g = acc >> 2, c = acc & 3;
-    unsigned char* base = reinterpret_cast<unsigned char*>(qtab + ((size_t)group * NG + g) * M * 256) + c * 4 + f * (EB / 8);
+    const int f = (ls % (J * F)) / J, acc = (ls / (J * F)) * AB + ls % J;  // inverse of Cfg::slot_of
+    const int d = acc / R, tb = f * R + acc % R;                           // ... and of Cfg::slot_of_table
+    const int g = d >> 2, c = d & 3;
+    unsigned char* base = reinterpret_cast<unsigned char*>(qtab + ((size_t)group * NG + g) * M * 256) + c * 4 + tb;
     for (int e = tid; e < M * 256; e += nthreads) {
         const int m = e >> 8;
-        uint32_t v;
-        if (T)
-            v = filter_field<M>(T[e], sc, of_m[m], m == 0 ? bias : 0u);
-        else
-            v = m == 0 ? (uint32_t)C::FIELD_MAX : 0u;
-        if constexpr (EB == 8)
-            base[(size_t)e * 16] = (unsigned char)v;
-        else
-            *reinterpret_cast<uint16_t*>(base + (size_t)e * 16) = (uint16_t)v;
+        const uint32_t v = T ? filter_field<M>(T[e], sc, of_m[m], m == 0 ? bias : 0u) : C::reject_entry(m);
+        base[(size_t)e * 16] = (unsigned char)v;
     }
 }
 
 template <int M>
 __global__ __launch_bounds__(256) void quantise_kernel(const ScanArgs a) {
     using C = Cfg<M>;
-    constexpr int F = C::F, EB = C::EB, QG = C::QG, NG = C::NG;
+    constexpr int QG = C::QG, NG = C::NG;
     constexpr int TE = M * 256;
-    constexpr int NS = 4 * F;  // slots served by one 16-byte entry
+    constexpr int NS = 16;  // slots served by one 16-byte entry: byte tb of dword c
     __shared__ float s_scale[NS], s_off[NS];
     __shared__ int32_t s_row[NS];
     __shared__ uint32_t s_bias[NS];
     const int g = blockIdx.x / M, m = blockIdx.x % M, group = blockIdx.y, k = threadIdx.x;
     if (k < NS) {
-        const int c = k / F, f = k % F;
-        const int ls = C::slot_of(4 * g + c, f);
+        const int ls = C::slot_of_table(g, k >> 2, k & 3);
         const int slot = group * QG + ls;
         int qq = a.slot_query ? a.slot_query[slot] : (slot < a.n_queries ? slot : -1);
         FilterScale fs{0.0f, 0u};
@@ -535,27 +547,18 @@ __global__ __launch_bounds__(256) void quantise_kernel(const ScanArgs a) {
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
 #pragma unroll
-        for (int f = 0; f < F; ++f) {
-            const int i = c * F + f;
+        for (int tb = 0; tb < 4; ++tb) {
+            const int i = c * 4 + tb;
             const int row = s_row[i];
             const float sc = s_scale[i], of = s_off[i];
             const uint32_t bias = s_bias[i];
             const float tv = row >= 0 ? a.lut32[(size_t)row + k] : 0.0f;
-            if constexpr (EB == 8) {
-                // v_cvt_pk_u8_f32: float -> u8 clamped to [0, 255], written into byte f of the dword.  Half a
-                // unit is taken off first, so whichever way the conversion rounds, the byte is <= floor(value):
-                // the entry stays a lower bound (negative -> 0; inf/NaN of centroids beyond K -> SAT by the min).
-                const float fv = fminf(__fmaf_rn(tv, sc, of), (float)C::SAT + (float)bias);  // `of` holds the shift here
-                out[c] = row < 0 ? out[c] | ((m == 0 ? (uint32_t)C::FIELD_MAX : 0u) << (EB * f))  // unused slot: top bit always set
-                                 : __builtin_amdgcn_cvt_pk_u8_f32(fv, (uint32_t)f, out[c]);
-            } else {
-                const float fv = __fmaf_rn(tv, sc, -of);
-                // fv < 0 only by the round-up of `of` (true value 0); NaN/inf (k >= K) saturate
-                uint32_t v = fv < (float)C::SAT ? (fv > 0.0f ? (uint32_t)fv : 0u) : (uint32_t)C::SAT;
-                v += bias;
-                if (row < 0) v = m == 0 ? (uint32_t)C::FIELD_MAX : 0u;  // unused slot: top bit always set
-                out[c] |= v << (EB * f);
-            }
+            // v_cvt_pk_u8_f32: float -> u8 clamped to [0, 255], written into byte tb of the dword.  Half a
+            // unit is taken off first, so whichever way the conversion rounds, the byte is <= floor(value):
+            // the entry stays a lower bound (negative -> 0; inf/NaN of centroids beyond K -> SAT by the min).
+            const float fv = fminf(__fmaf_rn(tv, sc, of), (float)C::SAT + (float)bias);  // `of` holds the shift here
+            out[c] = row < 0 ? out[c] | (C::reject_entry(m) << (8 * tb))  // unused slot: rejects everything
+                             : __builtin_amdgcn_cvt_pk_u8_f32(fv, (uint32_t)tb, out[c]);
         }
     }
     a.qtab[((size_t)group * NG * M + blockIdx.x) * 256 + k] = make_uint4(out[0], out[1], out[2], out[3]);
@@ -588,7 +591,7 @@ enum { kStPrologue = 0, kStSegment, kStDecode, kStGather, kStFold, kStPush, kStR
 template <int M, bool PLAIN, bool STAMPS>
 __global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanArgs a) {
     using C = Cfg<M>;
-    constexpr int W = C::W, QG = C::QG, NG = C::NG, NA = C::NA, EB = C::EB, F = C::F, MD = C::MD, QCAP = C::QCAP;
+    constexpr int W = C::W, QG = C::QG, NG = C::NG, NA = C::NA, EB = C::AB, F = C::F, MD = C::MD, QCAP = C::QCAP;
     constexpr int TE = M * 256;  // table entries per query
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint4* lut = reinterpret_cast<uint4*>(smem);                                        // [NG][M][256] x 16 B = 128 KB
@@ -829,25 +832,45 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanArgs a) {
             uint32_t acc[NA];
 #pragma unroll
             for (int g = 0; g < NG; ++g) {
-                uint32_t sx = 0, sy = 0, sz = 0, sw = 0;
-#pragma unroll
-                for (int m0 = 0; m0 < M; m0 += 8) {
+                if constexpr (C::R == 1) {
                     uint4 v[8];
 #pragma unroll
-                    for (int mm = 0; mm < 8; ++mm) {
-                        const int m = m0 + mm;
+                    for (int m = 0; m < 8; ++m) {
                         const uint32_t byte = (code[m >> 2] >> (8 * (m & 3))) & 0xffu;
-                        v[mm] = lut[(g * M + m) * 256 + byte];
+                        v[m] = lut[(g * M + m) * 256 + byte];
                     }
-                    sx += ((v[0].x + v[1].x + v[2].x) + v[3].x + v[4].x) + (v[5].x + v[6].x + v[7].x);
-                    sy += ((v[0].y + v[1].y + v[2].y) + v[3].y + v[4].y) + (v[5].y + v[6].y + v[7].y);
-                    sz += ((v[0].z + v[1].z + v[2].z) + v[3].z + v[4].z) + (v[5].z + v[6].z + v[7].z);
-                    sw += ((v[0].w + v[1].w + v[2].w) + v[3].w + v[4].w) + (v[5].w + v[6].w + v[7].w);
+                    acc[4 * g + 0] = ((v[0].x + v[1].x + v[2].x) + v[3].x + v[4].x) + (v[5].x + v[6].x + v[7].x);
+                    acc[4 * g + 1] = ((v[0].y + v[1].y + v[2].y) + v[3].y + v[4].y) + (v[5].y + v[6].y + v[7].y);
+                    acc[4 * g + 2] = ((v[0].z + v[1].z + v[2].z) + v[3].z + v[4].z) + (v[5].z + v[6].z + v[7].z);
+                    acc[4 * g + 3] = ((v[0].w + v[1].w + v[2].w) + v[3].w + v[4].w) + (v[5].w + v[6].w + v[7].w);
+                } else {
+                    // byte sums of four sub-spaces (no carry: 4 * SAT <= 255), widened into 16-bit fields:
+                    // even bytes -> accumulator 2 (4 g + c), odd bytes -> the next one; the fields start at BIAS
+                    uint32_t lo[4], hi[4];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) lo[c] = hi[c] = (uint32_t)C::BIAS * C::LOW;
+#pragma unroll
+                    for (int m0 = 0; m0 < M; m0 += C::PRE) {
+                        uint32_t p[4] = {0, 0, 0, 0};
+#pragma unroll
+                        for (int mm = 0; mm < C::PRE; ++mm) {
+                            const int m = m0 + mm;
+                            const uint32_t byte = (code[m >> 2] >> (8 * (m & 3))) & 0xffu;
+                            const uint4 v = lut[(g * M + m) * 256 + byte];
+                            p[0] += v.x, p[1] += v.y, p[2] += v.z, p[3] += v.w;
+                        }
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            lo[c] += __builtin_amdgcn_perm(0u, p[c], 0x0c020c00u);  // bytes 0, 2 -> 16-bit fields
+                            hi[c] += __builtin_amdgcn_perm(0u, p[c], 0x0c030c01u);  // bytes 1, 3
+                        }
+                    }
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        acc[(4 * g + c) * 2 + 0] = lo[c];
+                        acc[(4 * g + c) * 2 + 1] = hi[c];
+                    }
                 }
-                acc[4 * g + 0] = sx;
-                acc[4 * g + 1] = sy;
-                acc[4 * g + 2] = sz;
-                acc[4 * g + 3] = sw;
             }
             if constexpr (STAMPS) {
 #pragma unroll
