@@ -232,17 +232,34 @@ def main():
     if not torch.cuda.is_available():
         print("bench.py needs a GPU: the DeltaPQ query path has no CPU fallback", file=sys.stderr)
         sys.exit(3)
-    if args.backend == "gloo":
+    if args.backend == "gloo" or os.environ.get("DPQ_BENCH_SHARE_GPUS") == "1":   # rehearsals: more ranks than devices
         local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     cpu_coll = args.backend == "gloo"   # gloo collectives take host tensors
+    backend_note = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if not cpu_coll:
+            # RCCL, proved with one small collective before anything is built on it; if the node refuses it (no P2P
+            # between the visible devices, IPC mode ...) every rank sees the failure here and the run goes on over
+            # gloo with host-staged lists -- a slower exchange step, said so on the JSON line, instead of no line.
+            try:
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+                probe = torch.ones(1, device=dev)
+                dist.all_reduce(probe)
+                torch.cuda.synchronize(dev)
+                assert int(probe.item()) == world
+            except Exception as e:   # noqa: BLE001 -- any failure of the collective layer
+                backend_note = "RCCL unusable (%s: %s); exchange step over gloo with host staging" % (type(e).__name__, str(e)[:200])
+                print("bench.py rank %d: %s" % (rank, backend_note), file=sys.stderr)
+                try:
+                    dist.destroy_process_group()
+                except Exception:   # noqa: BLE001
+                    pass
+                cpu_coll = True
         if cpu_coll:
             dist.init_process_group("gloo", rank=rank, world_size=world)
-        else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     by_query = world > 1 and args.shard == "query"
     nq, k = args.queries, args.topk
@@ -402,6 +419,7 @@ def main():
                             ("query replicas x%d: every GPU holds the whole index and answers its own %d-query batch" % (world, nq)
                              if by_query else "dfs-range index shards x%d, one %d-query batch, one all-gather + merge" % (world, nq)),
                 "global_queries_per_step": global_q,
+                "collectives": None if world == 1 else (backend_note or ("gloo (host tensors)" if cpu_coll else "RCCL (backend nccl)")),
                 "query_batches_rotated": N_BATCHES,
                 "step_pipelining": "two lanes (dpq_query_batch_device_async)" if pipelined or not sharded else
                                    ("stream-ordered steps (dpq_query_batch_device_ordered), no host round trip; no batch had to be answered again"

@@ -414,7 +414,7 @@ def test_two_process_sharded_run_on_one_gpu(gpu, built):
     assert r.returncode == 0 and "DIST_GPU_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
 
 
-def _run_bench(extra, nproc=2, timeout=900):
+def _run_bench(extra, nproc=2, timeout=900, env=None):
     import json
     import socket
     import sys
@@ -426,7 +426,8 @@ def _run_bench(extra, nproc=2, timeout=900):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
            "--gpus", str(nproc)] + extra
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=dict(os.environ, OMP_NUM_THREADS="1"), cwd=ROOT)
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout,
+                       env=dict(os.environ, OMP_NUM_THREADS="1", **(env or {})), cwd=ROOT)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
     return json.loads(r.stdout.strip().splitlines()[-1])
 
@@ -465,6 +466,18 @@ def test_bench_two_gpus_over_rccl(gpu, built):
     line = _run_bench(["--backend", "nccl", "--data", "pipeline", "--codes", "300000", "--queries", "200", "--steps", "3",
                        "--warmup", "1", "--reps", "2", "--check", "8", "--no-cpu-baseline"])
     assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["parity_checked_queries"] == 8
+
+
+def test_bench_survives_an_unusable_rccl(gpu, built):
+    """The driver's N > 1 command line with the default backend where RCCL cannot work (two ranks on ONE device:
+    ncclInvalidUsage): bench.py proves the collective layer with one all-reduce, falls back to gloo with host staging
+    and says so on its line.  (With two devices visible RCCL works and the line says that.)"""
+    line = _run_bench(["--data", "pipeline", "--codes", "150000", "--queries", "100", "--steps", "3", "--warmup", "1", "--reps", "2",
+                       "--check", "4", "--no-cpu-baseline", "--no-replicas"], timeout=600, env={"DPQ_BENCH_SHARE_GPUS": "1"})
+    import torch
+    note = line["config"]["collectives"]
+    assert note.startswith("RCCL unusable" if torch.cuda.device_count() < 2 else "RCCL (backend nccl)"), note
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["parity_checked_queries"] == 4 and line["value"] > 0
 
 
 def test_part_of_a_larger_index_reports_global_positions(gpu, oracle, codebook):
