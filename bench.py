@@ -202,6 +202,9 @@ def main():
     ap.add_argument("--mean-diffs", type=float, default=3.0, help="changed bytes per node (--data stream)")
     ap.add_argument("--chunks-per-segment", type=int, default=0)
     ap.add_argument("--bootstrap", type=int, default=0, help="dpq_open_opts.bootstrap: 0 auto, 1 on, -1 off")
+    ap.add_argument("--batch-decode", type=int, default=0,
+                    help="dpq_open_opts.batch_decode: 0 auto (batches of >= 3 query groups decode once into a plain-code "
+                         "scratch), 1 always, -1 never (decode inside the scan)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU time given to each leg of the oracle baseline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--check", type=int, default=64, help="queries verified against the oracle before timing (time-bounded)")
@@ -267,7 +270,8 @@ def main():
 
     def open_index(**kw):
         idx = api.DeltaPQIndex.open_memory(wl["payload"], wl["n_local"], args.m, 256, device=local_rank,
-                                           chunks_per_segment=args.chunks_per_segment, bootstrap=args.bootstrap, **kw)
+                                           chunks_per_segment=args.chunks_per_segment, bootstrap=args.bootstrap,
+                                           batch_decode=args.batch_decode, **kw)
         idx.set_codebook(wl["codebook"])
         return idx
 
@@ -373,11 +377,13 @@ def main():
     QG = 64 if args.m <= 8 else 32   # queries served by one decode pass (8-bit filter entries: 128 KB of LDS tables)
     groups = (nq + QG - 1) // QG
     S = 64 * info["chunks_per_segment"]
+    batch_decoded = prof_aux["decode_ms"] > 0.0
+    decode_ms_step = prof_aux["decode_ms"] / aux_steps
     lds_bytes_step = float(info["n_segments"]) * S * groups * (4 if args.m <= 8 else 2) * args.m * 16   # NG * M * 16 B per node and group
     stats = torch.tensor([prof["scan_ms"], float(prof["scan_launches"]), float(info["algorithmic_bytes"]),
                           float(info["device_bytes"] + info["bootstrap_bytes"]), prof_aux["select_ms"], prof_aux["lut_ms"],
                           prof_aux["quantise_ms"], lds_bytes_step, float(prof_aux["exact_checks"]), float(prof_aux["candidates"]),
-                          float(info["node_hi"] - info["node_lo"])],
+                          float(info["node_hi"] - info["node_lo"]), prof_aux["decode_ms"]],
                          dtype=torch.float64, device=torch.device("cpu") if cpu_coll else dev)
     if world > 1:
         all_stats = [torch.zeros_like(stats) for _ in range(world)]
@@ -424,7 +430,10 @@ def main():
                 "step_pipelining": "two lanes (dpq_query_batch_device_async)" if pipelined or not sharded else
                                    ("stream-ordered steps (dpq_query_batch_device_ordered), no host round trip; no batch had to be answered again"
                                     if state["ordered"] else "one synchronous call per step (a batch overflowed in the stream-ordered run)"),
-                "queries_per_decode_pass": QG,
+                "queries_per_decode_pass": (groups * QG if batch_decoded else QG),
+                "decode": ("once per batch (decode_all_kernel) into %d MB of plain codes that the %d query groups' filter "
+                           "passes read through L2 / Infinity Cache" % (info["batch_decode_mb"], groups)) if batch_decoded
+                          else "inside the scan kernel, once per %d-query group" % QG,
                 "threshold_bootstrap": "multi-index, stride %d, %.1f MB" % (info["bootstrap_stride"], info["bootstrap_bytes"] / 1e6)
                                        if info["bootstrap_bytes"] else "off (spread-sample cascade)",
             },
@@ -455,19 +464,21 @@ def main():
                     "bytes_per_launch": traffic, "source": "profiles/%s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, "
                                                            "2 x FETCH_SIZE + WRITE_SIZE (gfx950 correction)" % pmc_name},
                 "algorithmic_hbm": {
-                    "GBps": (nq * alg_bytes_total) / (scan_ms_step * 1e-3) / 1e9 if scan_ms_step > 0 else 0.0,
+                    "GBps": (nq * alg_bytes_total) / ((scan_ms_step + decode_ms_step) * 1e-3) / 1e9 if scan_ms_step > 0 else 0.0,
                     "bytes_per_step": nq * alg_bytes_total,
-                    "note": "SURVEY.md 8(d) figure: queries x DTC payload bytes / scan time.  Every decoded chunk serves %d "
-                            "queries, so this is reuse, not traffic: it is NOT a fraction of the HBM roof" % QG},
+                    "note": "SURVEY.md 8(d) figure: queries x DTC payload bytes / (scan + per-batch decode) time.  Every decoded "
+                            "chunk serves %d queries, so this is reuse, not traffic: it is NOT a fraction of the HBM roof"
+                            % (groups * QG if batch_decoded else QG)},
                 "launches_per_step": launches_step,
                 "avg_launch_ms": avg_launch_ms,
                 "scan_ms_per_step": scan_ms_step,
                 "select_ms_per_step": float(all_stats[:, 4].max()) / aux_steps,
                 "lut_ms_per_step": float(all_stats[:, 5].max()) / aux_steps,
                 "quantise_ms_per_step": float(all_stats[:, 6].max()) / aux_steps,
+                "decode_ms_per_step": float(all_stats[:, 11].max()) / aux_steps,
                 "filter_survivors_per_query": float(all_stats[:, 8].sum()) / max(1, aux_steps * nq),
                 "candidates_per_query": float(all_stats[:, 9].sum()) / max(1, aux_steps * nq),
-                "event_note": "kernel times (scan, select incl. bootstrap, lut, quantise) from %d synchronous steps run after the "
+                "event_note": "kernel times (scan, select incl. bootstrap, lut, quantise, per-batch decode) from %d synchronous steps run after the "
                               "timed regions with HIP events around every kernel on the launch stream; the timed regions carry no "
                               "events (pipelined batches overlap on two lanes there)" % aux_steps,
             },

@@ -15,7 +15,7 @@ P = ctypes.POINTER
 
 class OpenOpts(ctypes.Structure):
     _fields_ = [("device", c_i32), ("shard_rank", c_i32), ("shard_count", c_i32), ("chunks_per_segment", c_i32),
-                ("cand_capacity", c_i32), ("num_codes", c_i32), ("bootstrap", c_i32), ("reserved", c_i32 * 1),
+                ("cand_capacity", c_i32), ("num_codes", c_i32), ("bootstrap", c_i32), ("batch_decode", c_i32),
                 ("global_offset", c_i64), ("global_n_codes", c_i64)]
 
 
@@ -24,7 +24,7 @@ class Info(ctypes.Structure):
                 ("algorithmic_bytes", c_i64), ("device_bytes", c_i64), ("n_diffs", c_i64), ("M", c_i32),
                 ("K", c_i32), ("Ds", c_i32), ("n_segments", c_i32), ("chunks_per_segment", c_i32),
                 ("max_depth", c_i32), ("device", c_i32), ("cand_capacity", c_i32), ("bootstrap_bytes", c_i64),
-                ("bootstrap_stride", c_i32), ("reserved", c_i32)]
+                ("bootstrap_stride", c_i32), ("batch_decode_mb", c_i32)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -35,7 +35,7 @@ class Profile(ctypes.Structure):
                 ("lut_launches", c_i64), ("scan_launches", c_i64), ("select_launches", c_i64),
                 ("scan_node_query_pairs", c_i64), ("scan_stream_bytes", c_i64), ("query_batches", c_i64),
                 ("queries", c_i64), ("overflow_reruns", c_i64), ("exact_checks", c_i64), ("candidates", c_i64),
-                ("quantise_ms", ctypes.c_double)]
+                ("quantise_ms", ctypes.c_double), ("decode_ms", ctypes.c_double)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

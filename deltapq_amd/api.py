@@ -217,24 +217,25 @@ class DeltaPQIndex:
 
     @classmethod
     def open_file(cls, path, M=8, K=256, device=0, shard_rank=0, shard_count=1, chunks_per_segment=0,
-                  cand_capacity=0, num_codes=0, bootstrap=0):
+                  cand_capacity=0, num_codes=0, bootstrap=0, batch_decode=0):
         """num_codes > 0: scan only the first num_codes codes (the reference's -N below the header's n_codes).
-        bootstrap: 0 auto, 1 on, -1 off (dpq_open_opts.bootstrap)."""
+        bootstrap: 0 auto, 1 on, -1 off (dpq_open_opts.bootstrap).  batch_decode: 0 auto, 1 always decode once per batch
+        into the plain-code scratch, -1 always decode inside the scan (dpq_open_opts.batch_decode)."""
         lib = _lib.load()
-        opts = OpenOpts(device, shard_rank, shard_count, chunks_per_segment, cand_capacity, num_codes, bootstrap)
+        opts = OpenOpts(device, shard_rank, shard_count, chunks_per_segment, cand_capacity, num_codes, bootstrap, batch_decode)
         h = ctypes.c_void_p()
         check(lib.dpq_open_file(path.encode(), M, K, opts, h), "dpq_open_file")
         return cls(h)
 
     @classmethod
     def open_memory(cls, payload, n_codes, M=8, K=256, device=0, shard_rank=0, shard_count=1, chunks_per_segment=0,
-                    cand_capacity=0, num_codes=0, bootstrap=0, global_offset=0, global_n_codes=0):
+                    cand_capacity=0, num_codes=0, bootstrap=0, global_offset=0, global_n_codes=0, batch_decode=0):
         """global_offset / global_n_codes: the payload is a self-contained part of a larger index (ids are
         reported as global_offset + local position; dpq_open_opts)."""
         lib = _lib.load()
         pl = np.ascontiguousarray(payload, dtype=np.uint8)
         opts = OpenOpts(device, shard_rank, shard_count, chunks_per_segment, cand_capacity, num_codes, bootstrap,
-                        (0,), global_offset, global_n_codes)
+                        batch_decode, global_offset, global_n_codes)
         h = ctypes.c_void_p()
         check(lib.dpq_open_memory(_np_ptr(pl), pl.size, n_codes, M, K, opts, h), "dpq_open_memory")
         return cls(h)

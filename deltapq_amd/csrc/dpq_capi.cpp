@@ -99,6 +99,8 @@ struct dpq_index {
     bool boot = false;
     int boot_classes = 0;
     unsigned long long* d_boot_stamps = nullptr;  // developer diagnostics (dpq_debug_boot_stamps)
+    uint8_t* d_batch_raw = nullptr;  // active lane: the shard's plain codes, decoded once per batch (batch_decode)
+    int batch_decode = 0;            // dpq_open_opts.batch_decode
     uint8_t* d_nbr = nullptr;        // [8][256][256] centroid neighbour lists of the bootstrap's sub-spaces (dpq_set_codebook)
     float* d_codebook = nullptr;
     // workspace, sized for ws_slots padded queries and ws_cap candidates each
@@ -133,6 +135,7 @@ struct dpq_index {
         uint4* d_qtab = nullptr;
         uint32_t *d_cand_count = nullptr, *d_overflow = nullptr;
         uint64_t *d_cand_key = nullptr, *d_thr_key = nullptr, *d_scratch = nullptr;
+        uint8_t* d_batch_raw = nullptr;
         int ws_slots = 0, ws_cap = 0;
     };
     Lane parked;                     // workspace of the lane that is not active
@@ -184,12 +187,12 @@ void switch_lane(dpq_index* x, int lane) {
     cur.d_lut32 = x->d_lut32; cur.d_lut_min = x->d_lut_min; cur.d_qtab = x->d_qtab;
     cur.d_cand_count = x->d_cand_count; cur.d_overflow = x->d_overflow;
     cur.d_cand_key = x->d_cand_key; cur.d_thr_key = x->d_thr_key; cur.d_scratch = x->d_scratch;
-    cur.ws_slots = x->ws_slots; cur.ws_cap = x->ws_cap;
+    cur.ws_slots = x->ws_slots; cur.ws_cap = x->ws_cap; cur.d_batch_raw = x->d_batch_raw;
     const dpq_index::Lane& o = x->parked;
     x->d_lut32 = o.d_lut32; x->d_lut_min = o.d_lut_min; x->d_qtab = o.d_qtab;
     x->d_cand_count = o.d_cand_count; x->d_overflow = o.d_overflow;
     x->d_cand_key = o.d_cand_key; x->d_thr_key = o.d_thr_key; x->d_scratch = o.d_scratch;
-    x->ws_slots = o.ws_slots; x->ws_cap = o.ws_cap;
+    x->ws_slots = o.ws_slots; x->ws_cap = o.ws_cap; x->d_batch_raw = o.d_batch_raw;
     x->parked = cur;
     x->active_lane = lane;
 }
@@ -197,7 +200,7 @@ void switch_lane(dpq_index* x, int lane) {
 void free_parked_lane(dpq_index* x) {
     dpq_index::Lane& o = x->parked;
     hipFree(o.d_lut32); hipFree(o.d_lut_min); hipFree(o.d_qtab); hipFree(o.d_cand_count); hipFree(o.d_overflow);
-    hipFree(o.d_cand_key); hipFree(o.d_thr_key); hipFree(o.d_scratch);
+    hipFree(o.d_cand_key); hipFree(o.d_thr_key); hipFree(o.d_scratch); hipFree(o.d_batch_raw);
     o = dpq_index::Lane();
 }
 
@@ -382,6 +385,23 @@ struct Timer {
     }
 };
 
+// plain-code scratch of a shard (per pipeline lane), and whether a batch of n_groups query groups uses it
+constexpr int64_t kBatchRawBudget = (int64_t)256 << 20;
+int64_t batch_raw_bytes(const dpq_index* x) {
+    return (int64_t)x->img.n_segments * dpq::kChunk * x->img.chunks_per_segment * x->M;
+}
+bool batch_decode_possible(const dpq_index* x) {
+    return !x->plain && x->batch_decode >= 0 && x->img.n_segments > 0 &&
+           (x->batch_decode > 0 || batch_raw_bytes(x) <= kBatchRawBudget);
+}
+bool use_batch_decode(const dpq_index* x, int n_groups) {
+    return batch_decode_possible(x) && (x->batch_decode > 0 || n_groups >= 3);
+}
+int ensure_batch_raw(dpq_index* x) {
+    if (x->d_batch_raw) return DPQ_OK;
+    return dev_alloc(&x->d_batch_raw, (size_t)batch_raw_bytes(x));
+}
+
 int splits_for(int n_seg_pass, int n_groups) {
     // One workgroup per CU is resident (LDS), so aim at ONE chip-wave: <= 256 workgroups.  Small levels
     // still spread over as many CUs as they have segments: the exact checks of the filter survivors
@@ -443,6 +463,20 @@ int run_batch(dpq_index* x, const float* d_queries, int nq, int top_k, int32_t* 
 
     dpq::ScanArgs sa{};
     sa.img = x->img;
+    sa.fp32_accum = x->plain ? 1 : 0;
+    // Where the decode happens (dpq_open_opts.batch_decode): a batch of several query groups decodes the shard
+    // once into plain codes that every group's filter pass reads (through L2 / Infinity Cache at the headline
+    // sizes) -- the scan kernel then runs its plain-code instantiation with the DTC distance rule; a batch of one or
+    // two groups, or a shard whose plain codes exceed the scratch budget, decodes inside the scan, once per group.
+    // Measured on 1 M codes x 1000 queries (16 groups): scan 0.166 -> 0.122 ms, step 0.212 -> 0.172 ms.
+    if (use_batch_decode(x, ngroups)) {
+        if ((rc = ensure_batch_raw(x))) return rc;
+        {
+            Timer t(x, stream, 4);
+            DPQ_HIP(dpq::launch_decode_all(x->img, reinterpret_cast<uint32_t*>(x->d_batch_raw), stream));
+        }
+        sa.img.raw = x->d_batch_raw;
+    }
     sa.lut32 = x->d_lut32;
     sa.lut_min = x->d_lut_min;
     sa.thr_key = x->d_thr_key;
@@ -708,6 +742,7 @@ int open_from_payload(const uint8_t* payload, int64_t n_bytes, int64_t n_codes, 
     x->K = K;
     x->cap_auto = o.cand_capacity <= 0;
     x->cap = o.cand_capacity;
+    x->batch_decode = o.batch_decode;
     auto up = [&](auto** dptr, const void* src, size_t bytes) -> int {
         using T = std::remove_pointer_t<std::remove_pointer_t<decltype(dptr)>>;
         int r = dev_alloc(dptr, (bytes + sizeof(T) - 1) / sizeof(T) + 64 / sizeof(T));
@@ -762,6 +797,7 @@ int open_from_payload(const uint8_t* payload, int64_t n_bytes, int64_t n_codes, 
     inf.device_bytes = soa.device_bytes();
     inf.bootstrap_bytes = x->boot ? soa.bootstrap_bytes() : 0;
     inf.bootstrap_stride = x->boot ? soa.mi_stride : 0;
+    inf.batch_decode_mb = batch_decode_possible(x) ? (int32_t)((batch_raw_bytes(x) + (1 << 20) - 1) >> 20) : 0;
     inf.n_diffs = soa.n_diffs;
     inf.M = M;
     inf.K = K;
@@ -1318,6 +1354,7 @@ int dpq_set_codebook(dpq_index* x, const float* codewords, int Ds) {
             }
         }
         hipFree(x->d_nbr);
+    hipFree(x->d_batch_raw);
         x->d_nbr = nullptr;
         rc = dev_alloc(&x->d_nbr, nbr.size());
         if (rc) return rc;
@@ -1636,6 +1673,7 @@ int dpq_debug_scan_time(dpq_index* x, int nq, int pass_all, int reps, int splits
     if (nqp > x->ws_slots) return fail(DPQ_ERR_ARG, "nq exceeds the workspace");
     dpq::ScanArgs sa{};
     sa.img = x->img;
+    sa.fp32_accum = x->plain ? 1 : 0;
     sa.lut32 = x->d_lut32;
     sa.lut_min = x->d_lut_min;
     sa.thr_key = x->d_thr_key;
@@ -1688,6 +1726,7 @@ int dpq_debug_scan_stamps(dpq_index* x, int nq, int splits, unsigned long long* 
     DPQ_HIP(hipMemset(d_st, 0, sizeof(unsigned long long) * dpq::scan_stamp_count()));
     dpq::ScanArgs sa{};
     sa.img = x->img;
+    sa.fp32_accum = x->plain ? 1 : 0;
     sa.lut32 = x->d_lut32;
     sa.lut_min = x->d_lut_min;
     sa.thr_key = x->d_thr_key;
@@ -1848,6 +1887,7 @@ int dpq_profile_read(dpq_index* x, dpq_profile* out) {
         if (ep.kind == 1) x->prof_acc.scan_ms += ms;
         if (ep.kind == 2) x->prof_acc.select_ms += ms;
         if (ep.kind == 3) x->prof_acc.quantise_ms += ms;
+        if (ep.kind == 4) x->prof_acc.decode_ms += ms;
         x->ev_pool.push_back(ep.a);
         x->ev_pool.push_back(ep.b);
     }

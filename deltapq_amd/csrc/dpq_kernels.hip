@@ -404,6 +404,28 @@ __global__ __launch_bounds__(64) void decode_segments_kernel(const DeviceImage i
     }
 }
 
+// The whole shard, decoded into plain codes [n_segments * S][M] (padded to whole segments): one wavefront per
+// segment.  grid = ceil(n_segments / 4), block = 256.
+template <int M>
+__global__ __launch_bounds__(256) void decode_all_kernel(const DeviceImage img, uint32_t* __restrict__ out_code) {
+    constexpr int W = Cfg<M>::W;
+    const int lane = threadIdx.x & 63;
+    const int64_t seg = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (seg >= img.n_segments) return;
+    const int cps = img.chunks_per_segment;
+    WaveDecoder<M> dec;
+    dec.begin_segment(img, (uint32_t)seg, lane);
+    for (int c = 0; c < cps; ++c) {
+        const int64_t node = (seg * cps + c) * 64 + lane;
+        uint32_t code[W];
+        dec.step(img, node, lane, c + 1 < cps, code);
+        if constexpr (W == 2)
+            reinterpret_cast<uint2*>(out_code)[node] = make_uint2(code[0], code[1]);
+        else
+            reinterpret_cast<uint4*>(out_code)[node] = make_uint4(code[0], code[1], code[2], code[3]);
+    }
+}
+
 // ---------------------------------------------------------------------------
 // scan: decode + ADC filter + exact check for QG queries per workgroup
 // ---------------------------------------------------------------------------
@@ -714,7 +736,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanArgs a) {
                 pend &= pend - 1;  // 0 stays 0
             }
 #pragma unroll
-            for (int e = 0; e < 2; ++e) d[e] = has[e] ? exact_dist<M>(a.lut32 + s_base[ls[e]], c, PLAIN) : 0.0f;
+            for (int e = 0; e < 2; ++e) d[e] = has[e] ? exact_dist<M>(a.lut32 + s_base[ls[e]], c, PLAIN && a.fp32_accum != 0) : 0.0f;
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
                 const uint64_t key = make_key(d[e], eid);
@@ -1716,6 +1738,18 @@ hipError_t launch_decode_segments(const DeviceImage& img, const uint32_t* seg_li
     else if (img.M == 16)
         hipLaunchKernelGGL(decode_segments_kernel<16>, dim3((unsigned)n_seg), dim3(64), 0, stream, img, seg_list,
                            out_id, out_code);
+    else
+        return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+hipError_t launch_decode_all(const DeviceImage& img, uint32_t* out_code, hipStream_t stream) {
+    if (img.n_segments <= 0) return hipSuccess;
+    const unsigned grid = (unsigned)((img.n_segments + 3) / 4);
+    if (img.M == 8)
+        hipLaunchKernelGGL(decode_all_kernel<8>, dim3(grid), dim3(256), 0, stream, img, out_code);
+    else if (img.M == 16)
+        hipLaunchKernelGGL(decode_all_kernel<16>, dim3(grid), dim3(256), 0, stream, img, out_code);
     else
         return hipErrorInvalidValue;
     return hipGetLastError();

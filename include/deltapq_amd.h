@@ -94,7 +94,12 @@ typedef struct dpq_open_opts {
                                  * from 64 K nodes per shard), 1 = on (from 16 K nodes), -1 = off (the spread-sample
                                  * cascade alone).  Results are identical either way.  dpq_soa_build: > 0 = build the
                                  * multi-index with this sampling stride. */
-    int32_t reserved[1];
+    int32_t batch_decode;       /* where the delta decode happens.  0 = automatic: a batch of >= 3 query groups (64 queries
+                                 * each; 32 at M = 16) decodes the shard ONCE into a plain-code scratch (M bytes per
+                                 * node, per pipeline lane; it stays in L2 / Infinity Cache at the headline sizes) that
+                                 * all its groups' filter passes read, when that scratch is <= 256 MB; smaller batches
+                                 * and larger shards decode inside the scan, once per group.  1 = scratch always,
+                                 * -1 = never.  Results are identical either way. */
     int64_t global_offset;      /* the payload is a self-contained PART of a larger index (its first node carries a
                                  * whole code): ids are reported as global_offset + position in this payload */
     int64_t global_n_codes;     /* 0 = this payload is the whole index; else N of the larger index (the even-N id
@@ -116,7 +121,8 @@ typedef struct dpq_info {
     int32_t cand_capacity;
     int64_t bootstrap_bytes;   /* HBM bytes of the threshold-bootstrap multi-index (0 = not in use) */
     int32_t bootstrap_stride;  /* every bootstrap_stride-th node is in it */
-    int32_t reserved;
+    int32_t batch_decode_mb;   /* MB of plain-code scratch a batch decodes into (per pipeline lane; 0 = this shard always
+                                * decodes inside the scan) */
 } dpq_info;
 
 /* Per-kernel device time accumulated since the last dpq_profile_reset, measured
@@ -131,6 +137,7 @@ typedef struct dpq_profile {
     int64_t exact_checks;              /* (code, query) pairs the filter let through, checked exactly in the scan */
     int64_t candidates;                /* pairs that passed the exact check (counted with dpq_profile_enable(idx, 1) only) */
     double quantise_ms;                /* filter-table builds (one per scan launch; dpq_profile_enable(idx, 1) only) */
+    double decode_ms;                  /* per-batch decodes into the plain-code scratch (dpq_profile_enable(idx, 1) only) */
 } dpq_profile;
 
 typedef struct dpq_dtc_stats {

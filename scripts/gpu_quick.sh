@@ -1,0 +1,14 @@
+#!/bin/bash
+# full GPU test suite, then the default and the M = 16 bench lines (short)
+mkdir -p gpurun_out
+python -m pytest tests -m gpu -x -q > gpurun_out/pytest_gpu.log 2>&1 || { tail -40 gpurun_out/pytest_gpu.log; exit 1; }
+tail -2 gpurun_out/pytest_gpu.log
+for cfg in "--m 8 --topk 100" "--m 16 --topk 1000" "--m 8 --topk 10" "--m 8 --topk 1000"; do
+python bench.py --no-cpu-baseline --reps 5 $cfg > gpurun_out/quick.json 2>gpurun_out/quick.err || { tail -5 gpurun_out/quick.err; exit 1; }
+python - <<PY
+import json
+d=json.loads(open("gpurun_out/quick.json").read().strip().splitlines()[-1])
+r=d["roofline"]
+print("$cfg", round(d["value"]), round(d["ms_per_step"],4), "scan", round(r["scan_ms_per_step"],4), "select+boot", round(r["select_ms_per_step"],4), "frac", round(r["frac"],3), "checks/q", round(r["filter_survivors_per_query"]), flush=True)
+PY
+done

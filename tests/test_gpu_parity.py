@@ -480,6 +480,42 @@ def test_bench_survives_an_unusable_rccl(gpu, built):
     assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["parity_checked_queries"] == 4 and line["value"] > 0
 
 
+@pytest.mark.parametrize("n,cps", [(200_000, 0), (70_001, 4), (9_000, 1)])
+def test_batch_decode_modes_agree(gpu, oracle, codebook, n, cps):
+    """dpq_open_opts.batch_decode: decoding the shard once per batch into the plain-code scratch (decode_all_kernel +
+    the scan's plain-code instantiation with the DTC distance rule) and decoding inside the scan give identical lists;
+    automatic = scratch from three query groups on.  Shapes: bootstrap shard, odd N with 4-chunk segments, small
+    cascade shard (level 0 included)."""
+    from deltapq_amd import synth
+    k = 40
+    tree, payload, _ = make_case(n, seed=41 + cps)
+    qs = synth.make_queries(200, 128, seed=42)
+    ids_f, d_f, prof_f, info_f = run(gpu, payload, n, codebook, qs, k, chunks_per_segment=cps, batch_decode=-1)
+    ids_b, d_b, prof_b, info_b = run(gpu, payload, n, codebook, qs, k, chunks_per_segment=cps, batch_decode=1)
+    assert np.array_equal(ids_f, ids_b) and np.array_equal(d_f.view(np.uint32), d_b.view(np.uint32))
+    assert prof_f["decode_ms"] == 0.0 and prof_b["decode_ms"] > 0.0
+    assert info_f["batch_decode_mb"] == 0 and info_b["batch_decode_mb"] == -(-info_b["n_segments"] * 64 * info_b["chunks_per_segment"] * 8 // (1 << 20))
+    ids_a, d_a, prof_a, _ = run(gpu, payload, n, codebook, qs, k, chunks_per_segment=cps)              # 200 queries: 4 groups
+    assert prof_a["decode_ms"] > 0.0 and np.array_equal(ids_a, ids_b) and np.array_equal(d_a.view(np.uint32), d_b.view(np.uint32))
+    ids_s, d_s, prof_s, _ = run(gpu, payload, n, codebook, qs[:128], k, chunks_per_segment=cps)        # 2 groups: inside the scan
+    assert prof_s["decode_ms"] == 0.0 and np.array_equal(ids_s, ids_b[:128]) and np.array_equal(d_s.view(np.uint32), d_b[:128].view(np.uint32))
+    assert_parity(ids_b[:12], d_b[:12], oracle_topk(oracle, payload, n, codebook, qs[:12], k), n)
+
+
+def test_batch_decode_m16(gpu):
+    """The same for the M = 16 format extension (4-dword codes)."""
+    from deltapq_amd import synth
+    n, k = 150_000, 30
+    codebook16 = synth.make_codebook(16, 256, 8, seed=3)
+    tree = synth.synth_tree(n, 16, seed=77, mean_diffs=5.0)
+    payload, _ = synth.encode_dtc(tree)
+    qs = synth.make_queries(130, 128, seed=78)
+    ids_f, d_f, _, _ = run(gpu, payload, n, codebook16, qs, k, M=16, batch_decode=-1)
+    ids_b, d_b, prof_b, _ = run(gpu, payload, n, codebook16, qs, k, M=16, batch_decode=1)
+    assert prof_b["decode_ms"] > 0.0
+    assert np.array_equal(ids_f, ids_b) and np.array_equal(d_f.view(np.uint32), d_b.view(np.uint32))
+
+
 def test_part_of_a_larger_index_reports_global_positions(gpu, oracle, codebook):
     """dpq_open_opts.global_offset / global_n_codes: a self-contained part of a larger index (what a rank of the
     100 M / 1 B-code runs holds).  ids = offset + local position; the even-N rule applies to the global tail only."""
