@@ -228,7 +228,7 @@ int ensure_workspace(dpq_index* x, int slots, int cap) {
     free_workspace(x);
     int rc;
     if ((rc = dev_alloc(&x->d_lut32, (size_t)slots * x->M * 256))) return rc;
-    if ((rc = dev_alloc(&x->d_lut_min, (size_t)slots * x->M))) return rc;
+    if ((rc = dev_alloc(&x->d_lut_min, (size_t)slots * x->M * 4))) return rc;  // four partial minima per (query, m)
     if ((rc = dev_alloc(&x->d_qtab, (size_t)(slots / dpq::queries_per_group(x->M) + 1) *
                                         (dpq::qtab_bytes_per_group(x->M) / sizeof(uint4)))))
         return rc;
@@ -452,15 +452,6 @@ int run_batch(dpq_index* x, const float* d_queries, int nq, int top_k, int32_t* 
     if ((rc = ensure_workspace(x, nqp, (int)stride))) return rc;
     stride = x->ws_cap;
 
-    {
-        Timer t(x, stream, 0);
-        // also clears the overflow flags of the nqp slots
-        DPQ_HIP(dpq::launch_lut_build(x->d_codebook, d_queries, nq, nqp, x->M, x->K, x->Ds, x->d_lut32, x->d_lut_min,
-                                      nullptr, x->d_overflow, stream));
-    }
-    if (x->prof) x->prof_acc.lut_launches++;
-    x->h_any[flag_slot] = 0;  // the slot is free: its previous batch has been finished
-
     dpq::ScanArgs sa{};
     sa.img = x->img;
     sa.fp32_accum = x->plain ? 1 : 0;
@@ -477,6 +468,17 @@ int run_batch(dpq_index* x, const float* d_queries, int nq, int top_k, int32_t* 
         }
         sa.img.raw = x->d_batch_raw;
     }
+    // (the decode goes first: neither it nor the table build needs LDS, so both run under the previous pipelined
+    // batch's scan; the bootstrap that follows has to wait for that scan's LDS anyway)
+    {
+        Timer t(x, stream, 0);
+        // also clears the overflow flags of the nqp slots
+        DPQ_HIP(dpq::launch_lut_build(x->d_codebook, d_queries, nq, nqp, x->M, x->K, x->Ds, x->d_lut32, x->d_lut_min,
+                                      nullptr, x->d_overflow, stream));
+    }
+    if (x->prof) x->prof_acc.lut_launches++;
+    x->h_any[flag_slot] = 0;  // the slot is free: its previous batch has been finished
+
     sa.lut32 = x->d_lut32;
     sa.lut_min = x->d_lut_min;
     sa.thr_key = x->d_thr_key;

@@ -41,7 +41,7 @@ struct ScanArgs {
     const uint32_t* seg_list;   // segments of this level (a slice of the visiting order), or NULL = all
     int32_t n_seg_pass;
     const float* lut32;         // exact tables [query][m][256] fp32
-    const float* lut_min;       // [query][8] per-sub-space minima of the exact tables
+    const float* lut_min;       // [query][M][4] per-sub-space minima of the exact tables (four partial minima each)
     const uint64_t* thr_key;    // [slots] threshold key of each slot (~0 = keep everything)
     const int32_t* slot_query;  // slot -> query of the batch, NULL = identity, -1 = unused slot (nothing passes)
     int32_t n_queries;          // slots >= n_queries are padding when slot_query == NULL
@@ -105,7 +105,7 @@ struct BootArgs {
     // non-NULL: also write the slot's fields of the first filter level's tables (what quantise_kernel would build
     // from this threshold); the launch then covers the padding slots too
     uint4* qtab;
-    const float* lut_min;          // [query][M]
+    const float* lut_min;          // [query][M][4]
     unsigned long long* stamps;    // developer diagnostics (NULL in product calls): [slots][8] s_memtime marks
 };
 

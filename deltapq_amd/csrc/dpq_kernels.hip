@@ -86,13 +86,18 @@ __device__ __forceinline__ uint64_t make_key(float d, uint32_t id) {
 // flags of the batch (saves two fill launches per batch).
 // ---------------------------------------------------------------------------
 constexpr int kLutQueries = 8;
+constexpr int kLutMinParts = 4;  // per (query, m): one partial minimum per wavefront of the 256-thread block
+
+__device__ __forceinline__ float lut_min_of(const float* __restrict__ lut_min, size_t q, int M, int m) {
+    const float4 p = *reinterpret_cast<const float4*>(lut_min + (q * M + m) * kLutMinParts);
+    return fminf(fminf(p.x, p.y), fminf(p.z, p.w));
+}
 
 __global__ __launch_bounds__(256) void lut_build_kernel(const float* __restrict__ codebook,
                                                          const float* __restrict__ queries, int nq, int n_slots, int M,
                                                          int K, int Ds, float* __restrict__ lut,
                                                          float* __restrict__ lut_min, uint32_t* __restrict__ cand_count,
                                                          uint32_t* __restrict__ overflow) {
-    __shared__ uint32_t wave_min[4][kLutQueries];
     const int q0 = blockIdx.x * kLutQueries, m = blockIdx.y, k = threadIdx.x;
     if (m == 0 && k < kLutQueries && q0 + k < n_slots) {
         if (cand_count) cand_count[q0 + k] = 0;
@@ -142,12 +147,12 @@ __global__ __launch_bounds__(256) void lut_build_kernel(const float* __restrict_
         uint32_t v = __float_as_uint(acc[j]);  // acc >= 0: uint order == float order
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) v = min(v, (uint32_t)__shfl_xor((int)v, o));
-        if ((k & 63) == 0) wave_min[k >> 6][j] = v;
+        // one partial minimum per wavefront: the readers take the least of the four (lut_min_of).  No LDS in this
+        // kernel: the scan fills every CU's LDS to the last KB, and a workgroup that wants even 128 B of it only
+        // starts where a scan workgroup has retired -- the table build of the next pipelined batch then ran in the
+        // scan's tail instead of under it.
+        if ((k & 63) == 0 && q0 + j < nq) lut_min[((size_t)(q0 + j) * M + m) * kLutMinParts + (k >> 6)] = __uint_as_float(v);
     }
-    __syncthreads();
-    if (k < kLutQueries && q0 + k < nq)  // feeds the filter quantisation
-        lut_min[(size_t)(q0 + k) * M + m] =
-            __uint_as_float(min(min(wave_min[0][k], wave_min[1][k]), min(wave_min[2][k], wave_min[3][k])));
 }
 
 // ---------------------------------------------------------------------------
@@ -474,12 +479,12 @@ struct FilterScale {
 };
 
 template <int M>
-__device__ __forceinline__ FilterScale filter_scale(uint64_t key, const float* __restrict__ mins) {
+__device__ __forceinline__ FilterScale filter_scale(uint64_t key, const float* __restrict__ lut_min, size_t q) {
     using C = Cfg<M>;
     FilterScale r{0.0f, 0u};
     double B = 0.0;
 #pragma unroll
-    for (int mm = 0; mm < M; ++mm) B += (double)mins[mm];
+    for (int mm = 0; mm < M; ++mm) B += (double)lut_min_of(lut_min, q, M, mm);
     const double taup = (double)__uint_as_float((uint32_t)(key >> 32)) * (1.0 + 0x1p-20);
     const double R = taup - B;
     if (key != ~0ull && R > 0.0 && R < 1e300) {  // else: no threshold yet (or degenerate), keep everything
@@ -551,8 +556,8 @@ __global__ __launch_bounds__(256) void quantise_kernel(const ScanArgs a) {
         if (qq >= 0 && a.debug_pass != 1) {
             uint64_t key = ~0ull;
             if (a.debug_pass != 2) key = a.thr_key[slot];
-            fs = filter_scale<M>(key, a.lut_min + (size_t)qq * M);
-            mn_m = a.lut_min[(size_t)qq * M + m];
+            fs = filter_scale<M>(key, a.lut_min, (size_t)qq);
+            mn_m = lut_min_of(a.lut_min, (size_t)qq, M, m);
         } else {
             qq = -1;
         }
@@ -1552,8 +1557,8 @@ __global__ __launch_bounds__(kBootThreads, M <= 8 ? 8 : 6) void bootstrap_kernel
         __shared__ float s_scale;
         __shared__ uint32_t s_bias;
         if (tid < M) {
-            const FilterScale fs = filter_scale<M>(kth, a.lut_min + (size_t)q * M);
-            s_of[tid] = filter_offset<M>(fs, a.lut_min[(size_t)q * M + tid], tid);
+            const FilterScale fs = filter_scale<M>(kth, a.lut_min, (size_t)q);
+            s_of[tid] = filter_offset<M>(fs, lut_min_of(a.lut_min, (size_t)q, M, tid), tid);
             if (tid == 0) {
                 s_scale = fs.s32;
                 s_bias = fs.bias;
