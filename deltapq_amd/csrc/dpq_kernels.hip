@@ -831,9 +831,27 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanArgs a) {
     stage2(A);
     stamp(kStSegment);
     while (A.seg >= 0) {
+        // The compiler waits for ALL outstanding loads (vmcnt(0): it cannot count them across the loop's branches) at
+        // the first use of any loaded register, and in program order those waits sat right behind the prefetches of
+        // the later stages -- every wave step paid one (plain codes: 27 % of the wave time in the STAMPS build) or two
+        // (compressed) full memory round trips.  So everything in flight is settled HERE, before this step issues
+        // its prefetches: each load has then been in flight for a whole wave step, and the decode and the filter of
+        // chunk A below run without a memory wait.
+        if constexpr (PLAIN) {
+#pragma unroll
+            for (int w = 0; w < W; ++w) asm volatile("" ::"v"(A.raw[w]), "v"(B.raw[w]));
+        } else {
+            asm volatile("" ::"v"(A.ld.level), "v"(A.ld.mk), "v"(A.ld.par), "v"(A.carry_lane), "v"(B.in.nb), "v"(B.in.mk),
+                         "v"(B.in.par), "v"(B.carry_lane));
+#pragma unroll
+            for (int h = 0; h < W / 2; ++h)
+                asm volatile("" ::"v"(A.ld.w[h][0]), "v"(A.ld.w[h][1]), "v"(A.ld.w[h][2]), "v"(A.ld.t[h].x), "v"(A.ld.t[h].y));
+#pragma unroll
+            for (int w = 0; w < W; ++w) asm volatile("" ::"v"(A.h_stk[w]), "v"(B.h_stk[w]));
+        }
         Cn = successor(B);
-        stage1(Cn);
         stage2(B);
+        stage1(Cn);
         {
             const int64_t node = node_of(A);
             uint32_t code[W];
