@@ -386,13 +386,19 @@ struct Timer {
 };
 
 // plain-code scratch of a shard (per pipeline lane), and whether a batch of n_groups query groups uses it
-constexpr int64_t kBatchRawBudget = (int64_t)256 << 20;
+// Budget of the scratch per pipeline lane: 1 GiB holds one GPU's 125 M-code share of BASELINE configs[4] (measured
+// there: 54.1 k -> 70.8 k queries/s; the scratch is read from HBM at that size, 16 GB per 1000-query batch, still far
+// from the HBM roof).  Tiling the levels would keep it cache-sized (leads).  DPQ_BATCH_RAW_MB overrides.
+int64_t batch_raw_budget() {
+    static const int64_t mb = getenv("DPQ_BATCH_RAW_MB") ? atoll(getenv("DPQ_BATCH_RAW_MB")) : 1024;
+    return mb << 20;
+}
 int64_t batch_raw_bytes(const dpq_index* x) {
     return (int64_t)x->img.n_segments * dpq::kChunk * x->img.chunks_per_segment * x->M;
 }
 bool batch_decode_possible(const dpq_index* x) {
     return !x->plain && x->batch_decode >= 0 && x->img.n_segments > 0 &&
-           (x->batch_decode > 0 || batch_raw_bytes(x) <= kBatchRawBudget);
+           (x->batch_decode > 0 || batch_raw_bytes(x) <= batch_raw_budget());
 }
 bool use_batch_decode(const dpq_index* x, int n_groups) {
     return batch_decode_possible(x) && (x->batch_decode > 0 || n_groups >= 3);

@@ -97,7 +97,7 @@ typedef struct dpq_open_opts {
     int32_t batch_decode;       /* where the delta decode happens.  0 = automatic: a batch of >= 3 query groups (64 queries
                                  * each; 32 at M = 16) decodes the shard ONCE into a plain-code scratch (M bytes per
                                  * node, per pipeline lane; it stays in L2 / Infinity Cache at the headline sizes) that
-                                 * all its groups' filter passes read, when that scratch is <= 256 MB; smaller batches
+                                 * all its groups' filter passes read, when that scratch is <= 1 GiB; smaller batches
                                  * and larger shards decode inside the scan, once per group.  1 = scratch always,
                                  * -1 = never.  Results are identical either way. */
     int64_t global_offset;      /* the payload is a self-contained PART of a larger index (its first node carries a
