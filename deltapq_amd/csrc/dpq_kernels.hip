@@ -10,16 +10,21 @@
 //                           the query's best cells of an inverted multi-index over sub-space
 //                           pairs, evaluated in fp32; an upper bound of the k-th key; also writes
 //                           the slot's fields of the first filter level's tables.
-//   quantise_kernel         conservative 8-bit (16-bit at M = 16) lower-bound tables of a query
-//                           group for one filter level, once per group (later levels, reruns).
+//   quantise_kernel         conservative 8-bit lower-bound tables of a query group for one filter
+//                           level, once per group (later levels, reruns).
+//   decode_all_kernel       a5, batches of >= 3 query groups: the shard decoded ONCE per batch into a
+//                           plain-code scratch (one wavefront per segment) that every group's scan
+//                           pass reads through L2 / Infinity Cache.
 //   scan_kernel             a5 + most of a6: delta decode + ADC filter + exact check.
 //                           One wavefront = one 64-node chunk per step, three chunks in flight
 //                           (software pipeline over the decode's two global round trips); child
 //                           codes are rebuilt from parent + packed deltas by pointer jumping over
 //                           ds_bpermute along parent lanes resolved at load; lower-bound
 //                           distances are LDS table gathers (a lookup workload: no MFMA).  A
-//                           workgroup keeps the filter tables of 64 queries in LDS (16 at
-//                           M = 16) and decodes every chunk once for all of them.  Nodes the
+//                           workgroup keeps the filter tables of 64 queries in LDS (32 at
+//                           M = 16) and decodes every chunk once for all of them -- or, behind
+//                           decode_all_kernel, reads the chunk's plain codes (the <M, PLAIN>
+//                           instantiation, also the -task pqscan comparator).  Nodes the
 //                           filter lets through for some query are queued per wavefront and
 //                           checked exactly (the reference's distance, whole (distance, id)
 //                           keys) against the query's threshold key; what passes is a candidate
@@ -39,8 +44,9 @@
 // low-discrepancy order, every segment exactly once, and keep the nodes whose
 // key is <= the current threshold; a level's k-th best key tightens it.  The
 // in-scan filter is a CONSERVATIVE LOWER BOUND of the distance in 8-bit fixed
-// point (16-bit at M = 16; scaled to the query's threshold, rounded down,
-// saturated), so it never drops a node the exact rule would keep.
+// point (byte entries summed in 16-bit fields at M = 16; scaled to the query's
+// threshold, rounded down, saturated), so it never drops a node the exact rule
+// would keep.
 #include "dpq_kernels.h"
 
 #include <atomic>
