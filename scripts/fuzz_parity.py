@@ -1,5 +1,5 @@
 """Randomised parity stress: HIP path vs oracle over random shapes/options (GPU box).
-usage: python scripts/fuzz_parity.py [seconds] [seed]"""
+usage: python scripts/fuzz_parity.py [seconds] [seed]     (DPQ_FUZZ_BIG=1: also shards of up to 400 K nodes)"""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -14,9 +14,12 @@ cases = bad = 0
 while time.time() < t_end:
     M = int(rng.choice([8, 8, 8, 16]))
     n = int(rng.choice([1, 2, 3, 63, 64, 65, 255, 257, int(rng.integers(300, 3000)), int(rng.integers(3000, 60000))]))
+    if os.environ.get("DPQ_FUZZ_BIG") == "1" and rng.random() < 0.3:
+        n = int(rng.integers(60000, 400000))  # bootstrap shards
     cps = int(rng.choice([1, 2, 4, 4, 8, 16, 64]))
     k = int(min(n, rng.choice([1, 2, 10, 100, 100, 1000, 2048])))
-    nq = int(rng.choice([1, 2, 31, 32, 33, 70]))
+    nq = int(rng.choice([1, 2, 31, 32, 33, 70, 129, 200]))
+    bd = int(rng.choice([-1, 0, 0, 1, 1]))  # dpq_open_opts.batch_decode
     cap = int(rng.choice([0, 0, 0, 64, 300]))
     shards = int(rng.choice([1, 1, 1, 2, 5]))
     K = int(rng.choice([256, 256, 256, 17, 100]))
@@ -28,12 +31,12 @@ while time.time() < t_end:
     tree["root"] = (tree["root"].astype(np.int64) % K).astype(np.uint8)
     payload, nb = synth.encode_dtc(tree)
     qs = synth.make_queries(nq, 128, seed + 2)
-    desc = "M=%d n=%d cps=%d k=%d nq=%d cap=%d shards=%d K=%d md=%.1f seed=%d" % (M, n, cps, k, nq, cap, shards, K, md, seed)
+    desc = "M=%d n=%d cps=%d k=%d nq=%d cap=%d shards=%d K=%d md=%.1f seed=%d batch_decode=%d" % (M, n, cps, k, nq, cap, shards, K, md, seed, bd)
     try:
         parts = []
         for r in range(shards):
             with api.DeltaPQIndex.open_memory(payload, n, M, K, chunks_per_segment=cps, cand_capacity=cap,
-                                              shard_rank=r, shard_count=shards) as idx:
+                                              shard_rank=r, shard_count=shards, batch_decode=bd) as idx:
                 idx.set_codebook(cb)
                 parts.append(idx.query_batch(qs, k))
         if shards > 1:
