@@ -483,6 +483,11 @@ def main():
                               "events (pipelined batches overlap on two lanes there)" % aux_steps,
             },
             "parity_checked_queries": parity,
+            # SURVEY.md 8(d) "report alongside": whole-job rates of the timed regions (median repetition)
+            "rates": {"code_query_pairs_per_s": global_q * args.steps / med * float(all_stats[:, 10].sum()) / (1 if sharded or world == 1 else world),
+                      "raw_pq_equivalent_GBps": global_q * args.steps / med * float(all_stats[:, 10].sum()) / (1 if sharded or world == 1 else world) * args.m / 1e9,
+                      "note": "queries/s x codes each query is compared with (every code, exactly once); x M bytes = the bandwidth "
+                              "a plain PQ scan would need at one query per pass"},
             "index": {"device_bytes_rank0": int(all_stats[0, 3]), "segments_rank0": info["n_segments"],
                       "codes_rank0": int(all_stats[0, 10]), "gen_seconds": wl["gen_s"]},
         }
