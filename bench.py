@@ -431,8 +431,8 @@ def main():
                                    ("stream-ordered steps (dpq_query_batch_device_ordered), no host round trip; no batch had to be answered again"
                                     if state["ordered"] else "one synchronous call per step (a batch overflowed in the stream-ordered run)"),
                 "queries_per_decode_pass": (groups * QG if batch_decoded else QG),
-                "decode": ("once per batch (decode_all_kernel) into %d MB of plain codes that the %d query groups' filter "
-                           "passes read through L2 / Infinity Cache" % (info["batch_decode_mb"], groups)) if batch_decoded
+                "decode": ("once per batch (decode_list_kernel), tile by tile, into %d MB of plain codes that the %d query groups' "
+                           "filter passes read through L2 / Infinity Cache" % (info["batch_decode_mb"], groups)) if batch_decoded
                           else "inside the scan kernel, once per %d-query group" % QG,
                 "threshold_bootstrap": "multi-index, stride %d, %.1f MB" % (info["bootstrap_stride"], info["bootstrap_bytes"] / 1e6)
                                        if info["bootstrap_bytes"] else "off (spread-sample cascade)",

@@ -220,7 +220,8 @@ class DeltaPQIndex:
                   cand_capacity=0, num_codes=0, bootstrap=0, batch_decode=0):
         """num_codes > 0: scan only the first num_codes codes (the reference's -N below the header's n_codes).
         bootstrap: 0 auto, 1 on, -1 off (dpq_open_opts.bootstrap).  batch_decode: 0 auto, 1 always decode once per batch
-        into the plain-code scratch, -1 always decode inside the scan (dpq_open_opts.batch_decode)."""
+        into the plain-code scratch, -1 always decode inside the scan, n >= 2 scratch in tiles of n segments
+        (dpq_open_opts.batch_decode)."""
         lib = _lib.load()
         opts = OpenOpts(device, shard_rank, shard_count, chunks_per_segment, cand_capacity, num_codes, bootstrap, batch_decode)
         h = ctypes.c_void_p()

@@ -386,20 +386,20 @@ struct Timer {
 };
 
 // plain-code scratch of a shard (per pipeline lane), and whether a batch of n_groups query groups uses it
-// Budget of the scratch per pipeline lane: 1 GiB holds one GPU's 125 M-code share of BASELINE configs[4] (measured
-// there: 54.1 k -> 70.8 k queries/s; the scratch is read from HBM at that size, 16 GB per 1000-query batch, still far
-// from the HBM roof).  Tiling the levels would keep it cache-sized (leads).  DPQ_BATCH_RAW_MB overrides.
-int64_t batch_raw_budget() {
-    static const int64_t mb = getenv("DPQ_BATCH_RAW_MB") ? atoll(getenv("DPQ_BATCH_RAW_MB")) : 1024;
-    return mb << 20;
+// Plain-code scratch of a batch (per pipeline lane): one TILE of a filter level's segment list at a time -- decode the
+// tile, scan it with every query group, next tile -- so the scratch stays Infinity-Cache-sized whatever the shard
+// (16 M nodes = 128 MB at M = 8; the 1 M-code headline and a 12.5 M-code shard are one tile, a 125 M-code shard's
+// last level eight).  DPQ_BATCH_TILE_NODES overrides; dpq_open_opts.batch_decode >= 2 = tile of that many segments.
+int64_t batch_tile_segments(const dpq_index* x) {
+    static const int64_t env_nodes = getenv("DPQ_BATCH_TILE_NODES") ? atoll(getenv("DPQ_BATCH_TILE_NODES")) : 0;
+    const int64_t S = (int64_t)dpq::kChunk * x->img.chunks_per_segment;
+    int64_t t = x->batch_decode >= 2 ? x->batch_decode : std::max<int64_t>(1, (env_nodes > 0 ? env_nodes : ((int64_t)16 << 20)) / S);
+    return std::min<int64_t>(t, std::max<int64_t>(1, x->img.n_segments));
 }
 int64_t batch_raw_bytes(const dpq_index* x) {
-    return (int64_t)x->img.n_segments * dpq::kChunk * x->img.chunks_per_segment * x->M;
+    return batch_tile_segments(x) * dpq::kChunk * x->img.chunks_per_segment * x->M;
 }
-bool batch_decode_possible(const dpq_index* x) {
-    return !x->plain && x->batch_decode >= 0 && x->img.n_segments > 0 &&
-           (x->batch_decode > 0 || batch_raw_bytes(x) <= batch_raw_budget());
-}
+bool batch_decode_possible(const dpq_index* x) { return !x->plain && x->batch_decode >= 0 && x->img.n_segments > 0; }
 bool use_batch_decode(const dpq_index* x, int n_groups) {
     return batch_decode_possible(x) && (x->batch_decode > 0 || n_groups >= 3);
 }
@@ -466,16 +466,21 @@ int run_batch(dpq_index* x, const float* d_queries, int nq, int top_k, int32_t* 
     // sizes) -- the scan kernel then runs its plain-code instantiation with the DTC distance rule; a batch of one or
     // two groups, or a shard whose plain codes exceed the scratch budget, decodes inside the scan, once per group.
     // Measured on 1 M codes x 1000 queries (16 groups): scan 0.166 -> 0.122 ms, step 0.212 -> 0.172 ms.
-    if (use_batch_decode(x, ngroups)) {
-        if ((rc = ensure_batch_raw(x))) return rc;
+    const bool scratch = use_batch_decode(x, ngroups);
+    if (scratch && (rc = ensure_batch_raw(x))) return rc;
+    const int64_t tile_segs = scratch ? batch_tile_segments(x) : 0;
+    // One tile covers the whole shard (the common case): it is decoded here, ahead of the table build, so that both
+    // run under the previous pipelined batch's scan (neither needs LDS; the bootstrap that follows has to wait for
+    // that scan's LDS anyway), and every level scans its slice of the shard-ordered scratch.  Otherwise each level
+    // decodes its own tiles in list order.
+    const bool one_tile = scratch && tile_segs >= x->img.n_segments;
+    if (one_tile) {
         {
             Timer t(x, stream, 4);
-            DPQ_HIP(dpq::launch_decode_all(x->img, reinterpret_cast<uint32_t*>(x->d_batch_raw), stream));
+            DPQ_HIP(dpq::launch_decode_list(x->img, nullptr, x->img.n_segments, reinterpret_cast<uint32_t*>(x->d_batch_raw), stream));
         }
         sa.img.raw = x->d_batch_raw;
     }
-    // (the decode goes first: neither it nor the table build needs LDS, so both run under the previous pipelined
-    // batch's scan; the bootstrap that follows has to wait for that scan's LDS anyway)
     {
         Timer t(x, stream, 0);
         // also clears the overflow flags of the nqp slots
@@ -587,7 +592,32 @@ int run_batch(dpq_index* x, const float* d_queries, int nq, int top_k, int32_t* 
                 Timer t(x, stream, 3);
                 DPQ_HIP(dpq::launch_quantise(sa, ngroups, stream));
             }
-            {
+            if (scratch && !one_tile) {
+                // the level's list in tiles: decode a tile into the scratch (list order), scan it with all groups
+                const uint32_t* list = sa.seg_list;
+                const int total = sa.n_seg_pass;
+                for (int t0 = 0; t0 < total; t0 += (int)tile_segs) {
+                    const int cnt = std::min<int>((int)tile_segs, total - t0);
+                    {
+                        Timer t(x, stream, 4);
+                        DPQ_HIP(dpq::launch_decode_list(x->img, list + t0, cnt, reinterpret_cast<uint32_t*>(x->d_batch_raw), stream));
+                    }
+                    sa.img.raw = x->d_batch_raw;
+                    sa.raw_by_pos = 1;
+                    sa.append = t0 > 0 ? 1 : 0;
+                    sa.seg_list = list + t0;
+                    sa.n_seg_pass = cnt;
+                    {
+                        Timer t(x, stream, 1);
+                        DPQ_HIP(dpq::launch_scan(sa, ngroups, rg.splits, stream));
+                    }
+                    if (x->prof && t0 > 0) x->prof_acc.scan_launches++;
+                }
+                sa.img.raw = nullptr;
+                sa.raw_by_pos = sa.append = 0;
+                sa.seg_list = list;
+                sa.n_seg_pass = total;
+            } else {
                 Timer t(x, stream, 1);
                 DPQ_HIP(dpq::launch_scan(sa, ngroups, rg.splits, stream));
             }
@@ -668,6 +698,7 @@ int run_batch(dpq_index* x, const float* d_queries, int nq, int top_k, int32_t* 
         chk(hipMemsetAsync(c_over, 0, sizeof(uint32_t) * slots2, stream));
         sa.seg_list = nullptr;
         sa.n_seg_pass = x->img.n_segments;
+        if (!one_tile) sa.img.raw = x->img.raw;  // a tiled scratch holds the last tile only: the rerun decodes inside the scan
         sa.thr_key = c_tk;
         sa.slot_query = d_slot_query;
         sa.n_queries = slots2;

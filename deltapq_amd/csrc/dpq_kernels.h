@@ -46,6 +46,8 @@ struct ScanArgs {
     const int32_t* slot_query;  // slot -> query of the batch, NULL = identity, -1 = unused slot (nothing passes)
     int32_t n_queries;          // slots >= n_queries are padding when slot_query == NULL
     int32_t debug_pass;         // developer experiments: 0 normal, 1 nothing passes, 2 everything passes
+    int32_t raw_by_pos;         // img.raw is the per-batch scratch of THIS launch's list: entry s of seg_list at position s
+    int32_t append;             // the launch continues a level: region counts start from cand_count instead of 0
     int32_t fp32_accum;         // plain index (-task pqscan): exact distances are fp32 sums in position order (h:2658-2662)
     // candidate buffer of a slot: [region 0: winners carried from the previous level, region_off keys]
     // [region 1 + s: what workgroup (split) s of this launch found, region_cap keys each]
@@ -114,7 +116,8 @@ struct BootArgs {
 hipError_t launch_lut_build(const float* d_codebook, const float* d_queries, int nq, int n_slots, int M, int K, int Ds,
                             float* d_lut32, float* d_lut_min, uint32_t* d_cand_count, uint32_t* d_overflow,
                             hipStream_t stream);
-hipError_t launch_decode_all(const DeviceImage& img, uint32_t* out_code, hipStream_t stream);
+hipError_t launch_decode_list(const DeviceImage& img, const uint32_t* seg_list, int n_seg, uint32_t* out_code,
+                              hipStream_t stream);
 hipError_t launch_decode_segments(const DeviceImage& img, const uint32_t* seg_list, int n_seg, uint32_t* out_id,
                                   uint32_t* out_code, hipStream_t stream);
 // launch_quantise builds the level's filter tables of every query group (needs the level's thresholds in

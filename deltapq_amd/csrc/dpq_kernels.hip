@@ -12,9 +12,9 @@
 //                           the slot's fields of the first filter level's tables.
 //   quantise_kernel         conservative 8-bit lower-bound tables of a query group for one filter
 //                           level, once per group (later levels, reruns).
-//   decode_all_kernel       a5, batches of >= 3 query groups: the shard decoded ONCE per batch into a
-//                           plain-code scratch (one wavefront per segment) that every group's scan
-//                           pass reads through L2 / Infinity Cache.
+//   decode_list_kernel      a5, batches of >= 3 query groups: a tile of a filter level's segment list decoded
+//                           ONCE into a plain-code scratch (one wavefront per segment) that every group's
+//                           scan pass reads through L2 / Infinity Cache.
 //   scan_kernel             a5 + most of a6: delta decode + ADC filter + exact check.
 //                           One wavefront = one 64-node chunk per step, three chunks in flight
 //                           (software pipeline over the decode's two global round trips); child
@@ -23,7 +23,7 @@
 //                           distances are LDS table gathers (a lookup workload: no MFMA).  A
 //                           workgroup keeps the filter tables of 64 queries in LDS (32 at
 //                           M = 16) and decodes every chunk once for all of them -- or, behind
-//                           decode_all_kernel, reads the chunk's plain codes (the <M, PLAIN>
+//                           decode_list_kernel, reads the chunk's plain codes (the <M, PLAIN>
 //                           instantiation, also the -task pqscan comparator).  Nodes the
 //                           filter lets through for some query are queued per wavefront and
 //                           checked exactly (the reference's distance, whole (distance, id)
@@ -415,25 +415,28 @@ __global__ __launch_bounds__(64) void decode_segments_kernel(const DeviceImage i
     }
 }
 
-// The whole shard, decoded into plain codes [n_segments * S][M] (padded to whole segments): one wavefront per
-// segment.  grid = ceil(n_segments / 4), block = 256.
+// Segments decoded into plain codes, one wavefront per segment: entry j of seg_list (NULL: segment j) goes to
+// position j of the scratch, [n_seg * S][M].  grid = ceil(n_seg / 4), block = 256.
 template <int M>
-__global__ __launch_bounds__(256) void decode_all_kernel(const DeviceImage img, uint32_t* __restrict__ out_code) {
+__global__ __launch_bounds__(256) void decode_list_kernel(const DeviceImage img, const uint32_t* __restrict__ seg_list,
+                                                           int n_seg, uint32_t* __restrict__ out_code) {
     constexpr int W = Cfg<M>::W;
     const int lane = threadIdx.x & 63;
-    const int64_t seg = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (seg >= img.n_segments) return;
+    const int64_t j = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (j >= n_seg) return;
+    const int64_t seg = seg_list ? (int64_t)seg_list[j] : j;
     const int cps = img.chunks_per_segment;
     WaveDecoder<M> dec;
     dec.begin_segment(img, (uint32_t)seg, lane);
     for (int c = 0; c < cps; ++c) {
         const int64_t node = (seg * cps + c) * 64 + lane;
+        const int64_t out = (j * cps + c) * 64 + lane;
         uint32_t code[W];
         dec.step(img, node, lane, c + 1 < cps, code);
         if constexpr (W == 2)
-            reinterpret_cast<uint2*>(out_code)[node] = make_uint2(code[0], code[1]);
+            reinterpret_cast<uint2*>(out_code)[out] = make_uint2(code[0], code[1]);
         else
-            reinterpret_cast<uint4*>(out_code)[node] = make_uint4(code[0], code[1], code[2], code[3]);
+            reinterpret_cast<uint4*>(out_code)[out] = make_uint4(code[0], code[1], code[2], code[3]);
     }
 }
 
@@ -680,7 +683,8 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanArgs a) {
         }
         s_base[tid] = qq >= 0 ? qq * TE : -1;
         s_thr[tid] = key;
-        wg_count[tid] = 0;
+        // a level scanned in several launches (tiles of its segment list) keeps appending to its regions
+        wg_count[tid] = a.append ? a.cand_count[(size_t)slot * kRegionStride + 1 + split] : 0u;
         if (tid == 0) {
             *wg_checks = 0;
             *wg_next = 0;
@@ -768,12 +772,14 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanArgs a) {
     // list entry s -> workgroup s % splits (a short list still reaches every workgroup); inside the
     // workgroup the wavefronts draw their next entry from an LDS counter, so a wavefront that met
     // segments with many filter survivors does not hold the others back
+    int entry_pos = 0;  // list position of the entry next_entry() returned last (the plain-code scratch is laid out by it)
     auto next_entry = [&]() -> int {  // wave-uniform: the next segment of this wavefront, -1 = the list is used up
         int j = 0;
         if (lane == 0) j = (int)atomicAdd(wg_next, 1u);
         j = __builtin_amdgcn_readfirstlane(j);
         const int s = split + (int)gridDim.x * j;
         if (s >= a.n_seg_pass) return -1;
+        entry_pos = s;
         return __builtin_amdgcn_readfirstlane(a.seg_list ? (int)a.seg_list[s] : s);
     };
     // Software pipeline over the chunks this wavefront draws: while chunk A is decoded and filtered, the
@@ -782,6 +788,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanArgs a) {
     // wavefront spent most of its time on (STAMPS build: decode 47 % of the wave time).
     struct Chunk {
         int seg, c;                       // wave-uniform; seg < 0: no chunk
+        int pos;                          // PLAIN: list position of the segment
         typename WaveDecoder<M>::In in;   // stage 1
         uint32_t carry_lane;              // stage 1 (lanes 0..LEVELS-1): the chunk's last node of depth `lane`, 0xFF = none
         uint64_t h_doff;                  // stage 1, first chunk of a segment: offset of its first changed byte,
@@ -795,7 +802,11 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanArgs a) {
         const int64_t node = node_of(k);
         if (PLAIN) {  // uncompressed comparator (h:2590-2678): the code is simply there
 #pragma unroll
-            for (int w = 0; w < W; ++w) k.raw[w] = reinterpret_cast<const uint32_t*>(a.img.raw)[(size_t)node * W + w];
+            for (int w = 0; w < W; ++w) {
+                // the codes of a plain index lie in node order, the per-batch scratch in the order of the launch's list
+                const int64_t at = a.raw_by_pos ? ((int64_t)k.pos * cps + k.c) * 64 + lane : node;
+                k.raw[w] = reinterpret_cast<const uint32_t*>(a.img.raw)[(size_t)at * W + w];
+            }
         } else {
             k.in = WaveDecoder<M>::load_in(a.img, node);
             k.carry_lane = 0xffu;
@@ -821,15 +832,18 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanArgs a) {
     auto successor = [&](const Chunk& k) {
         Chunk n;
         n.seg = k.seg;
+        n.pos = k.pos;
         n.c = k.c + 1;
         if (k.seg >= 0 && n.c == cps) {
             n.seg = next_entry();
+            n.pos = entry_pos;
             n.c = 0;
         }
         return n;
     };
     Chunk A, B, Cn;
     A.seg = next_entry();
+    A.pos = entry_pos;
     A.c = 0;
     stage1(A);
     B = successor(A);
@@ -973,10 +987,10 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanArgs a) {
     // ---- epilogue: this workgroup's candidate counts (a count above region_cap tells the select
     // kernel that candidates were dropped) ----
     __syncthreads();
-    if (tid < QG) a.cand_count[(size_t)(slot0 + tid) * kRegionStride + 1 + split] = wg_count[tid];
     if (a.counters && tid < 64) {  // statistics: one pair of global atomics per workgroup
         uint32_t c = 0;
-        for (int q = tid; q < QG; q += 64) c += wg_count[q];
+        for (int q = tid; q < QG; q += 64)
+            c += wg_count[q] - (a.append ? a.cand_count[(size_t)(slot0 + q) * kRegionStride + 1 + split] : 0u);
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) c += (uint32_t)__shfl_xor((int)c, off, 64);
         if (tid == 0) {
@@ -984,6 +998,8 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanArgs a) {
             atomicAdd(&a.counters[1], (unsigned long long)c);
         }
     }
+    __syncthreads();  // the statistics above read the counts this launch started from
+    if (tid < QG) a.cand_count[(size_t)(slot0 + tid) * kRegionStride + 1 + split] = wg_count[tid];
     if constexpr (STAMPS) {
         st[kStTotal] = __builtin_amdgcn_s_memtime() - t_start;
         st[kStWaves] = 1;
@@ -1772,13 +1788,14 @@ hipError_t launch_decode_segments(const DeviceImage& img, const uint32_t* seg_li
     return hipGetLastError();
 }
 
-hipError_t launch_decode_all(const DeviceImage& img, uint32_t* out_code, hipStream_t stream) {
-    if (img.n_segments <= 0) return hipSuccess;
-    const unsigned grid = (unsigned)((img.n_segments + 3) / 4);
+hipError_t launch_decode_list(const DeviceImage& img, const uint32_t* seg_list, int n_seg, uint32_t* out_code,
+                              hipStream_t stream) {
+    if (n_seg <= 0) return hipSuccess;
+    const unsigned grid = (unsigned)((n_seg + 3) / 4);
     if (img.M == 8)
-        hipLaunchKernelGGL(decode_all_kernel<8>, dim3(grid), dim3(256), 0, stream, img, out_code);
+        hipLaunchKernelGGL(decode_list_kernel<8>, dim3(grid), dim3(256), 0, stream, img, seg_list, n_seg, out_code);
     else if (img.M == 16)
-        hipLaunchKernelGGL(decode_all_kernel<16>, dim3(grid), dim3(256), 0, stream, img, out_code);
+        hipLaunchKernelGGL(decode_list_kernel<16>, dim3(grid), dim3(256), 0, stream, img, seg_list, n_seg, out_code);
     else
         return hipErrorInvalidValue;
     return hipGetLastError();

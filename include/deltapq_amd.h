@@ -95,11 +95,13 @@ typedef struct dpq_open_opts {
                                  * cascade alone).  Results are identical either way.  dpq_soa_build: > 0 = build the
                                  * multi-index with this sampling stride. */
     int32_t batch_decode;       /* where the delta decode happens.  0 = automatic: a batch of >= 3 query groups (64 queries
-                                 * each; 32 at M = 16) decodes the shard ONCE into a plain-code scratch (M bytes per
-                                 * node, per pipeline lane; it stays in L2 / Infinity Cache at the headline sizes) that
-                                 * all its groups' filter passes read, when that scratch is <= 1 GiB; smaller batches
-                                 * and larger shards decode inside the scan, once per group.  1 = scratch always,
-                                 * -1 = never.  Results are identical either way. */
+                                 * each; 32 at M = 16) decodes every segment ONCE, tile by tile (16 M nodes of a filter
+                                 * level's segment list at a time; a shard up to that size is one tile), into a
+                                 * plain-code scratch (M bytes per node of a tile, per pipeline lane: at most 128 MB at
+                                 * M = 8, cache-resident) that all its groups' filter passes read; smaller batches
+                                 * decode inside the scan, once per group.  1 = scratch always, -1 = never,
+                                 * n >= 2 = scratch always with tiles of n segments (testing aid).  Results are
+                                 * identical either way. */
     int64_t global_offset;      /* the payload is a self-contained PART of a larger index (its first node carries a
                                  * whole code): ids are reported as global_offset + position in this payload */
     int64_t global_n_codes;     /* 0 = this payload is the whole index; else N of the larger index (the even-N id
@@ -121,8 +123,8 @@ typedef struct dpq_info {
     int32_t cand_capacity;
     int64_t bootstrap_bytes;   /* HBM bytes of the threshold-bootstrap multi-index (0 = not in use) */
     int32_t bootstrap_stride;  /* every bootstrap_stride-th node is in it */
-    int32_t batch_decode_mb;   /* MB of plain-code scratch a batch decodes into (per pipeline lane; 0 = this shard always
-                                * decodes inside the scan) */
+    int32_t batch_decode_mb;   /* MB of plain-code scratch (one tile, per pipeline lane) a batch decodes into; 0 = this
+                                * handle always decodes inside the scan */
 } dpq_info;
 
 /* Per-kernel device time accumulated since the last dpq_profile_reset, measured

@@ -35,10 +35,10 @@ scans = [(v.get("stats", {}).get("calls", 0), k, v) for k, v in summary["kernels
 sc = max(scans)[2] if scans else {}
 if scans:
     summary["scan_kernel_instantiation"] = max(scans)[1]
-dk = next((v for k, v in summary["kernels"].items() if k.startswith("dpq::decode_all_kernel")), {})
+dk = next((v for k, v in summary["kernels"].items() if k.startswith("dpq::decode_list_kernel")), {})
 if "FETCH_SIZE" in dk and "WRITE_SIZE" in dk:
-    summary["decode_all_kernel_hbm_bytes_per_launch"] = 2 * dk["FETCH_SIZE"]["mean_kib"] * 1024 + dk["WRITE_SIZE"]["mean_kib"] * 1024
-    summary["decode_all_kernel_avg_launch_ms_kernel_trace"] = dk["stats"]["avg_ns"] / 1e6
+    summary["decode_list_kernel_hbm_bytes_per_launch"] = 2 * dk["FETCH_SIZE"]["mean_kib"] * 1024 + dk["WRITE_SIZE"]["mean_kib"] * 1024
+    summary["decode_list_kernel_avg_launch_ms_kernel_trace"] = dk["stats"]["avg_ns"] / 1e6
 if "FETCH_SIZE" in sc and "WRITE_SIZE" in sc:
     summary["scan_kernel_hbm_bytes_per_launch"] = 2 * sc["FETCH_SIZE"]["mean_kib"] * 1024 + sc["WRITE_SIZE"]["mean_kib"] * 1024
     summary["scan_kernel_hbm_bytes_per_launch_uncorrected"] = (sc["FETCH_SIZE"]["mean_kib"] + sc["WRITE_SIZE"]["mean_kib"]) * 1024
@@ -47,7 +47,7 @@ if "FETCH_SIZE" in sc and "WRITE_SIZE" in sc:
     summary["scan_kernel_hbm_GBps"] = summary["scan_kernel_hbm_bytes_per_launch"] / (summary["scan_kernel_avg_launch_ms_kernel_trace"] * 1e-3) / 1e9
 summary["bench_line_under_rocprof"] = {k: line[k] for k in ("value", "ms_per_step", "repetitions") if k in line}
 json.dump(summary, open("%s/%s_pmc_summary.json" % (out, tag), "w"), indent=1)
-print(json.dumps({k: summary[k] for k in summary if k.startswith("scan_kernel") or k.startswith("decode_all")}, indent=1))
+print(json.dumps({k: summary[k] for k in summary if k.startswith("scan_kernel") or k.startswith("decode_list")}, indent=1))
 for k, v in summary["kernels"].items():
     if "stats" in v and k.startswith("dpq::") and "anonymous" not in k:
         print("%-46s calls %5d avg %9.1f us" % (k[:46], v["stats"]["calls"], v["stats"]["avg_ns"] / 1e3))

@@ -482,7 +482,7 @@ def test_bench_survives_an_unusable_rccl(gpu, built):
 
 @pytest.mark.parametrize("n,cps", [(200_000, 0), (70_001, 4), (9_000, 1)])
 def test_batch_decode_modes_agree(gpu, oracle, codebook, n, cps):
-    """dpq_open_opts.batch_decode: decoding the shard once per batch into the plain-code scratch (decode_all_kernel +
+    """dpq_open_opts.batch_decode: decoding the shard once per batch into the plain-code scratch (decode_list_kernel +
     the scan's plain-code instantiation with the DTC distance rule) and decoding inside the scan give identical lists;
     automatic = scratch from three query groups on.  Shapes: bootstrap shard, odd N with 4-chunk segments, small
     cascade shard (level 0 included)."""
@@ -500,6 +500,24 @@ def test_batch_decode_modes_agree(gpu, oracle, codebook, n, cps):
     ids_s, d_s, prof_s, _ = run(gpu, payload, n, codebook, qs[:128], k, chunks_per_segment=cps)        # 2 groups: inside the scan
     assert prof_s["decode_ms"] == 0.0 and np.array_equal(ids_s, ids_b[:128]) and np.array_equal(d_s.view(np.uint32), d_b[:128].view(np.uint32))
     assert_parity(ids_b[:12], d_b[:12], oracle_topk(oracle, payload, n, codebook, qs[:12], k), n)
+
+
+@pytest.mark.parametrize("n,tile,k", [(300_000, 37, 60), (2_600_000, 3000, 100)])
+def test_batch_decode_in_tiles(gpu, oracle, codebook, n, tile, k):
+    """The scratch one TILE of a level's segment list at a time (dpq_open_opts.batch_decode = tile segments): the
+    scan addresses the scratch by list position and a level's launches append to its candidate regions.  A
+    single-level shard in 64 tiles, and a shard beyond 2 M nodes (two filter levels in the golden-ratio visiting
+    order, tiles that straddle nothing: each level is tiled on its own)."""
+    from deltapq_amd import synth
+    tree, payload, _ = make_case(n, seed=91)
+    qs = synth.make_queries(200, 128, seed=92)
+    ids_f, d_f, prof_f, _ = run(gpu, payload, n, codebook, qs, k, batch_decode=-1)
+    ids_t, d_t, prof_t, info_t = run(gpu, payload, n, codebook, qs, k, batch_decode=tile)
+    assert np.array_equal(ids_f, ids_t) and np.array_equal(d_f.view(np.uint32), d_t.view(np.uint32))
+    assert prof_t["decode_ms"] > 0.0 and prof_t["scan_launches"] >= -(-info_t["n_segments"] // tile)
+    assert info_t["batch_decode_mb"] == -(-tile * 64 * info_t["chunks_per_segment"] * 8 // (1 << 20))
+    assert prof_t["exact_checks"] == prof_f["exact_checks"] and prof_t["candidates"] == prof_f["candidates"]
+    assert_parity(ids_t[:6], d_t[:6], oracle_topk(oracle, payload, n, codebook, qs[:6], k), n)
 
 
 def test_batch_decode_m16(gpu):
