@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <numeric>
 #include <stdexcept>
 #include <string>
 #include <type_traits>
@@ -1721,6 +1722,9 @@ int dpq_debug_scan_time(dpq_index* x, int nq, int pass_all, int reps, int splits
     sa.debug_pass = pass_all == 2 ? 0 : (pass_all ? 2 : 1);  // 2: the thresholds the last batch left behind
     sa.seg_list = nullptr;
     sa.n_seg_pass = x->img.n_segments;
+    // what the last batch ran: its plain-code scratch, if it decoded the whole shard into one
+    if (!x->plain && x->d_batch_raw && batch_tile_segments(x) >= x->img.n_segments && !getenv("DPQ_DEBUG_FUSED"))
+        sa.img.raw = x->d_batch_raw;
     if (const char* e = getenv("DPQ_DEBUG_NSEG")) sa.n_seg_pass = std::min(x->img.n_segments, atoi(e));
     if (splits <= 0) splits = splits_for(sa.n_seg_pass, nqp / QG);
     sa.cand_count = x->d_cand_count;
@@ -1743,6 +1747,33 @@ int dpq_debug_scan_time(dpq_index* x, int nq, int pass_all, int reps, int splits
     *ms_out = ms / reps;
     hipEventDestroy(a);
     hipEventDestroy(b);
+    if (getenv("DPQ_DEBUG_WG_TIMES")) {  // when do the workgroups of one launch start and end?
+        const int nwg = splits * (nqp / QG);
+        unsigned long long* d_t = nullptr;
+        int rc = dev_alloc(&d_t, (size_t)nwg * 2);
+        if (rc) return rc;
+        sa.wg_times = d_t;
+        DPQ_HIP(dpq::launch_scan(sa, nqp / QG, splits, nullptr));
+        DPQ_HIP(hipDeviceSynchronize());
+        std::vector<unsigned long long> h((size_t)nwg * 2);
+        DPQ_HIP(hipMemcpy(h.data(), d_t, h.size() * 8, hipMemcpyDeviceToHost));
+        hipFree(d_t);
+        unsigned long long t0 = ~0ull, t1 = 0;
+        for (int i = 0; i < nwg; ++i) t0 = std::min(t0, h[2 * (size_t)i]), t1 = std::max(t1, h[2 * (size_t)i + 1]);
+        std::vector<double> st, en, life;
+        for (int i = 0; i < nwg; ++i) {
+            st.push_back((double)(h[2 * (size_t)i] - t0) / 100.0);
+            en.push_back((double)(h[2 * (size_t)i + 1] - t0) / 100.0);
+            life.push_back(en.back() - st.back());
+        }
+        std::sort(st.begin(), st.end()); std::sort(en.begin(), en.end()); std::sort(life.begin(), life.end());
+        auto pct = [&](const std::vector<double>& v, double p) { return v[(size_t)(p * (v.size() - 1))]; };
+        fprintf(stderr, "scan workgroups (%d, %s codes): span %.1f us; start p50 %.1f max %.1f; end min %.1f p10 %.1f p50 %.1f p90 %.1f max %.1f; "
+                        "lifetime min %.1f p50 %.1f max %.1f us; busy %.1f %%\n", nwg, sa.img.raw ? "plain" : "compressed",
+                (double)(t1 - t0) / 100.0, pct(st, 0.5), st.back(), en.front(), pct(en, 0.1), pct(en, 0.5), pct(en, 0.9), en.back(),
+                life.front(), pct(life, 0.5), life.back(),
+                100.0 * std::accumulate(life.begin(), life.end(), 0.0) / (nwg * (double)(t1 - t0) / 100.0));
+    }
     return DPQ_OK;
     });
 }

@@ -46,6 +46,7 @@ struct ScanArgs {
     const int32_t* slot_query;  // slot -> query of the batch, NULL = identity, -1 = unused slot (nothing passes)
     int32_t n_queries;          // slots >= n_queries are padding when slot_query == NULL
     int32_t debug_pass;         // developer experiments: 0 normal, 1 nothing passes, 2 everything passes
+    unsigned long long* wg_times;  // developer diagnostics: [workgroups][2] start / end on the 100 MHz clock (NULL = off)
     int32_t raw_by_pos;         // img.raw is the per-batch scratch of THIS launch's list: entry s of seg_list at position s
     int32_t append;             // the launch continues a level: region counts start from cand_count instead of 0
     int32_t fp32_accum;         // plain index (-task pqscan): exact distances are fp32 sums in position order (h:2658-2662)

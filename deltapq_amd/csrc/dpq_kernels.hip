@@ -655,6 +655,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanArgs a) {
         }
     };
     if constexpr (STAMPS) t_start = t_mark = __builtin_amdgcn_s_memtime();
+    if (a.wg_times && tid == 0) a.wg_times[2 * (blockIdx.y * gridDim.x + blockIdx.x)] = __builtin_amdgcn_s_memrealtime();
 
     // Workgroups are dealt to the 8 XCDs round-robin in launch order (observed; speed only).  All
     // workgroups of a query group read the same filter tables and exact tables (QG * M KB), so give each
@@ -716,6 +717,9 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanArgs a) {
     int rq_head = 0, rq_n = 0;  // wave-uniform
     const size_t region0 = (size_t)a.region_off + (size_t)split * a.region_cap;  // this workgroup's region in a slot's buffer
     auto bit_slot = [](int p) { return (p >> 5) * (C::J * F) + ((p & 31) / EB) * C::J + (p % EB); };  // bit -> local slot
+    // survivor bits a lane checks per round (their table gathers, M each from L2, are in flight together); 3, 4 and 6
+    // per round measured the same step time as 2
+    constexpr int RB = 2;
     auto refine = [&](int n) {
         __builtin_amdgcn_wave_barrier();  // ring entries were written by other lanes of this wavefront
         int i = rq_head + lane;
@@ -741,19 +745,19 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanArgs a) {
             if constexpr (STAMPS) st[kStEntries] += pc;
         }
         while (__ballot(pend != 0)) {
-            int ls[2];
-            bool has[2];
-            float d[2];
+            int ls[RB];
+            bool has[RB];
+            float d[RB];
 #pragma unroll
-            for (int e = 0; e < 2; ++e) {
+            for (int e = 0; e < RB; ++e) {
                 has[e] = pend != 0;
                 ls[e] = has[e] ? bit_slot(__ffsll((unsigned long long)pend) - 1) : 0;
                 pend &= pend - 1;  // 0 stays 0
             }
 #pragma unroll
-            for (int e = 0; e < 2; ++e) d[e] = has[e] ? exact_dist<M>(a.lut32 + s_base[ls[e]], c, PLAIN && a.fp32_accum != 0) : 0.0f;
+            for (int e = 0; e < RB; ++e) d[e] = has[e] ? exact_dist<M>(a.lut32 + s_base[ls[e]], c, PLAIN && a.fp32_accum != 0) : 0.0f;
 #pragma unroll
-            for (int e = 0; e < 2; ++e) {
+            for (int e = 0; e < RB; ++e) {
                 const uint64_t key = make_key(d[e], eid);
                 if (has[e] && key <= s_thr[ls[e]]) {
                     const uint32_t li = atomicAdd(&wg_count[ls[e]], 1u);
@@ -1000,6 +1004,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanArgs a) {
     }
     __syncthreads();  // the statistics above read the counts this launch started from
     if (tid < QG) a.cand_count[(size_t)(slot0 + tid) * kRegionStride + 1 + split] = wg_count[tid];
+    if (a.wg_times && tid == 0) a.wg_times[2 * (blockIdx.y * gridDim.x + blockIdx.x) + 1] = __builtin_amdgcn_s_memrealtime();
     if constexpr (STAMPS) {
         st[kStTotal] = __builtin_amdgcn_s_memtime() - t_start;
         st[kStWaves] = 1;
