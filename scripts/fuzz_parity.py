@@ -19,7 +19,7 @@ while time.time() < t_end:
     cps = int(rng.choice([1, 2, 4, 4, 8, 16, 64]))
     k = int(min(n, rng.choice([1, 2, 10, 100, 100, 1000, 2048])))
     nq = int(rng.choice([1, 2, 31, 32, 33, 70, 129, 200]))
-    bd = int(rng.choice([-1, 0, 0, 1, 1]))  # dpq_open_opts.batch_decode
+    bd = int(rng.choice([-1, 0, 0, 1, 1, 2, 5, 37, 300]))  # dpq_open_opts.batch_decode (>= 2: scratch tiles of that many segments)
     cap = int(rng.choice([0, 0, 0, 64, 300]))
     shards = int(rng.choice([1, 1, 1, 2, 5]))
     K = int(rng.choice([256, 256, 256, 17, 100]))
