@@ -212,6 +212,8 @@ def main():
                     help="N > 1: 'index' (= auto) cuts the index into DFS ranges, every GPU answers the one batch on its "
                          "range, one all-gather + merge (strong scaling, the north-star decomposition); 'query' = every GPU "
                          "holds the whole index and answers its own batch (weak scaling, no collective)")
+    ap.add_argument("--sharded-streams", type=int, default=2,
+                    help="index shards: stream-ordered steps alternate between this many torch streams (1 or 2)")
     ap.add_argument("--no-replicas", action="store_true",
                     help="N > 1 index shards of an index every rank could hold whole: skip the query-replica run timed beside it")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
@@ -293,12 +295,28 @@ def main():
     pipelined = not sharded
     state = {"ordered": sharded, "reruns": 0}
 
+    # Stream-ordered sharded steps alternate between two torch streams: the library gives each caller stream one of
+    # its two workspaces, so step i + 1's decode / table build run under step i's scan and its bootstrap beside step
+    # i's select, while every step's exchange (pack -> all-gather -> merge) still follows its own batch in stream order.
+    n_step_streams = max(1, min(2, args.sharded_streams)) if sharded else 1
+    step_streams, step_out = [], [(ids, dists)]
+    if sharded and n_step_streams == 2:
+        step_streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
+        for st_ in step_streams:
+            st_.wait_stream(torch.cuda.current_stream(dev))   # the query batches are there
+        step_out.append((torch.empty_like(ids), torch.empty_like(dists)))
+
     def step(i, index=None):
         if pipelined:
             (index or idx).query_batch_torch(batches[i % N_BATCHES], k, ids, dists, wait=False)
             return ids, dists   # this rank's batch; complete after sync()
         # index shards: the path's one exchange step -- all-gather of the partial lists
         # (nq * k * 8 B per rank) over RCCL, then the device merge
+        if state["ordered"] and step_streams:
+            o_ids, o_dists = step_out[i & 1]
+            with torch.cuda.stream(step_streams[i & 1]):
+                (index or idx).query_batch_torch(batches[i % N_BATCHES], k, o_ids, o_dists, wait=False, ordered=True)
+                return dpq_dist.gather_and_merge(o_ids, o_dists)
         (index or idx).query_batch_torch(batches[i % N_BATCHES], k, ids, dists, wait=not state["ordered"], ordered=state["ordered"])
         return dpq_dist.gather_and_merge(ids, dists)
 
@@ -428,7 +446,8 @@ def main():
                 "collectives": None if world == 1 else (backend_note or ("gloo (host tensors)" if cpu_coll else "RCCL (backend nccl)")),
                 "query_batches_rotated": N_BATCHES,
                 "step_pipelining": "two lanes (dpq_query_batch_device_async)" if pipelined or not sharded else
-                                   ("stream-ordered steps (dpq_query_batch_device_ordered), no host round trip; no batch had to be answered again"
+                                   ("stream-ordered steps (dpq_query_batch_device_ordered) alternating between %d stream(s), no host round trip; "
+                                    "no batch had to be answered again" % n_step_streams
                                     if state["ordered"] else "one synchronous call per step (a batch overflowed in the stream-ordered run)"),
                 "queries_per_decode_pass": (groups * QG if batch_decoded else QG),
                 "decode": ("once per batch (decode_list_kernel), tile by tile, into %d MB of plain codes that the %d query groups' "

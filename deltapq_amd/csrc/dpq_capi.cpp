@@ -144,6 +144,8 @@ struct dpq_index {
     hipStream_t lane_stream[2] = {nullptr, nullptr};
     hipEvent_t lane_ready[2] = {nullptr, nullptr};   // recorded on the caller's stream: the batch's inputs are there
     uint64_t async_seq = 0;
+    hipStream_t ordered_stream[2] = {nullptr, nullptr};  // caller streams with stream-ordered batches: stream k <-> workspace k
+    bool ordered_stream_set[2] = {false, false};
     int64_t finish_reruns = 0;       // batches dpq_finish had to answer again (a query overflowed its candidate buffers)
     std::vector<Pending> pending;
     // staging for the host-pointer entry point
@@ -1532,15 +1534,45 @@ int enqueue_async(dpq_index* x, const float* d_queries, int nq, int top_k, int32
     if (rc || nq == 0) return rc;
     DPQ_HIP(hipSetDevice(x->device));
     hipStream_t user = reinterpret_cast<hipStream_t>(hip_stream);
-    // Batches in flight are ordered by the caller's stream.  A batch for another stream first settles what is in flight.
-    if (!x->pending.empty() && x->pending.back().user_stream != user && (rc = dpq_finish(x))) return rc;
     // DPQ_ASYNC_OVERLAP=0: every batch on the caller's stream with one workspace (round 1's behaviour)
     static const bool overlap_env = !(getenv("DPQ_ASYNC_OVERLAP") && atoi(getenv("DPQ_ASYNC_OVERLAP")) == 0);
     const bool overlap = overlap_env && allow_lanes;
-    // a stream-ordered batch uses the active workspace on the caller's stream: batches still running on a lane's
-    // own stream are settled first (a laned batch after ordered ones is safe: it waits for the caller's stream)
-    if (!overlap && !x->pending.empty() && x->pending.back().stream != x->pending.back().user_stream && (rc = dpq_finish(x)))
-        return rc;
+    auto in_flight_on_other_stream = [&]() {
+        for (const auto& p : x->pending)
+            if (p.user_stream != user) return true;
+        return false;
+    };
+    if (overlap) {
+        // Laned batches are ordered by the caller's stream: a batch for another stream first settles what is in flight.
+        if (in_flight_on_other_stream() && (rc = dpq_finish(x))) return rc;
+    } else {
+        // A stream-ordered batch runs on the caller's stream.  Batches still running on a lane's own stream are
+        // settled first.  Up to TWO caller streams may have stream-ordered batches in flight: each is given one of the
+        // two workspaces (a stream's batches follow each other, so its workspace is never shared) -- a caller that
+        // alternates its steps between two streams gets the overlap of two lanes with every step still consumable in
+        // stream order (the sharded driver: select -> pack -> all-gather -> merge behind each batch).  A third stream
+        // settles everything first.
+        bool laned = false;
+        for (const auto& p : x->pending) laned = laned || p.stream != p.user_stream;
+        if (laned && (rc = dpq_finish(x))) return rc;
+        int lane = -1;
+        for (int k = 0; k < 2; ++k)
+            if (x->ordered_stream_set[k] && x->ordered_stream[k] == user) lane = k;
+        if (lane < 0) {
+            for (int k = 0; k < 2 && lane < 0; ++k) {
+                bool busy = false;
+                for (const auto& p : x->pending) busy = busy || (x->ordered_stream_set[k] && p.user_stream == x->ordered_stream[k]);
+                if (!x->ordered_stream_set[k] || !busy) lane = k;
+            }
+            if (lane < 0) {
+                if ((rc = dpq_finish(x))) return rc;
+                lane = 0;
+            }
+            x->ordered_stream[lane] = user;
+            x->ordered_stream_set[lane] = true;
+        }
+        switch_lane(x, lane);
+    }
     const int D = x->M * x->Ds;
     for (int base = 0; base < nq; base += kMaxBatchQueries) {
         const int n = std::min(kMaxBatchQueries, nq - base);

@@ -285,7 +285,11 @@ int dpq_merge_topk_device_packed(const int32_t* d_packed, int n_lists, int nq, i
  * select -> pack -> all-gather -> merge without a host round trip per batch): the batch is enqueued on `hip_stream`
  * itself; work enqueued on that stream afterwards sees the result -- PROVIDED no query of the batch overflowed its
  * candidate buffers, which only dpq_finish can tell (it answers such a batch again; whatever consumed the first
- * answer must then be redone).  dpq_finish_count reports how many batches that happened to. */
+ * answer must then be redone).  dpq_finish_count reports how many batches that happened to.
+ * Up to TWO streams may have stream-ordered batches in flight at once: each is given one of the library's two
+ * workspaces, so a caller that alternates its steps between two streams overlaps a step's table build and bootstrap
+ * with the previous step's scan and select (a third stream, or a dpq_query_batch_device_async batch, first settles
+ * what is in flight). */
 int dpq_query_batch_device_ordered(dpq_index* idx, const float* d_queries, int nq, int top_k, int32_t* d_ids,
                                    float* d_dists, void* hip_stream);
 int dpq_finish_count(dpq_index* idx, int32_t* rerun_batches);

@@ -206,6 +206,49 @@ def test_stream_ordered_batches_feed_device_consumers(gpu, oracle, codebook):
                     assert_parity(ci.cpu().numpy()[rows], cd.cpu().numpy()[rows], oracle_topk(oracle, payload, n, codebook, q[rows], k), n)
 
 
+def test_stream_ordered_batches_on_two_alternating_streams(gpu, codebook):
+    """Stream-ordered batches of two caller streams in flight together: each stream is given one of the two
+    workspaces, no host round trip when the caller switches streams (the sharded driver alternates its steps like
+    this).  Eight batches, consumed by a copy enqueued behind each on its own stream, against synchronous calls; then
+    a third stream and a laned batch settle what is in flight and still answer right."""
+    import torch
+    from deltapq_amd import synth
+    n, k = 150000, 25
+    tree, payload, _ = make_case(n, seed=173)
+    qs = [torch.from_numpy(synth.make_queries(200, 128, seed=190 + i)).cuda() for i in range(8)]
+    with gpu.DeltaPQIndex.open_memory(payload, n, 8, 256) as idx:
+        idx.set_codebook(codebook)
+        want = [tuple(t.clone() for t in idx.query_batch_torch(q, k)) for q in qs]
+        streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+        for st in streams:
+            st.wait_stream(torch.cuda.current_stream())
+        out = [(torch.empty((200, k), dtype=torch.int32, device="cuda"), torch.empty((200, k), dtype=torch.float32, device="cuda"))
+               for _ in range(2)]
+        got = []
+        for i, q in enumerate(qs):
+            with torch.cuda.stream(streams[i & 1]):
+                o_i, o_d = out[i & 1]
+                idx.query_batch_torch(q, k, o_i, o_d, wait=False, ordered=True)
+                got.append((o_i.clone(), o_d.clone()))      # consumed in stream order; the buffer is reused two steps later
+        assert idx.finish() == 0
+        torch.cuda.synchronize()
+        for (wi, wd), (gi, gd) in zip(want, got):
+            assert torch.equal(wi, gi) and torch.equal(wd.view(torch.int32), gd.view(torch.int32))
+        third = torch.cuda.Stream()
+        third.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(streams[0]):
+            idx.query_batch_torch(qs[0], k, out[0][0], out[0][1], wait=False, ordered=True)
+        with torch.cuda.stream(streams[1]):
+            idx.query_batch_torch(qs[1], k, out[1][0], out[1][1], wait=False, ordered=True)
+        with torch.cuda.stream(third):
+            t_i, t_d = idx.query_batch_torch(qs[2], k, wait=False, ordered=True)    # settles the two above first
+        l_i, l_d = idx.query_batch_torch(qs[3], k, wait=False)                          # laned: settles again
+        assert idx.finish() == 0
+        torch.cuda.synchronize()
+        for j, (gi, gd) in enumerate((out[0], out[1], (t_i, t_d), (l_i, l_d))):
+            assert torch.equal(want[j][0], gi) and torch.equal(want[j][1].view(torch.int32), gd.view(torch.int32))
+
+
 def test_large_batch_is_split_internally(gpu, oracle, codebook):
     from deltapq_amd import synth
     n = 3000
