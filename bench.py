@@ -45,7 +45,7 @@ def pmc_traffic(args, world):
     """HBM bytes per scan-kernel launch from the committed rocprofv3 --pmc passes (scripts/collect_pmc.sh:
     FETCH_SIZE and WRITE_SIZE in separate runs, gfx950 x2 read correction).  Valid for the workload it was
     taken on: the summary names it."""
-    for name in ("r02_pmc_summary_default.json", "r02_pmc_summary_125M.json"):
+    for name in ("r02_pmc_summary_default.json", "r02_pmc_summary_125M.json", "r02_pmc_summary_125M_stream.json"):
         path = os.path.join(HERE, "profiles", name)
         if not os.path.exists(path):
             continue
@@ -54,6 +54,8 @@ def pmc_traffic(args, world):
         w = s.get("workload", {})
         if (w.get("n"), w.get("queries"), w.get("topk"), w.get("m"), w.get("data"), w.get("gpus")) == \
                 (args.n, args.queries, args.topk, args.m, args.data, world):
+            if "stream_kernel_hbm_bytes_per_launch" in s:   # one query per pass
+                return s["stream_kernel_hbm_bytes_per_launch"], s.get("stream_kernel_avg_launch_ms_kernel_trace"), name
             return s.get("scan_kernel_hbm_bytes_per_launch"), s.get("scan_kernel_avg_launch_ms_under_pmc"), name
     return None, None, None
 
@@ -510,6 +512,19 @@ def main():
             "index": {"device_bytes_rank0": int(all_stats[0, 3]), "segments_rank0": info["n_segments"],
                       "codes_rank0": int(all_stats[0, 10]), "gen_seconds": wl["gen_s"]},
         }
+        stream_max = int(os.environ.get("DPQ_STREAM_MAX_QUERIES", "2"))
+        if nq <= stream_max:
+            # one or two queries: one query per pass over the compressed image (stream_kernel) -- the mode in which the
+            # path is bound by the decode and by HBM, not by the LDS array
+            r = result["roofline"]
+            alg = (nq * alg_bytes_total) / (scan_ms_step * 1e-3) / 1e9 if scan_ms_step > 0 else 0.0
+            r.update({"bound": "hbm", "kernel": "stream_kernel", "achieved": alg, "peak": HBM_PEAK_GBPS * world, "frac": alg / (HBM_PEAK_GBPS * world),
+                      "definition": "one query per pass: achieved = queries x DTC payload bytes (SURVEY.md 8(d): every pass streams the "
+                                    "compressed image once) / stream-kernel time (HIP events on the launch stream); peak = 8 TB/s HBM3E.  "
+                                    "`hbm` holds the physical bytes of the counters where a matching PMC summary is committed."})
+            r.pop("lds_gather_bytes_per_step", None)
+            result["config"]["decode"] = "inside the stream kernel, once per query (one query per pass)"
+            result["config"]["queries_per_decode_pass"] = 1
         if replicas:
             result["query_replicas"] = replicas
         if world == 1 and not args.no_cpu_baseline:

@@ -469,7 +469,12 @@ int run_batch(dpq_index* x, const float* d_queries, int nq, int top_k, int32_t* 
     // sizes) -- the scan kernel then runs its plain-code instantiation with the DTC distance rule; a batch of one or
     // two groups, or a shard whose plain codes exceed the scratch budget, decodes inside the scan, once per group.
     // Measured on 1 M codes x 1000 queries (16 groups): scan 0.166 -> 0.122 ms, step 0.212 -> 0.172 ms.
-    const bool scratch = use_batch_decode(x, ngroups);
+    // One or two queries (the reference's own call shape): one query per pass over the compressed image, every node
+    // evaluated against the exact table (stream_kernel) -- no filter tables, no 64-query group machinery.
+    // DPQ_STREAM_MAX_QUERIES overrides the batch size up to which this mode is used (0 = never).
+    static const int stream_max = getenv("DPQ_STREAM_MAX_QUERIES") ? atoi(getenv("DPQ_STREAM_MAX_QUERIES")) : 2;
+    const bool direct = !x->plain && nq <= stream_max;
+    const bool scratch = !direct && use_batch_decode(x, ngroups);
     if (scratch && (rc = ensure_batch_raw(x))) return rc;
     const int64_t tile_segs = scratch ? batch_tile_segments(x) : 0;
     // One tile covers the whole shard (the common case): it is decoded here, ahead of the table build, so that both
@@ -566,12 +571,12 @@ int run_batch(dpq_index* x, const float* d_queries, int nq, int top_k, int32_t* 
             ba.n_queries = nq;
             // DPQ_FUSE_QUANTISE=0: the first level's tables from quantise_kernel, as for every later level
             static const bool fuse = !(getenv("DPQ_FUSE_QUANTISE") && atoi(getenv("DPQ_FUSE_QUANTISE")) == 0);
-            ba.qtab = fuse ? x->d_qtab : nullptr;
+            ba.qtab = fuse && !direct ? x->d_qtab : nullptr;
             ba.lut_min = x->d_lut_min;
-            boot_built_tables = fuse;
+            boot_built_tables = fuse && !direct;
             {
                 Timer t(x, stream, 2);
-                DPQ_HIP(dpq::launch_bootstrap(ba, x->M, fuse ? nqp : nq, stream));
+                DPQ_HIP(dpq::launch_bootstrap(ba, x->M, fuse && !direct ? nqp : nq, stream));
             }
             if (x->prof) x->prof_acc.select_launches++;
             continue;
@@ -589,6 +594,22 @@ int run_batch(dpq_index* x, const float* d_queries, int nq, int top_k, int32_t* 
             sa.seg_list = x->d_order + x->level_off[l];
             sa.n_seg_pass = x->level_cnt[l];
             const Regions rg = regions_for(x, sa.n_seg_pass, ngroups, top_k, cap);
+            if (direct) {
+                // one region per slot behind the carried winners, filled through a global counter
+                sa.region_cap = se.region_cap = (int32_t)std::min<int64_t>(stride - top_k, INT32_MAX);
+                se.n_regions = 2;
+                DPQ_HIP(hipMemset2DAsync(x->d_cand_count + 1, sizeof(uint32_t) * dpq::kRegionStride, 0, sizeof(uint32_t),
+                                         (size_t)nq, stream));
+                {
+                    Timer t(x, stream, 1);
+                    DPQ_HIP(dpq::launch_stream(sa, nq, stream));
+                }
+                if (x->prof) {
+                    x->prof_acc.scan_launches++;
+                    x->prof_acc.scan_stream_bytes +=
+                        (int64_t)nq * (int64_t)((double)x->info.device_bytes * sa.n_seg_pass / std::max(1, x->img.n_segments));
+                }
+            } else {
             sa.region_cap = se.region_cap = rg.region_cap;
             se.n_regions = 1 + rg.splits;
             if (!(boot_built_tables && l == 1)) {  // the bootstrap kernel wrote the first level's tables itself
@@ -628,6 +649,7 @@ int run_batch(dpq_index* x, const float* d_queries, int nq, int top_k, int32_t* 
                 x->prof_acc.scan_launches++;
                 x->prof_acc.scan_stream_bytes +=
                     (int64_t)((double)x->info.device_bytes * sa.n_seg_pass / std::max(1, x->img.n_segments));
+            }
             }
         }
         if (x->prof) x->prof_acc.scan_node_query_pairs += (int64_t)x->level_cnt[l] * S * nq;

@@ -123,6 +123,7 @@ hipError_t launch_decode_segments(const DeviceImage& img, const uint32_t* seg_li
                                   uint32_t* out_code, hipStream_t stream);
 // launch_quantise builds the level's filter tables of every query group (needs the level's thresholds in
 // thr_key); launch_scan must follow it on the same stream.
+hipError_t launch_stream(const ScanArgs& a, int n_slots, hipStream_t stream);
 hipError_t launch_quantise(const ScanArgs& a, int n_slot_groups, hipStream_t stream);
 hipError_t launch_scan(const ScanArgs& a, int n_slot_groups, int splits, hipStream_t stream);
 size_t qtab_bytes_per_group(int M);

@@ -30,6 +30,9 @@
 //                           keys) against the query's threshold key; what passes is a candidate
 //                           key in the workgroup's own region of the query's buffer (no global
 //                           atomics).
+//   stream_kernel           a5 + a6 for batches of one or two queries (the reference's own call shape): one query
+//                           per pass over the compressed image, every decoded node against the query's exact
+//                           table in LDS -- the mode bound by the decode and HBM instead of the LDS array.
 //   decode_segments_kernel  the same decode, writing plain codes (small shards: cascade level 0
 //                           is a query-independent spread sample).
 //   select_kernel           the rest of a6: candidate regions gathered; k-th smallest
@@ -1014,6 +1017,138 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanArgs a) {
 }
 
 // ---------------------------------------------------------------------------
+// stream: ONE query per pass (batches of one or two queries -- the reference's own call shape, main:328-339).
+// The 64-query filter machinery does not pay for a single query (a 128 KB table set of which one column is used);
+// here a wavefront decodes its chunks exactly as the scan does (same WaveDecoder, same three chunks in flight) and
+// evaluates every node against the query's EXACT table in LDS: an fp32 sum of the M entries first, the reference's
+// fp64 sum only for nodes within 2^-19 of the threshold; what passes the threshold key is a candidate, appended to
+// the slot's single region through one global atomic per wave step that found any (a tight bootstrap threshold
+// leaves a few per thousand nodes).  8 or 16 KB of LDS and ~64 VGPRs per wavefront: 32 wavefronts per CU stream the
+// compressed image -- this is the mode in which the path is bound by the decode and by HBM, not by the LDS array.
+// grid = (workgroups, slots), block = 256; the segments of the launch's list are dealt round-robin to the grid's
+// wavefronts.
+// ---------------------------------------------------------------------------
+constexpr int kStreamThreads = 256;
+
+template <int M>
+__global__ __launch_bounds__(kStreamThreads, M <= 8 ? 8 : 4) void stream_kernel(const ScanArgs a) {
+    using C = Cfg<M>;
+    constexpr int W = C::W, TE = M * 256;
+    __shared__ float T[TE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int slot = blockIdx.y;
+    int qq = a.slot_query ? a.slot_query[slot] : (slot < a.n_queries ? slot : -1);
+    if (qq < 0) return;  // block-uniform
+    {
+        const float4* src = reinterpret_cast<const float4*>(a.lut32 + (size_t)qq * TE);
+        for (int i = tid; i < TE / 4; i += kStreamThreads) reinterpret_cast<float4*>(T)[i] = src[i];
+    }
+    const uint64_t thr = a.thr_key[slot];
+    // fp32 sums are within M * 2^-24 (relative) of the exact distance: everything that can pass lies below this
+    const float quick = thr == ~0ull ? INFINITY : __uint_as_float((uint32_t)(thr >> 32)) * (1.0f + 0x1p-19f);
+    __syncthreads();
+
+    const int cps = a.img.chunks_per_segment;
+    const int n_waves = (int)gridDim.x * (kStreamThreads / 64);
+    int entry = (int)blockIdx.x * (kStreamThreads / 64) + wave;  // list position of this wavefront's next segment
+    auto next_entry = [&]() -> int {
+        if (entry >= a.n_seg_pass) return -1;
+        const int s = entry;
+        entry += n_waves;
+        return __builtin_amdgcn_readfirstlane(a.seg_list ? (int)a.seg_list[s] : s);
+    };
+    WaveDecoder<M> dec;
+    struct Chunk {
+        int seg, c;
+        typename WaveDecoder<M>::In in;
+        uint32_t carry_lane;
+        uint64_t h_doff;
+        uint32_t h_stk[W];
+        typename WaveDecoder<M>::Ld ld;
+    };
+    auto node_of = [&](const Chunk& k) { return ((int64_t)k.seg * cps + k.c) * 64 + lane; };
+    auto stage1 = [&](Chunk& k) {
+        if (k.seg < 0) return;
+        const int64_t node = node_of(k);
+        k.in = WaveDecoder<M>::load_in(a.img, node);
+        k.carry_lane = 0xffu;
+        if (k.c + 1 < cps && lane < C::LEVELS) k.carry_lane = a.img.carry[(size_t)(node >> 6) * C::LEVELS + lane];
+        if (k.c == 0) {
+            k.h_doff = a.img.seg_delta_off[k.seg];
+#pragma unroll
+            for (int w = 0; w < W; ++w) k.h_stk[w] = 0;
+            if (lane < C::LEVELS) {
+                const uint32_t* ck = reinterpret_cast<const uint32_t*>(a.img.seg_ckpt) + ((size_t)k.seg * C::LEVELS + lane) * W;
+#pragma unroll
+                for (int w = 0; w < W; ++w) k.h_stk[w] = ck[w];
+            }
+        }
+    };
+    uint64_t at = 0;
+    auto stage2 = [&](Chunk& k) {
+        if (k.seg < 0) return;
+        if (k.c == 0) at = k.h_doff;
+        k.ld = WaveDecoder<M>::load_delta(a.img, k.in, node_of(k), at);
+    };
+    auto successor = [&](const Chunk& k) {
+        Chunk n;
+        n.seg = k.seg;
+        n.c = k.c + 1;
+        if (k.seg >= 0 && n.c == cps) {
+            n.seg = next_entry();
+            n.c = 0;
+        }
+        return n;
+    };
+    uint32_t* count = a.cand_count + (size_t)slot * kRegionStride + 1;      // the slot's single region
+    uint64_t* region = a.cand_key + (size_t)slot * a.cand_stride + a.region_off;
+    Chunk A, B, Cn;
+    A.seg = next_entry();
+    A.c = 0;
+    stage1(A);
+    B = successor(A);
+    stage1(B);
+    stage2(A);
+    while (A.seg >= 0) {
+        // settle what is in flight before this step issues its prefetches (see scan_kernel)
+        asm volatile("" ::"v"(A.ld.level), "v"(A.ld.mk), "v"(A.ld.par), "v"(A.carry_lane), "v"(B.in.nb), "v"(B.in.mk),
+                     "v"(B.in.par), "v"(B.carry_lane));
+#pragma unroll
+        for (int h = 0; h < W / 2; ++h)
+            asm volatile("" ::"v"(A.ld.w[h][0]), "v"(A.ld.w[h][1]), "v"(A.ld.w[h][2]), "v"(A.ld.t[h].x), "v"(A.ld.t[h].y));
+        Cn = successor(B);
+        stage2(B);
+        stage1(Cn);
+        const int64_t node = node_of(A);
+        uint32_t code[W];
+        if (A.c == 0) {
+#pragma unroll
+            for (int w = 0; w < W; ++w) dec.stk[w] = A.h_stk[w];
+        }
+        dec.finish(A.ld, lane, A.carry_lane, code);
+        float d32 = 0.0f;
+#pragma unroll
+        for (int m = 0; m < M; ++m) d32 += T[m * 256 + ((code[m >> 2] >> (8 * (m & 3))) & 0xffu)];
+        bool pass = node < a.img.n_local && d32 <= quick;
+        uint64_t key = 0;
+        if (pass) {  // the reference's distance (fp64 sum rounded once) and the whole (distance, id) key
+            key = make_key(exact_dist<M>(T, code, false), a.img.id_base + (uint32_t)node);
+            pass = key <= thr;
+        }
+        const uint64_t found = __ballot(pass);
+        if (found) {
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(count, (uint32_t)__popcll(found));
+            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+            const uint32_t li = base + mbcnt64(found, 0);
+            if (pass && li < (uint32_t)a.region_cap) region[li] = key;
+        }
+        A = B;
+        B = Cn;
+    }
+}
+
+// ---------------------------------------------------------------------------
 // a6: select.  grid = slots, block = 512 (level 0) or 256 threads, dynamic LDS
 // ---------------------------------------------------------------------------
 
@@ -1813,6 +1948,21 @@ static hipError_t launch_scan_m(const ScanArgs& a, int n_slot_groups, int splits
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL((scan_kernel<M, PLAIN, STAMPS>), dim3((unsigned)splits, (unsigned)n_slot_groups),
                        dim3(kScanThreads), scan_lds_bytes(M), stream, a);
+    return hipGetLastError();
+}
+
+// One query per pass: n_slots passes over the launch's segment list (stream_kernel).  The slot's region 1 count must be
+// zero before the launch.
+hipError_t launch_stream(const ScanArgs& a, int n_slots, hipStream_t stream) {
+    if (a.n_seg_pass <= 0 || n_slots <= 0) return hipSuccess;
+    // enough workgroups for 32 wavefronts per CU on 256 CUs, never more wavefronts than segments
+    const int wgs = std::max(1, std::min(2048 / std::max(1, std::min(n_slots, 8)), (a.n_seg_pass + 3) / 4));
+    if (a.img.M == 8)
+        hipLaunchKernelGGL(stream_kernel<8>, dim3((unsigned)wgs, (unsigned)n_slots), dim3(kStreamThreads), 0, stream, a);
+    else if (a.img.M == 16)
+        hipLaunchKernelGGL(stream_kernel<16>, dim3((unsigned)wgs, (unsigned)n_slots), dim3(kStreamThreads), 0, stream, a);
+    else
+        return hipErrorInvalidValue;
     return hipGetLastError();
 }
 

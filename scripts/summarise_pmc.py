@@ -45,9 +45,14 @@ if "FETCH_SIZE" in sc and "WRITE_SIZE" in sc:
     summary["scan_kernel_avg_launch_ms_under_pmc"] = sc.get("avg_ns_under_pmc_fetch", sc["stats"]["avg_ns"]) / 1e6
     summary["scan_kernel_avg_launch_ms_kernel_trace"] = sc["stats"]["avg_ns"] / 1e6
     summary["scan_kernel_hbm_GBps"] = summary["scan_kernel_hbm_bytes_per_launch"] / (summary["scan_kernel_avg_launch_ms_kernel_trace"] * 1e-3) / 1e9
+st = next((v for k, v in summary["kernels"].items() if k.startswith("dpq::stream_kernel")), {})
+if "FETCH_SIZE" in st and "WRITE_SIZE" in st:   # one query per pass
+    summary["stream_kernel_hbm_bytes_per_launch"] = 2 * st["FETCH_SIZE"]["mean_kib"] * 1024 + st["WRITE_SIZE"]["mean_kib"] * 1024
+    summary["stream_kernel_avg_launch_ms_kernel_trace"] = st["stats"]["avg_ns"] / 1e6
+    summary["stream_kernel_hbm_GBps"] = summary["stream_kernel_hbm_bytes_per_launch"] / (st["stats"]["avg_ns"] * 1e-9) / 1e9
 summary["bench_line_under_rocprof"] = {k: line[k] for k in ("value", "ms_per_step", "repetitions") if k in line}
 json.dump(summary, open("%s/%s_pmc_summary.json" % (out, tag), "w"), indent=1)
-print(json.dumps({k: summary[k] for k in summary if k.startswith("scan_kernel") or k.startswith("decode_list")}, indent=1))
+print(json.dumps({k: summary[k] for k in summary if k.startswith("scan_kernel") or k.startswith("decode_list") or k.startswith("stream_kernel")}, indent=1))
 for k, v in summary["kernels"].items():
     if "stats" in v and k.startswith("dpq::") and "anonymous" not in k:
         print("%-46s calls %5d avg %9.1f us" % (k[:46], v["stats"]["calls"], v["stats"]["avg_ns"] / 1e3))

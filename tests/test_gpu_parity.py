@@ -563,6 +563,30 @@ def test_batch_decode_in_tiles(gpu, oracle, codebook, n, tile, k):
     assert_parity(ids_t[:6], d_t[:6], oracle_topk(oracle, payload, n, codebook, qs[:6], k), n)
 
 
+@pytest.mark.parametrize("n,M,k", [(200_000, 8, 50), (9_000, 8, 10), (2_300_000, 8, 100), (150_000, 16, 30)])
+def test_one_query_per_pass_matches_the_batched_path(gpu, oracle, n, M, k):
+    """Batches of one or two queries run stream_kernel (one query per pass over the compressed image, every node
+    against the exact table); the same queries inside a larger batch run the 64-query filter path.  Same lists, bit
+    for bit; and against the oracle.  Shapes: bootstrap shard, small cascade shard, a shard beyond 2 M nodes (two
+    levels), M = 16; also as shard 1 of 2."""
+    from deltapq_amd import synth
+    cb = synth.make_codebook(M, 256, 128 // M, seed=3)
+    tree = synth.synth_tree(n, M, seed=n + 5, mean_diffs=3.0 if M == 8 else 5.0)
+    payload, _ = synth.encode_dtc(tree)
+    qs = synth.make_queries(70, 128, seed=n + 6)
+    for kw in ({}, {"shard_rank": 1, "shard_count": 2}):
+        with gpu.DeltaPQIndex.open_memory(payload, n, M, 256, **kw) as idx:
+            idx.set_codebook(cb)
+            ids_b, d_b = idx.query_batch(qs, k)                # 70 queries: filter path
+            ids_1, d_1 = idx.query_batch(qs[:1], k)            # stream
+            ids_2, d_2 = idx.query_batch(qs[5:7], k)           # stream, two passes
+        assert np.array_equal(ids_1, ids_b[:1]) and np.array_equal(d_1.view(np.uint32), d_b[:1].view(np.uint32))
+        assert np.array_equal(ids_2, ids_b[5:7]) and np.array_equal(d_2.view(np.uint32), d_b[5:7].view(np.uint32))
+        if not kw:
+            assert_parity(np.concatenate([ids_1, ids_2]), np.concatenate([d_1, d_2]),
+                          oracle_topk(oracle, payload, n, cb, qs[[0, 5, 6]], k), n)
+
+
 def test_batch_decode_m16(gpu):
     """The same for the M = 16 format extension (4-dword codes)."""
     from deltapq_amd import synth
