@@ -803,7 +803,19 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanArgs a) {
         typename WaveDecoder<M>::Ld ld;   // stage 2
         uint32_t raw[W];                  // PLAIN: the code itself (stage 1)
     };
-    auto node_of = [&](const Chunk& k) { return ((int64_t)k.seg * cps + k.c) * 64 + lane; };  // local position
+    // Which node of its chunk a lane takes.  The decode ties lane i to node i (parents are reached by lane); plain
+    // codes can be dealt freely, and ds_read_b128 serves a wavefront in four fixed 16-lane groups ({0-3, 12-15, 20-27},
+    // {4-11, 16-19, 28-31}, the same + 32): giving each group 16 CONSECUTIVE nodes of the DFS order -- neighbours share
+    // bytes, equal table rows are broadcast -- costs 1.52 instead of 1.60 LDS cycles per group read
+    // (scripts/sim_lane_permutation.py).
+    int nlane = lane;
+    if constexpr (PLAIN) {
+        const int h = lane & 31;
+        const int g = (h >= 4 && h < 12) || (h >= 16 && h < 20) || h >= 28;
+        const int pos = h < 4 ? h : h < 12 ? h - 4 : h < 16 ? h - 8 : h < 20 ? h - 8 : h < 28 ? h - 12 : h - 16;
+        nlane = (lane & 32) + 16 * g + pos;
+    }
+    auto node_of = [&](const Chunk& k) { return ((int64_t)k.seg * cps + k.c) * 64 + nlane; };  // local position
     auto stage1 = [&](Chunk& k) {
         if (k.seg < 0) return;
         const int64_t node = node_of(k);
@@ -811,7 +823,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanArgs a) {
 #pragma unroll
             for (int w = 0; w < W; ++w) {
                 // the codes of a plain index lie in node order, the per-batch scratch in the order of the launch's list
-                const int64_t at = a.raw_by_pos ? ((int64_t)k.pos * cps + k.c) * 64 + lane : node;
+                const int64_t at = a.raw_by_pos ? ((int64_t)k.pos * cps + k.c) * 64 + nlane : node;
                 k.raw[w] = reinterpret_cast<const uint32_t*>(a.img.raw)[(size_t)at * W + w];
             }
         } else {
