@@ -102,11 +102,13 @@ struct dpq_index {
     unsigned long long* d_boot_stamps = nullptr;  // developer diagnostics (dpq_debug_boot_stamps)
     uint8_t* d_batch_raw = nullptr;  // active lane: the shard's plain codes, decoded once per batch (batch_decode)
     int batch_decode = 0;            // dpq_open_opts.batch_decode
+    uint8_t* d_relabel = nullptr;    // [M][256] code value -> label in the plain-code scratch (bank-aware; NULL = code values)
     uint8_t* d_nbr = nullptr;        // [8][256][256] centroid neighbour lists of the bootstrap's sub-spaces (dpq_set_codebook)
     float* d_codebook = nullptr;
     // workspace, sized for ws_slots padded queries and ws_cap candidates each
     int ws_slots = 0, ws_cap = 0;
     float* d_lut32 = nullptr;       // exact tables [query][8][256]
+    float* d_lut32r = nullptr;      // the same, rows by the labels of the plain-code scratch (only with d_relabel)
     float* d_lut_min = nullptr;     // [query][8] minima (anchor of the filter quantisation)
     uint4* d_qtab = nullptr;        // [slot groups][128 KB] filter tables of the cascade level being scanned
     uint32_t *d_cand_count = nullptr, *d_overflow = nullptr;
@@ -132,7 +134,7 @@ struct dpq_index {
     // the LUT kernel needs neither) and its bootstrap next to the previous batch's select.  The d_* workspace
     // fields above are the ACTIVE lane's; the other lane is parked here.
     struct Lane {
-        float *d_lut32 = nullptr, *d_lut_min = nullptr;
+        float *d_lut32 = nullptr, *d_lut_min = nullptr, *d_lut32r = nullptr;
         uint4* d_qtab = nullptr;
         uint32_t *d_cand_count = nullptr, *d_overflow = nullptr;
         uint64_t *d_cand_key = nullptr, *d_thr_key = nullptr, *d_scratch = nullptr;
@@ -187,12 +189,12 @@ namespace {
 void switch_lane(dpq_index* x, int lane) {
     if (lane == x->active_lane) return;
     dpq_index::Lane cur;
-    cur.d_lut32 = x->d_lut32; cur.d_lut_min = x->d_lut_min; cur.d_qtab = x->d_qtab;
+    cur.d_lut32 = x->d_lut32; cur.d_lut_min = x->d_lut_min; cur.d_qtab = x->d_qtab; cur.d_lut32r = x->d_lut32r;
     cur.d_cand_count = x->d_cand_count; cur.d_overflow = x->d_overflow;
     cur.d_cand_key = x->d_cand_key; cur.d_thr_key = x->d_thr_key; cur.d_scratch = x->d_scratch;
     cur.ws_slots = x->ws_slots; cur.ws_cap = x->ws_cap; cur.d_batch_raw = x->d_batch_raw;
     const dpq_index::Lane& o = x->parked;
-    x->d_lut32 = o.d_lut32; x->d_lut_min = o.d_lut_min; x->d_qtab = o.d_qtab;
+    x->d_lut32 = o.d_lut32; x->d_lut_min = o.d_lut_min; x->d_qtab = o.d_qtab; x->d_lut32r = o.d_lut32r;
     x->d_cand_count = o.d_cand_count; x->d_overflow = o.d_overflow;
     x->d_cand_key = o.d_cand_key; x->d_thr_key = o.d_thr_key; x->d_scratch = o.d_scratch;
     x->ws_slots = o.ws_slots; x->ws_cap = o.ws_cap; x->d_batch_raw = o.d_batch_raw;
@@ -203,12 +205,15 @@ void switch_lane(dpq_index* x, int lane) {
 void free_parked_lane(dpq_index* x) {
     dpq_index::Lane& o = x->parked;
     hipFree(o.d_lut32); hipFree(o.d_lut_min); hipFree(o.d_qtab); hipFree(o.d_cand_count); hipFree(o.d_overflow);
+    hipFree(o.d_lut32r);
     hipFree(o.d_cand_key); hipFree(o.d_thr_key); hipFree(o.d_scratch); hipFree(o.d_batch_raw);
     o = dpq_index::Lane();
 }
 
 void free_workspace(dpq_index* x) {
     hipFree(x->d_lut32);
+    hipFree(x->d_lut32r);
+    x->d_lut32r = nullptr;
     hipFree(x->d_lut_min);
     hipFree(x->d_qtab);
     hipFree(x->d_cand_count);
@@ -231,6 +236,7 @@ int ensure_workspace(dpq_index* x, int slots, int cap) {
     free_workspace(x);
     int rc;
     if ((rc = dev_alloc(&x->d_lut32, (size_t)slots * x->M * 256))) return rc;
+    if (x->d_relabel && (rc = dev_alloc(&x->d_lut32r, (size_t)slots * x->M * 256))) return rc;
     if ((rc = dev_alloc(&x->d_lut_min, (size_t)slots * x->M * 4))) return rc;  // four partial minima per (query, m)
     if ((rc = dev_alloc(&x->d_qtab, (size_t)(slots / dpq::queries_per_group(x->M) + 1) *
                                         (dpq::qtab_bytes_per_group(x->M) / sizeof(uint4)))))
@@ -485,20 +491,25 @@ int run_batch(dpq_index* x, const float* d_queries, int nq, int top_k, int32_t* 
     if (one_tile) {
         {
             Timer t(x, stream, 4);
-            DPQ_HIP(dpq::launch_decode_list(x->img, nullptr, x->img.n_segments, reinterpret_cast<uint32_t*>(x->d_batch_raw), stream));
+            DPQ_HIP(dpq::launch_decode_list(x->img, nullptr, x->img.n_segments, x->d_relabel,
+                                            reinterpret_cast<uint32_t*>(x->d_batch_raw), stream));
         }
         sa.img.raw = x->d_batch_raw;
     }
+    // the scratch holds relabelled codes (bank-aware labels): the filter tables of this batch are laid
+    // out by label, the scan maps a surviving node's code back before the exact check
+    const bool labelled = scratch && x->d_relabel != nullptr;
     {
         Timer t(x, stream, 0);
         // also clears the overflow flags of the nqp slots
+        // batches that scan the plain-code scratch also get the tables in the scratch's label order
         DPQ_HIP(dpq::launch_lut_build(x->d_codebook, d_queries, nq, nqp, x->M, x->K, x->Ds, x->d_lut32, x->d_lut_min,
-                                      nullptr, x->d_overflow, stream));
+                                      nullptr, x->d_overflow, scratch ? x->d_relabel : nullptr, x->d_lut32r, stream));
     }
     if (x->prof) x->prof_acc.lut_launches++;
     x->h_any[flag_slot] = 0;  // the slot is free: its previous batch has been finished
 
-    sa.lut32 = x->d_lut32;
+    sa.lut32 = labelled ? x->d_lut32r : x->d_lut32;
     sa.lut_min = x->d_lut_min;
     sa.thr_key = x->d_thr_key;
     sa.slot_query = nullptr;
@@ -572,6 +583,7 @@ int run_batch(dpq_index* x, const float* d_queries, int nq, int top_k, int32_t* 
             // DPQ_FUSE_QUANTISE=0: the first level's tables from quantise_kernel, as for every later level
             static const bool fuse = !(getenv("DPQ_FUSE_QUANTISE") && atoi(getenv("DPQ_FUSE_QUANTISE")) == 0);
             ba.qtab = fuse && !direct ? x->d_qtab : nullptr;
+            ba.relabel = scratch ? x->d_relabel : nullptr;
             ba.lut_min = x->d_lut_min;
             boot_built_tables = fuse && !direct;
             {
@@ -624,7 +636,8 @@ int run_batch(dpq_index* x, const float* d_queries, int nq, int top_k, int32_t* 
                     const int cnt = std::min<int>((int)tile_segs, total - t0);
                     {
                         Timer t(x, stream, 4);
-                        DPQ_HIP(dpq::launch_decode_list(x->img, list + t0, cnt, reinterpret_cast<uint32_t*>(x->d_batch_raw), stream));
+                        DPQ_HIP(dpq::launch_decode_list(x->img, list + t0, cnt, x->d_relabel,
+                                                        reinterpret_cast<uint32_t*>(x->d_batch_raw), stream));
                     }
                     sa.img.raw = x->d_batch_raw;
                     sa.raw_by_pos = 1;
@@ -723,7 +736,10 @@ int run_batch(dpq_index* x, const float* d_queries, int nq, int top_k, int32_t* 
         chk(hipMemsetAsync(c_over, 0, sizeof(uint32_t) * slots2, stream));
         sa.seg_list = nullptr;
         sa.n_seg_pass = x->img.n_segments;
-        if (!one_tile) sa.img.raw = x->img.raw;  // a tiled scratch holds the last tile only: the rerun decodes inside the scan
+        if (!one_tile) {  // a tiled scratch holds the last tile only: the rerun decodes inside the scan, code values as labels
+            sa.img.raw = x->img.raw;
+            sa.lut32 = x->d_lut32;
+        }
         sa.thr_key = c_tk;
         sa.slot_query = d_slot_query;
         sa.n_queries = slots2;
@@ -832,6 +848,10 @@ int open_from_payload(const uint8_t* payload, int64_t n_bytes, int64_t n_codes, 
         if (!rc) rc = up(&x->d_mi_id, soa.mi_id.data(), soa.mi_id.size() * 4);
         x->boot = !rc;
         x->boot_classes = soa.mi_classes;
+    }
+    static const bool relabel_env = !(getenv("DPQ_RELABEL") && atoi(getenv("DPQ_RELABEL")) == 0);  // developer A/B
+    if (!rc && relabel_env && soa.relabel.size() == (size_t)M * 256) {
+        rc = up(&x->d_relabel, soa.relabel.data(), soa.relabel.size());
     }
     if (rc) {
         dpq_close(x);
@@ -1418,7 +1438,6 @@ int dpq_set_codebook(dpq_index* x, const float* codewords, int Ds) {
             }
         }
         hipFree(x->d_nbr);
-    hipFree(x->d_batch_raw);
         x->d_nbr = nullptr;
         rc = dev_alloc(&x->d_nbr, nbr.size());
         if (rc) return rc;
@@ -1466,6 +1485,8 @@ int dpq_close(dpq_index* x) {
     hipFree(x->d_seg_off);
     hipFree(x->d_boot_stamps);
     hipFree(x->d_nbr);
+    hipFree(x->d_batch_raw);  // the active lane's plain-code scratch (the parked lane's goes with free_parked_lane)
+    hipFree(x->d_relabel);
     hipFree(x->d_mi_cell);
     hipFree(x->d_mi_code);
     hipFree(x->d_mi_id);
@@ -1777,8 +1798,10 @@ int dpq_debug_scan_time(dpq_index* x, int nq, int pass_all, int reps, int splits
     sa.seg_list = nullptr;
     sa.n_seg_pass = x->img.n_segments;
     // what the last batch ran: its plain-code scratch, if it decoded the whole shard into one
-    if (!x->plain && x->d_batch_raw && batch_tile_segments(x) >= x->img.n_segments && !getenv("DPQ_DEBUG_FUSED"))
+    if (!x->plain && x->d_batch_raw && batch_tile_segments(x) >= x->img.n_segments && !getenv("DPQ_DEBUG_FUSED")) {
         sa.img.raw = x->d_batch_raw;
+        if (x->d_relabel) sa.lut32 = x->d_lut32r;
+    }
     if (const char* e = getenv("DPQ_DEBUG_NSEG")) sa.n_seg_pass = std::min(x->img.n_segments, atoi(e));
     if (splits <= 0) splits = splits_for(sa.n_seg_pass, nqp / QG);
     sa.cand_count = x->d_cand_count;

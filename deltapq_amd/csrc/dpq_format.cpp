@@ -229,6 +229,12 @@ int transcode(const uint8_t* payload, int64_t n_bytes, int64_t n_codes, int M, i
 
     std::vector<uint8_t> stack((size_t)levels * M, 0);  // vecs_stack (h:2858-2862)
     int last_lane[16], top_level[64];                   // per chunk: last lane of every depth; per lane: its chain's stack level
+    // co-occurrence of code values inside 16-node read groups (every group_step-th group): input of the relabelling
+    const bool want_relabel = multi_index_stride > 0 && M % 4 == 0;
+    const int64_t group_step = std::max<int64_t>(1, (o.node_hi - o.node_lo) / (16 * 65536));
+    std::vector<uint32_t> cooc(want_relabel ? (size_t)M * 65536 : 0, 0);
+    uint8_t grp[16][16];  // [sub-space][member]
+    int grp_n = 0;
     std::vector<uint32_t> mi_ids;   // bootstrap sample: global position and decoded code of every stride-th node
     std::vector<uint8_t> mi_codes;
     if (multi_index_stride > 0) {
@@ -283,6 +289,52 @@ int transcode(const uint8_t* payload, int64_t n_bytes, int64_t n_codes, int M, i
                 mi_ids.push_back((uint32_t)i);
                 mi_codes.insert(mi_codes.end(), cur, cur + M);
             }
+            if (want_relabel && (l / 16) % group_step == 0) {
+                for (int m = 0; m < M; ++m) grp[m][grp_n] = cur[m];
+                if (++grp_n == 16 || i + 1 == o.node_hi) {
+                    for (int m = 0; m < M; ++m) {
+                        uint8_t* v = grp[m];
+                        std::sort(v, v + grp_n);
+                        const int nd = (int)(std::unique(v, v + grp_n) - v);
+                        uint32_t* Wm = &cooc[(size_t)m * 65536];
+                        for (int x = 0; x < nd; ++x)
+                            for (int y = x + 1; y < nd; ++y) {
+                                Wm[(size_t)v[x] * 256 + v[y]]++;
+                                Wm[(size_t)v[y] * 256 + v[x]]++;
+                            }
+                    }
+                    grp_n = 0;
+                }
+            }
+        }
+    }
+    if (want_relabel) {
+        // balanced 16-colouring per sub-space: heaviest values first, each to the colour (bank-quad residue) where it
+        // meets the least weight, at most 16 values per colour; label = colour + 16 * rank inside the colour
+        o.relabel.assign((size_t)M * 256, 0);
+        for (int m = 0; m < M; ++m) {
+            const uint32_t* Wm = &cooc[(size_t)m * 65536];
+            std::vector<uint64_t> weight(256, 0);
+            for (int a = 0; a < 256; ++a)
+                for (int b = 0; b < 256; ++b) weight[(size_t)a] += Wm[(size_t)a * 256 + b];
+            std::vector<int> order(256);
+            for (int a = 0; a < 256; ++a) order[(size_t)a] = a;
+            std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return weight[(size_t)a] > weight[(size_t)b]; });
+            int load[16] = {0};
+            std::vector<uint64_t> cost(256 * 16, 0);  // cost[value][colour]
+            int colour[256];
+            for (int a : order) {
+                int best = -1;
+                for (int c = 0; c < 16; ++c)
+                    if (load[c] < 16 && (best < 0 || cost[(size_t)a * 16 + c] < cost[(size_t)a * 16 + best] ||
+                                         (cost[(size_t)a * 16 + c] == cost[(size_t)a * 16 + best] && load[c] < load[best])))
+                        best = c;
+                colour[a] = best;
+                load[best]++;
+                for (int b = 0; b < 256; ++b) cost[(size_t)b * 16 + best] += Wm[(size_t)b * 256 + a];
+            }
+            int seen[16] = {0};
+            for (int a = 0; a < 256; ++a) o.relabel[(size_t)m * 256 + a] = (uint8_t)(colour[a] + 16 * seen[colour[a]]++);
         }
     }
     if (multi_index_stride > 0)

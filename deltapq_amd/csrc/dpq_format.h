@@ -86,6 +86,11 @@ struct SoA {
     std::vector<uint32_t> mi_cell_start;  // [mi_classes][65537] absolute position of every cell's first entry
     std::vector<uint32_t> mi_code;        // [entries][M / 4] decoded codes, cell-major
     std::vector<uint32_t> mi_id;          // [entries] global DFS position
+    // Bank-aware relabelling of the centroids for the per-batch plain-code scratch: relabel[m * 256 + c]
+    // = the label code value c of sub-space m carries THERE (a permutation of 0..255 per sub-space; empty = identity).
+    // The scan reads a 16-byte table row per (sub-space, label): rows whose labels agree mod 16 share an LDS bank
+    // quad, so values that often meet inside a 16-node read group are given different residues.
+    std::vector<uint8_t> relabel;
     int64_t nodes_per_segment() const { return (int64_t)kChunk * chunks_per_segment; }
     int64_t device_bytes() const {
         return (int64_t)(nib.size() + par.size() + carry.size() + mask.size() + delta.size() + seg_delta_off.size() * 8 +

@@ -40,7 +40,8 @@ struct ScanArgs {
     DeviceImage img;
     const uint32_t* seg_list;   // segments of this level (a slice of the visiting order), or NULL = all
     int32_t n_seg_pass;
-    const float* lut32;         // exact tables [query][m][256] fp32
+    const float* lut32;         // exact tables [query][m][256] fp32, rows by the labels of the codes the launch reads
+                                // (code values; the per-batch scratch: its bank-aware labels)
     const float* lut_min;       // [query][M][4] per-sub-space minima of the exact tables (four partial minima each)
     const uint64_t* thr_key;    // [slots] threshold key of each slot (~0 = keep everything)
     const int32_t* slot_query;  // slot -> query of the batch, NULL = identity, -1 = unused slot (nothing passes)
@@ -91,6 +92,7 @@ struct SelectArgs {
 
 // Threshold bootstrap from the inverted multi-index (see bootstrap_kernel).
 struct BootArgs {
+    const uint8_t* relabel;        // [M][256] code value -> label of the first filter level's table rows (NULL: identity)
     const uint8_t* nbr;            // [8 sort slots][256][256]: per centroid of the slot's sub-space, all centroids nearest first
     const uint32_t* cell_start;    // [n_classes][65537] absolute entry positions
     int32_t n_classes;             // 4 (sub-space pairs 0/1 .. 6/7) or 1 (pair 0/1)
@@ -116,9 +118,10 @@ struct BootArgs {
 // slots [0, n_slots) (either may be NULL).
 hipError_t launch_lut_build(const float* d_codebook, const float* d_queries, int nq, int n_slots, int M, int K, int Ds,
                             float* d_lut32, float* d_lut_min, uint32_t* d_cand_count, uint32_t* d_overflow,
+                            const uint8_t* d_relabel, float* d_lut_labels,
                             hipStream_t stream);
-hipError_t launch_decode_list(const DeviceImage& img, const uint32_t* seg_list, int n_seg, uint32_t* out_code,
-                              hipStream_t stream);
+hipError_t launch_decode_list(const DeviceImage& img, const uint32_t* seg_list, int n_seg, const uint8_t* relabel,
+                              uint32_t* out_code, hipStream_t stream);
 hipError_t launch_decode_segments(const DeviceImage& img, const uint32_t* seg_list, int n_seg, uint32_t* out_id,
                                   uint32_t* out_code, hipStream_t stream);
 // launch_quantise builds the level's filter tables of every query group (needs the level's thresholds in

@@ -14,7 +14,8 @@
 //                           level, once per group (later levels, reruns).
 //   decode_list_kernel      a5, batches of >= 3 query groups: a tile of a filter level's segment list decoded
 //                           ONCE into a plain-code scratch (one wavefront per segment) that every group's
-//                           scan pass reads through L2 / Infinity Cache.
+//                           scan pass reads through L2 / Infinity Cache; the bytes it writes are bank-aware
+//                           LABELS of the code values (a permutation per sub-space, found at load).
 //   scan_kernel             a5 + most of a6: delta decode + ADC filter + exact check.
 //                           One wavefront = one 64-node chunk per step, three chunks in flight
 //                           (software pipeline over the decode's two global round trips); child
@@ -106,7 +107,8 @@ __global__ __launch_bounds__(256) void lut_build_kernel(const float* __restrict_
                                                          const float* __restrict__ queries, int nq, int n_slots, int M,
                                                          int K, int Ds, float* __restrict__ lut,
                                                          float* __restrict__ lut_min, uint32_t* __restrict__ cand_count,
-                                                         uint32_t* __restrict__ overflow) {
+                                                         uint32_t* __restrict__ overflow, const uint8_t* __restrict__ relabel,
+                                                         float* __restrict__ lut_labels) {
     const int q0 = blockIdx.x * kLutQueries, m = blockIdx.y, k = threadIdx.x;
     if (m == 0 && k < kLutQueries && q0 + k < n_slots) {
         if (cand_count) cand_count[q0 + k] = 0;
@@ -153,6 +155,9 @@ __global__ __launch_bounds__(256) void lut_build_kernel(const float* __restrict_
 #pragma unroll
     for (int j = 0; j < kLutQueries; ++j) {
         if (q0 + j < nq) lut[((size_t)(q0 + j) * M + m) * 256 + k] = acc[j];
+        // second copy, rows by the LABELS of the per-batch plain-code scratch (the scan's exact checks and its filter
+        // tables index it with the scratch's codes as they are)
+        if (lut_labels && q0 + j < nq) lut_labels[((size_t)(q0 + j) * M + m) * 256 + relabel[m * 256 + k]] = acc[j];
         uint32_t v = __float_as_uint(acc[j]);  // acc >= 0: uint order == float order
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) v = min(v, (uint32_t)__shfl_xor((int)v, o));
@@ -422,8 +427,15 @@ __global__ __launch_bounds__(64) void decode_segments_kernel(const DeviceImage i
 // position j of the scratch, [n_seg * S][M].  grid = ceil(n_seg / 4), block = 256.
 template <int M>
 __global__ __launch_bounds__(256) void decode_list_kernel(const DeviceImage img, const uint32_t* __restrict__ seg_list,
-                                                           int n_seg, uint32_t* __restrict__ out_code) {
+                                                           int n_seg, const uint8_t* __restrict__ relabel,
+                                                           uint32_t* __restrict__ out_code) {
     constexpr int W = Cfg<M>::W;
+    __shared__ uint8_t s_rl[M * 256];  // relabel[m][code value]: the labels the scratch (and the filter tables) use
+    if (relabel) {
+        for (int i = threadIdx.x; i < M * 256 / 4; i += 256)
+            reinterpret_cast<uint32_t*>(s_rl)[i] = reinterpret_cast<const uint32_t*>(relabel)[i];
+        __syncthreads();
+    }
     const int lane = threadIdx.x & 63;
     const int64_t j = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (j >= n_seg) return;
@@ -436,6 +448,15 @@ __global__ __launch_bounds__(256) void decode_list_kernel(const DeviceImage img,
         const int64_t out = (j * cps + c) * 64 + lane;
         uint32_t code[W];
         dec.step(img, node, lane, c + 1 < cps, code);
+        if (relabel) {
+#pragma unroll
+            for (int w = 0; w < W; ++w) {
+                uint32_t r = 0;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) r |= (uint32_t)s_rl[(4 * w + b) * 256 + ((code[w] >> (8 * b)) & 0xffu)] << (8 * b);
+                code[w] = r;
+            }
+        }
         if constexpr (W == 2)
             reinterpret_cast<uint2*>(out_code)[out] = make_uint2(code[0], code[1]);
         else
@@ -534,7 +555,7 @@ __device__ __forceinline__ uint32_t filter_field(float tv, float sc, float of, u
 // T = the slot's exact tables (NULL: an unused slot, its entries reject).
 template <int M>
 __device__ __forceinline__ void write_filter_fields(uint4* qtab, int slot, const float* T, float sc, const float* of_m,
-                                                    uint32_t bias, int tid, int nthreads) {
+                                                    uint32_t bias, const uint8_t* __restrict__ relabel, int tid, int nthreads) {
     using C = Cfg<M>;
     constexpr int F = C::F, AB = C::AB, R = C::R, QG = C::QG, NG = C::NG, J = C::J;
     const int group = slot / QG, ls = slot % QG;
@@ -545,7 +566,8 @@ __device__ __forceinline__ void write_filter_fields(uint4* qtab, int slot, const
     for (int e = tid; e < M * 256; e += nthreads) {
         const int m = e >> 8;
         const uint32_t v = T ? filter_field<M>(T[e], sc, of_m[m], m == 0 ? bias : 0u) : C::reject_entry(m);
-        base[(size_t)e * 16] = (unsigned char)v;
+        const int row = relabel ? (m << 8) + relabel[e] : e;  // the label this code value carries in the scratch
+        base[(size_t)row * 16] = (unsigned char)v;
     }
 }
 
@@ -1547,7 +1569,7 @@ __global__ __launch_bounds__(kBootThreads, M <= 8 ? 8 : 6) void bootstrap_kernel
     const int slot = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int q = a.slot_query ? a.slot_query[slot] : (slot < a.n_queries ? slot : -1);
     if (q < 0) {  // padding slot of the last query group: its filter-table fields reject everything
-        if (a.qtab) write_filter_fields<M>(a.qtab, slot, nullptr, 0.0f, nullptr, 0u, tid, kBootThreads);
+        if (a.qtab) write_filter_fields<M>(a.qtab, slot, nullptr, 0.0f, nullptr, 0u, nullptr, tid, kBootThreads);
         return;
     }
     if (a.stamps && tid == 0) a.stamps[(size_t)slot * 8 + 6] = __builtin_amdgcn_s_memrealtime();  // 100 MHz, chip-wide
@@ -1757,7 +1779,7 @@ __global__ __launch_bounds__(kBootThreads, M <= 8 ? 8 : 6) void bootstrap_kernel
             }
         }
         __syncthreads();
-        write_filter_fields<M>(a.qtab, slot, T, s_scale, s_of, s_bias, tid, kBootThreads);
+        write_filter_fields<M>(a.qtab, slot, T, s_scale, s_of, s_bias, a.relabel, tid, kBootThreads);
     }
     if (a.stamps && tid == 0) a.stamps[(size_t)slot * 8 + 7] = __builtin_amdgcn_s_memrealtime();
 }
@@ -1917,12 +1939,12 @@ size_t select_lds_bytes(int M, int top_k, int n_shared) {
 
 hipError_t launch_lut_build(const float* d_codebook, const float* d_queries, int nq, int n_slots, int M, int K, int Ds,
                             float* d_lut32, float* d_lut_min, uint32_t* d_cand_count, uint32_t* d_overflow,
-                            hipStream_t stream) {
+                            const uint8_t* d_relabel, float* d_lut_labels, hipStream_t stream) {
     if (nq <= 0) return hipSuccess;
     n_slots = std::max(n_slots, nq);
     hipLaunchKernelGGL(lut_build_kernel, dim3((unsigned)((n_slots + kLutQueries - 1) / kLutQueries), (unsigned)M),
                        dim3(256), 0, stream, d_codebook, d_queries, nq, n_slots, M, K, Ds, d_lut32, d_lut_min,
-                       d_cand_count, d_overflow);
+                       d_cand_count, d_overflow, d_relabel, d_relabel ? d_lut_labels : nullptr);
     return hipGetLastError();
 }
 
@@ -1940,14 +1962,14 @@ hipError_t launch_decode_segments(const DeviceImage& img, const uint32_t* seg_li
     return hipGetLastError();
 }
 
-hipError_t launch_decode_list(const DeviceImage& img, const uint32_t* seg_list, int n_seg, uint32_t* out_code,
-                              hipStream_t stream) {
+hipError_t launch_decode_list(const DeviceImage& img, const uint32_t* seg_list, int n_seg, const uint8_t* relabel,
+                              uint32_t* out_code, hipStream_t stream) {
     if (n_seg <= 0) return hipSuccess;
     const unsigned grid = (unsigned)((n_seg + 3) / 4);
     if (img.M == 8)
-        hipLaunchKernelGGL(decode_list_kernel<8>, dim3(grid), dim3(256), 0, stream, img, seg_list, n_seg, out_code);
+        hipLaunchKernelGGL(decode_list_kernel<8>, dim3(grid), dim3(256), 0, stream, img, seg_list, n_seg, relabel, out_code);
     else if (img.M == 16)
-        hipLaunchKernelGGL(decode_list_kernel<16>, dim3(grid), dim3(256), 0, stream, img, seg_list, n_seg, out_code);
+        hipLaunchKernelGGL(decode_list_kernel<16>, dim3(grid), dim3(256), 0, stream, img, seg_list, n_seg, relabel, out_code);
     else
         return hipErrorInvalidValue;
     return hipGetLastError();

@@ -12,7 +12,7 @@ z = np.load("/tmp/sim_filter_%d.npz" % N)
 cb, codes = z["cb"], z["codes"]
 tree = api.DeltaTree(codes, codebook=cb, device=None)
 dfs = codes[tree.vec_id]
-GROUPS = [list(range(0, 4)) + list(range(12, 16)) + list(range(20, 28)),
+GROUPS = [list(range(0, 16)), list(range(16, 32)), list(range(32, 48)), list(range(48, 64))] if os.environ.get("CONSECUTIVE") else [list(range(0, 4)) + list(range(12, 16)) + list(range(20, 28)),
           list(range(4, 12)) + list(range(16, 20)) + list(range(28, 32)),
           list(range(32, 36)) + list(range(44, 48)) + list(range(52, 60)),
           list(range(36, 44)) + list(range(48, 52)) + list(range(60, 64))]

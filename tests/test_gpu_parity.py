@@ -587,6 +587,26 @@ def test_one_query_per_pass_matches_the_batched_path(gpu, oracle, n, M, k):
                           oracle_topk(oracle, payload, n, cb, qs[[0, 5, 6]], k), n)
 
 
+def test_codebook_can_be_set_again_between_scratch_batches(gpu, oracle, codebook):
+    """dpq_set_codebook after batches that used the plain-code scratch and the relabelled tables (it once freed them):
+    the same index answers for a second codebook and again for the first."""
+    from deltapq_amd import synth
+    n, k = 120_000, 20
+    tree, payload, _ = make_case(n, seed=61)
+    qs = synth.make_queries(200, 128, seed=62)
+    cb2 = synth.make_codebook(8, 256, 16, seed=99)
+    with gpu.DeltaPQIndex.open_memory(payload, n, 8, 256) as idx:
+        idx.set_codebook(codebook)
+        ids_a, d_a = idx.query_batch(qs, k)
+        idx.set_codebook(cb2)
+        ids_b, d_b = idx.query_batch(qs, k)
+        idx.set_codebook(codebook)
+        ids_c, d_c = idx.query_batch(qs, k)
+    assert np.array_equal(ids_a, ids_c) and np.array_equal(d_a.view(np.uint32), d_c.view(np.uint32))
+    assert_parity(ids_a[:5], d_a[:5], oracle_topk(oracle, payload, n, codebook, qs[:5], k), n)
+    assert_parity(ids_b[:5], d_b[:5], oracle_topk(oracle, payload, n, cb2, qs[:5], k), n)
+
+
 def test_batch_decode_m16(gpu):
     """The same for the M = 16 format extension (4-dword codes)."""
     from deltapq_amd import synth
