@@ -430,12 +430,9 @@ __global__ __launch_bounds__(256) void decode_list_kernel(const DeviceImage img,
                                                            int n_seg, const uint8_t* __restrict__ relabel,
                                                            uint32_t* __restrict__ out_code) {
     constexpr int W = Cfg<M>::W;
-    __shared__ uint8_t s_rl[M * 256];  // relabel[m][code value]: the labels the scratch (and the filter tables) use
-    if (relabel) {
-        for (int i = threadIdx.x; i < M * 256 / 4; i += 256)
-            reinterpret_cast<uint32_t*>(s_rl)[i] = reinterpret_cast<const uint32_t*>(relabel)[i];
-        __syncthreads();
-    }
+    // relabel[m][code value] = the label the scratch (and the batch's tables) use; read from global memory (2-4 KB, L1):
+    // this kernel must not ask for LDS -- a workgroup that does is only placed where a scan workgroup has retired, and
+    // the decode of the next pipelined batch then runs in the scan's tail instead of under it (as lut_build_kernel did)
     const int lane = threadIdx.x & 63;
     const int64_t j = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (j >= n_seg) return;
@@ -453,7 +450,7 @@ __global__ __launch_bounds__(256) void decode_list_kernel(const DeviceImage img,
             for (int w = 0; w < W; ++w) {
                 uint32_t r = 0;
 #pragma unroll
-                for (int b = 0; b < 4; ++b) r |= (uint32_t)s_rl[(4 * w + b) * 256 + ((code[w] >> (8 * b)) & 0xffu)] << (8 * b);
+                for (int b = 0; b < 4; ++b) r |= (uint32_t)relabel[(4 * w + b) * 256 + ((code[w] >> (8 * b)) & 0xffu)] << (8 * b);
                 code[w] = r;
             }
         }
