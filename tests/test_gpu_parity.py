@@ -674,6 +674,103 @@ def test_config4_per_gpu_share_125m_codes_bvecs_queries(gpu, oracle, tmp_path):
     print("config4 share: %.0f s" % (time.time() - t0))
 
 
+def _eight_way_decomposition(gpu, oracle, N, nq, k, checked, queries, world=8):
+    """BASELINE configs[3]/[4] as what they name, share after share on ONE GPU: rank r's DFS range synthesised exactly
+    as bench.py does (seed 102 + 1000 r), opened as a self-contained part (global_offset / global_n_codes), the whole
+    batch answered on it; the `checked` queries are verified against the oracle run on that share; the 8 partial
+    lists are merged on the host (dpq_merge_topk_host) AND on the device from the packed [8][nq][2k] tensor the
+    all-gather would deliver (dpq_merge_topk_device_packed); the merged lists of the checked queries must be the top-k
+    of the union of the oracle's partial lists.  Properties on the whole batch; the even-N id rule on the global tail only."""
+    import time
+    import torch
+    from deltapq_amd import dist as dpq_dist, synth
+    from oracle.dtc_oracle import tie_aware_equal
+    cb = synth.make_codebook(8, 256, 16, seed=100)
+    per = N // world
+    part_ids, part_d, ora = [], [], {q: [] for q in checked}
+    pairs = 0
+    for r in range(world):
+        t0 = time.time()
+        n = per if r + 1 < world else N - per * (world - 1)
+        tree = synth.synth_tree_large(n, 8, seed=102 + 1000 * r, mean_diffs=3.0)
+        payload, nb = synth.encode_dtc(tree)
+        del tree
+        with gpu.DeltaPQIndex.open_memory(payload, n, 8, 256, global_offset=r * per, global_n_codes=N) as idx:
+            idx.set_codebook(cb)
+            idx.profile_enable(True)
+            ids, dists = idx.query_batch(queries, k)
+            prof, info = idx.profile_read(), idx.info()
+        assert info["node_lo"] == r * per and info["node_hi"] == r * per + n and info["algorithmic_bytes"] == nb
+        S = 64 * info["chunks_per_segment"]
+        assert prof["scan_node_query_pairs"] == info["n_segments"] * S * nq      # every node filtered once per query
+        pairs += n * nq
+        assert np.all(np.diff(dists, axis=1) >= 0)
+        tail = r + 1 == world and N % 2 == 0
+        for q in range(nq):
+            row = ids[q].astype(np.int64)
+            assert len(set(row.tolist())) == k and row.min() >= r * per
+            assert row.max() < r * per + n or (tail and row.max() == N)          # id N: the global tail only (h:2949, 2970)
+            assert (N - 1) not in row.tolist() if tail else True
+        for q in checked:
+            lut = oracle.build_lut(cb, queries[q])
+            oi, od, alld, _ = oracle.scan_lut(payload, n, lut, k, want_all=True)
+            if n % 2 == 0:    # the oracle sees a whole index of n codes: fold its id n back, then the global tail's forward
+                oi = np.where(oi == n, n - 1, oi)
+            mine = ids[q].astype(np.int64) - r * per
+            if tail:
+                mine = np.where(mine == n, n - 1, mine)
+            ok, msg = tie_aware_equal(mine, dists[q], oi, od, alld, n | 1)
+            assert ok, "share %d query %d: %s" % (r, q, msg)
+            g = oi.astype(np.int64) + r * per
+            ora[q].append((np.where(g == N - 1, N, g) if tail else g, od))
+        part_ids.append(ids)
+        part_d.append(dists)
+        del payload
+        print("share %d of %d (%d codes): %.0f s" % (r, world, n, time.time() - t0), flush=True)
+    pi, pd = np.stack(part_ids), np.stack(part_d)
+    mi, md = gpu.merge_topk_host(pi, pd)
+    packed = torch.stack([dpq_dist.pack_lists(torch.from_numpy(part_ids[r]).cuda(), torch.from_numpy(part_d[r]).cuda())
+                          for r in range(world)]).contiguous()                   # [8][nq][2k]: the all-gather's layout
+    di, dd = gpu.merge_topk_packed_torch(packed, k)
+    torch.cuda.synchronize()
+    assert np.array_equal(di.cpu().numpy(), mi) and np.array_equal(dd.cpu().numpy().view(np.uint32), md.view(np.uint32))
+    # every merged row = the k smallest (distance, id) keys of the union of the 8 partial rows
+    keys = (pd.view(np.uint32).astype(np.uint64) << np.uint64(32)) | pi.astype(np.uint32).astype(np.uint64)
+    want = np.sort(keys.transpose(1, 0, 2).reshape(nq, -1), axis=1)[:, :k]
+    got = (md.view(np.uint32).astype(np.uint64) << np.uint64(32)) | mi.astype(np.uint32).astype(np.uint64)
+    assert np.array_equal(got, want)
+    for q in checked:   # ... and, for the checked queries, of the union of the ORACLE's partial lists (tie-aware at the boundary)
+        oi = np.concatenate([a for a, _ in ora[q]])
+        od = np.concatenate([b for _, b in ora[q]])
+        order = np.lexsort((oi, od.view(np.uint32)))[:k]
+        assert np.array_equal(md[q].view(np.uint32), od[order].view(np.uint32))
+        below = od[order] < od[order][-1]
+        assert set(mi[q][below[:k]].tolist()) == set(oi[order][below].tolist())
+    return pairs
+
+
+def test_config3_100m_codes_as_eight_shares_and_merge(gpu, oracle):
+    """BASELINE configs[3] -- 100 M codes over 8 GPUs, per-GPU partial top-k host-merged -- executed as the 8-way
+    decomposition it names, one share after the other on this GPU."""
+    from deltapq_amd import synth
+    nq = 64
+    qs = synth.make_queries(nq, 128, seed=8)
+    _eight_way_decomposition(gpu, oracle, 100_000_000, nq, 100, [0, 31, 63], qs)
+
+
+def test_config4_1b_codes_as_eight_parts_and_packed_gather_merge(gpu, oracle, tmp_path):
+    """BASELINE configs[4] -- 1 B bvecs-shaped codes over 8 GPUs with a gather of the candidate lists -- executed as
+    its 8 parts of 125 M codes, one after the other on this GPU; u8 queries through dpq_read_vecs(.bvecs); the merge
+    consumes the packed [8][nq][2k] tensor the RCCL all-gather delivers."""
+    from deltapq_amd import synth
+    nq = 32
+    qpath = str(tmp_path / "query.bvecs")
+    synth.write_bvecs(qpath, synth.make_queries(nq, 128, seed=5))
+    qs = gpu.read_vecs(qpath, ext="bvecs")
+    assert qs.shape == (nq, 128) and np.all(qs == np.rint(qs))
+    _eight_way_decomposition(gpu, oracle, 1_000_000_000, nq, 100, [0, 17], qs)
+
+
 M16_SHAPES = [(1, 3, 1), (2, 2, 2), (65, 5, 10), (1000, 20, 10), (10000, 50, 100), (100001, 40, 1000), (300000, 33, 100)]
 
 

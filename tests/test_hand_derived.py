@@ -194,6 +194,51 @@ E_Q = [F(2254117, 131072), F(11750887, 262144), F(10049977, 131072)]
 E_MIXED, E_FP32_ONLY, E_FP64_ONLY = 0x46E2431A, 0x46E24319, 0x46E2431B
 
 
+# D2. Case D scaled by 1/2 so that a real codebook can produce its table (Ds = 4, all-zero query; the product takes a
+#     codebook, not a table).  T[0][0] = T[1][0] = T[1][2] = 1/4 = (1/2)^2; T[1][1] = 1/4 - 2^-26 =
+#     (3^2 + 9^2 + 90^2 + 4095^2) / 2^26 (every partial sum is an integer below 2^24 over 2^26: exact in float, so the
+#     mixed rule of h:2845-2846 accumulates it without a rounding).  root = 1/2; node 1 = 1/2 - 1/4 + (1/4 - 2^-26) =
+#     1/2 - 2^-26 exactly in double, and float(1/2 - 2^-26) = 1/2 (the midpoint of 1/2 - 2^-25 and 1/2, to even);
+#     node 2 = 1/2.  h:2911: the DOUBLE 1/2 - 2^-26 is below the stored FLOAT 1/2 -> the reference answers id 1.
+D2_ROWS = {(0, 0): [0, 0, 0, F(1, 2)], (1, 0): [0, 0, 0, F(1, 2)], (1, 2): [0, 0, 0, F(1, 2)],
+           (1, 1): [F(3, 8192), F(9, 8192), F(90, 8192), F(4095, 8192)]}
+ANSWER_D2 = ([1], [0x3F000000])
+
+# F. The documented deviation, pinned to a known case: the product forms the fp64 SUM of the M
+#    table entries, the reference carries an INCREMENTAL fp64 stack (h:2896-2905); they differ where a partial sum is not
+#    exact in double.  Ds = 3, all-zero query.  T[0][1] = 1; T[1][1] = 2^-24 + 2^-47 = (2^-24)^2 + (2^-24)^2 + (2^-12)^2
+#    (float accumulation: 2^-48, 2^-47, 2^-24 (1 + 2^-23): exact); T[3][1] = 2^30 = (2^15)^2; T[3][0] = 0.
+#    root code [1,1,0,1,0,0,0,0]: 1 + (2^-24 + 2^-47) + 0 + 2^30 -> double(2^30 + 1 + 2^-24 + 2^-47) = 2^30 + 1 (the
+#    fraction is a quarter of the double's ulp 2^-22 and a bit: down).  node 1 (depth 1) sets position 3 to 0:
+#    reference: (2^30 + 1) - 2^30 + 0 = 1 -> float 1.0 = 0x3F800000.
+#    sum rule: 1 + 2^-24 + 2^-47 (exact in double) -> float: above the midpoint 1 + 2^-24 -> 1 + 2^-23 = 0x3F800001.
+#    One ulp apart: 1.2e-7 relative, inside the north star's 1e-5.
+STREAM_F = bytes([1, 1, 0, 1, 0, 0, 0, 0,     # root
+                  0x11,                        # depths of nodes 1, 2
+                  0x08, 0,                     # node 1: position 3 -> 0
+                  0x00])                       # node 2: a copy of the root (keeps N odd: no trailing node)
+F_ROWS = {(0, 1): [0, 0, 1], (1, 1): [F(1, 2 ** 24), F(1, 2 ** 24), F(1, 2 ** 12)], (3, 1): [0, 0, 2 ** 15]}
+F_REFERENCE_BITS, F_SUM_RULE_BITS = 0x3F800000, 0x3F800001
+
+
+def rows_codebook(rows, Ds):
+    """A codebook [8][256][Ds] that is zero except for the given (m, k) rows (exact floats, asserted)."""
+    cb = np.zeros((8, 256, Ds), dtype=np.float32)
+    for (m, k), row in rows.items():
+        for d, v in enumerate(row):
+            cb[m, k, d] = float(F(v))
+            assert F(float(cb[m, k, d])) == F(v)
+    return cb
+
+
+def table_from_rows(rows, Ds):
+    """The table the mixed rule builds from such a codebook against the all-zero query, on exact rationals."""
+    T = [[F(0)] * 256 for _ in range(8)]
+    for (m, k), row in rows.items():
+        T[m][k] = table_entry_by_the_book([F(v) for v in row], [F(0)] * Ds)
+    return T
+
+
 def table_d():
     T = [[F(0)] * 256 for _ in range(8)]
     T[0][0] = F(1, 2)
@@ -236,6 +281,22 @@ def test_literals_follow_from_the_definitions():
         acc64 = rnd(acc64 + rnd(d64 * d64, 53), 53)
     assert bits32(acc32) == E_FP32_ONLY and bits32(rnd(acc64, 24)) == E_FP64_ONLY
     assert len({E_MIXED, E_FP32_ONLY, E_FP64_ONLY}) == 3
+    # D2: the codebook rows give the table by the book, and the scan gives the admission case
+    T2 = table_from_rows(D2_ROWS, 4)
+    assert T2[0][0] == T2[1][0] == T2[1][2] == F(1, 4) and T2[1][1] == F(1, 4) - F(1, 2 ** 26)
+    d2 = scan_by_the_book(STREAM_D, 3, T2, 1)
+    assert d2 == [(0, F(1, 2)), (1, F(1, 2) - F(1, 2 ** 26)), (2, F(1, 2))] and rnd(d2[1][1], 24) == F(1, 2)
+    assert heap_topk_by_the_book(d2, 1) == [(F(1, 2), 1)] and bits32(F(1, 2)) == ANSWER_D2[1][0]
+    # F: incremental stack against one-shot sum
+    TF = table_from_rows(F_ROWS, 3)
+    assert TF[0][1] == 1 and TF[1][1] == F(1, 2 ** 24) + F(1, 2 ** 47) and TF[3][1] == 2 ** 30 and rnd(TF[1][1], 24) == TF[1][1]
+    f = scan_by_the_book(STREAM_F, 3, TF, 3)
+    assert f[0][1] == 2 ** 30 + 1 and f[1] == (1, F(1)) and bits32(rnd(f[1][1], 24)) == F_REFERENCE_BITS
+    one_shot = F(0)
+    for m, byte in enumerate([1, 1, 0, 0, 0, 0, 0, 0]):      # node 1's code, summed in position order, double by double
+        one_shot = rnd(one_shot + TF[m][byte], 53)
+    assert one_shot == 1 + F(1, 2 ** 24) + F(1, 2 ** 47) and bits32(rnd(one_shot, 24)) == F_SUM_RULE_BITS
+    assert abs(rnd(one_shot, 24) - rnd(f[1][1], 24)) / rnd(f[1][1], 24) == F(1, 2 ** 23) < F(1, 10 ** 5)
 
 
 # ---------------------------------------------------------------------------
@@ -286,6 +347,27 @@ def test_oracle_stream_across_a_4k_block(oracle, tmp_path):
 def test_oracle_double_against_float_admission(oracle):
     got_i, got_d = both_scans(oracle, STREAM_D, 3, np_table(table_d()), 1)
     assert got_i.tolist() == ANSWER_D[0] and got_d.view(np.uint32).tolist() == ANSWER_D[1]
+
+
+def test_oracle_admission_case_from_a_real_codebook(oracle):
+    """D2: the same admission case with its table built by the oracle's own LUT rule from a Ds = 4 codebook."""
+    cb = rows_codebook(D2_ROWS, 4)
+    lut = oracle.build_lut(cb, np.zeros(32, dtype=np.float32))
+    assert lut[1, 1] == np.float32(0.25 - 2.0 ** -26) and lut[0, 0] == lut[1, 0] == lut[1, 2] == np.float32(0.25)
+    got_i, got_d = both_scans(oracle, STREAM_D, 3, lut, 1)
+    assert got_i.tolist() == ANSWER_D2[0] and got_d.view(np.uint32).tolist() == ANSWER_D2[1]
+
+
+def test_oracle_incremental_stack_differs_from_the_sum_rule_on_case_f(oracle):
+    """F: the oracle follows the reference's incremental stack (0x3F800000), not the fp64 sum (0x3F800001)."""
+    cb = rows_codebook(F_ROWS, 3)
+    lut = oracle.build_lut(cb, np.zeros(24, dtype=np.float32))
+    assert lut[3, 1] == np.float32(2.0 ** 30) and float(lut[1, 1]) == 2.0 ** -24 + 2.0 ** -47
+    _, _, alld, codes = oracle.scan_lut(np.frombuffer(STREAM_F, dtype=np.uint8), 3, lut, 1, want_all=True)
+    assert codes[1].tolist() == [1, 1, 0, 0, 0, 0, 0, 0]
+    assert int(alld.view(np.uint32)[1]) == F_REFERENCE_BITS
+    one_shot = np.float32(sum(np.float64(lut[m, codes[1][m]]) for m in range(8)))
+    assert int(one_shot.view(np.uint32)) == F_SUM_RULE_BITS
 
 
 def test_oracle_table_arithmetic_is_the_mixed_rule(oracle):
@@ -352,3 +434,42 @@ def test_product_table_arithmetic_is_the_mixed_rule(lib):
         idx.set_codebook(cb)
         ids, d = idx.query_batch(q, 1)
     assert ids[0, 0] == 0 and int(d.view(np.uint32)[0, 0]) == E_MIXED
+
+
+@pytest.mark.gpu
+def test_product_on_the_admission_case(lib):
+    """D2 through the HIP path.  All three nodes have the fp32 distance 1/2; the reference's `double < float` admission
+    (h:2911) answers id 1 at k = 1.  The product's distance rule gives the same bits for every node and its documented tie
+    rule (the k-th boundary group is represented by ascending id) answers id 0 -- the tie-aware
+    comparator accepts exactly that: distance bits equal at every rank, boundary ids out of the boundary group."""
+    from deltapq_amd import api
+    from oracle.dtc_oracle import tie_aware_equal
+    cb = rows_codebook(D2_ROWS, 4)
+    pl = np.frombuffer(STREAM_D, dtype=np.uint8)
+    q = np.zeros((1, 32), dtype=np.float32)
+    with api.DeltaPQIndex.open_memory(pl, 3, 8, 256) as idx:
+        idx.set_codebook(cb)
+        ids1, d1 = idx.query_batch(q, 1)
+        ids3, d3 = idx.query_batch(q, 3)
+    assert d1.view(np.uint32).tolist() == [ANSWER_D2[1]] and ids1[0, 0] in (0, 1, 2)
+    assert d3.view(np.uint32).tolist() == [[0x3F000000] * 3] and sorted(ids3[0].tolist()) == [0, 1, 2]
+    alld = np.array([0.5, 0.5, 0.5], dtype=np.float32)
+    ok, msg = tie_aware_equal(ids1[0], d1[0], np.array(ANSWER_D2[0]), np.array(ANSWER_D2[1], dtype=np.uint32).view(np.float32), alld, 3)
+    assert ok, msg
+
+
+@pytest.mark.gpu
+def test_product_deviation_from_the_incremental_stack_is_the_pinned_case(lib):
+    """F through the HIP path: the product's fp64-sum rule answers 0x3F800001 for node 1 where the reference's incremental
+    stack answers 0x3F800000 -- one ulp, 1.2e-7 relative, inside the north star's 1e-5 (documented deviation)."""
+    from deltapq_amd import api
+    cb = rows_codebook(F_ROWS, 3)
+    pl = np.frombuffer(STREAM_F, dtype=np.uint8)
+    with api.DeltaPQIndex.open_memory(pl, 3, 8, 256) as idx:
+        idx.set_codebook(cb)
+        ids, d = idx.query_batch(np.zeros((1, 24), dtype=np.float32), 3)
+    assert ids[0, 0] == 1 and int(d.view(np.uint32)[0, 0]) == F_SUM_RULE_BITS
+    ref = np.array([F_REFERENCE_BITS], dtype=np.uint32).view(np.float32)[0]
+    assert abs(float(d[0, 0]) - float(ref)) / float(ref) <= 1e-5
+    # nodes 0 and 2 (the root's code): double(2^30 + 1 + 2^-24 + 2^-47) = 2^30 + 1 -> float 2^30 (its ulp is 128)
+    assert ids[0, 1:].tolist() == [0, 2] and float(d[0, 1]) == float(d[0, 2]) == 2.0 ** 30
