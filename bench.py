@@ -132,7 +132,7 @@ def parity_gate(args, wl, queries, hi, hd, budget_s=25.0):
             print("bench.py: PARITY FAILURE on query %d: %s" % (i, msg), file=sys.stderr)
             sys.exit(4)
         checked += 1
-        if time.time() - t0 > budget_s:
+        if time.time() - t0 > budget_s and checked >= min(args.min_check, args.check):
             break
     return checked
 
@@ -209,6 +209,10 @@ def main():
                          "scratch), 1 always, -1 never (decode inside the scan)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU time given to each leg of the oracle baseline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sustain-seconds", type=float, default=2.0, help="length of the sustained block after the timed regions (0 = skip)")
+    ap.add_argument("--host-steps", type=int, default=20, help="steps of the host-to-host leg through dpq_query_batch (N = 1; 0 = skip)")
+    ap.add_argument("--min-check", type=int, default=8,
+                    help="queries the parity gate verifies whatever its time budget (a 125 M-code oracle scan takes seconds per query)")
     ap.add_argument("--check", type=int, default=64, help="queries verified against the oracle before timing (time-bounded)")
     ap.add_argument("--shard", choices=["auto", "index", "query"], default="auto",
                     help="N > 1: 'index' (= auto) cuts the index into DFS ranges, every GPU answers the one batch on its "
@@ -301,17 +305,18 @@ def main():
     # its two workspaces, so step i + 1's decode / table build run under step i's scan and its bootstrap beside step
     # i's select, while every step's exchange (pack -> all-gather -> merge) still follows its own batch in stream order.
     n_step_streams = max(1, min(2, args.sharded_streams)) if sharded else 1
-    step_streams, step_out = [], [(ids, dists)]
+    # every step in flight owns its output pair: two lanes = two batches in flight
+    step_streams, step_out = [], [(ids, dists), (torch.empty_like(ids), torch.empty_like(dists))]
     if sharded and n_step_streams == 2:
         step_streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
         for st_ in step_streams:
             st_.wait_stream(torch.cuda.current_stream(dev))   # the query batches are there
-        step_out.append((torch.empty_like(ids), torch.empty_like(dists)))
 
     def step(i, index=None):
         if pipelined:
-            (index or idx).query_batch_torch(batches[i % N_BATCHES], k, ids, dists, wait=False)
-            return ids, dists   # this rank's batch; complete after sync()
+            o_ids, o_dists = step_out[i & 1]
+            (index or idx).query_batch_torch(batches[i % N_BATCHES], k, o_ids, o_dists, wait=False)
+            return o_ids, o_dists   # this rank's batch; complete after sync()
         # index shards: the path's one exchange step -- all-gather of the partial lists
         # (nq * k * 8 B per rank) over RCCL, then the device merge
         if state["ordered"] and step_streams:
@@ -339,6 +344,17 @@ def main():
             parity = parity_gate(args, wl, batches_np[0], ids.cpu().numpy(), dists.cpu().numpy())
             m_ids = out_ids.cpu().numpy()
             assert np.all(np.diff(out_dists.cpu().numpy(), axis=1) >= 0) and m_ids.min() >= 0 and m_ids.max() <= args.n
+
+    # ... and the overlapped path itself (two batches in flight on the two lanes, each with its own outputs) before it
+    # is timed: the first rows of both against the oracle
+    overlap_parity = 0
+    if pipelined:
+        o0, o1 = step(0), step(1)
+        sync()
+        if rank == 0 and args.check > 0 and wl["whole"]:
+            for b, (oi, od) in enumerate((o0, o1)):
+                overlap_parity += parity_gate(args, wl, batches_np[b][:max(2, args.check // 8)], oi.cpu().numpy(), od.cpu().numpy(),
+                                              budget_s=8.0)
 
     def timed(index=None, reps=args.reps):
         """--reps repetitions of the K-step region; returns the per-repetition wall times (max over ranks)."""
@@ -371,6 +387,51 @@ def main():
         if int(flag.item()) > 0:
             state["ordered"] = False
             times = timed()
+    # Sustained rate: the same steps back to back for >= --sustain-seconds (the K-step regions above last a few
+    # milliseconds: boost clocks; MI355X_MICROARCH.md 'DVFS give-back').  Same work per step, nothing skipped.
+    sustained = None
+    if args.sustain_seconds > 0:
+        sync()
+        n_done, t0 = 0, time.perf_counter()
+        while True:
+            for i in range(args.steps):
+                step(n_done + i)
+            n_done += args.steps
+            sync()
+            el = time.perf_counter() - t0
+            tt = torch.tensor([el], dtype=torch.float64, device=torch.device("cpu") if cpu_coll else dev)
+            if world > 1:
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            if float(tt.item()) >= args.sustain_seconds:
+                el = float(tt.item())
+                break
+        sustained = {"value": (world if by_query else 1) * nq * n_done / el, "unit": "queries/s", "seconds": el, "steps": n_done,
+                     "ms_per_step": 1e3 * el / n_done,
+                     "note": "the same steps back to back for >= %.1f s, a host synchronisation every %d steps" % (args.sustain_seconds, args.steps)}
+
+    # Host-to-host rate through the drop-in entry point dpq_query_batch (host pointers in and out: PCIe both ways and a
+    # synchronous call per batch), pinned host buffers; never used for `value`.
+    host_to_host = None
+    if world == 1 and args.host_steps > 0:
+        hq = [torch.from_numpy(b).pin_memory() for b in batches_np]
+        h_ids = torch.empty((nq, k), dtype=torch.int32).pin_memory()
+        h_d = torch.empty((nq, k), dtype=torch.float32).pin_memory()
+        import ctypes as _ct
+        from deltapq_amd import _lib as _l
+        fn = _l.load().dpq_query_batch
+        for i in range(2):
+            _l.check(fn(idx._h, _ct.c_void_p(hq[i % N_BATCHES].data_ptr()), nq, k, _ct.c_void_p(h_ids.data_ptr()), _ct.c_void_p(h_d.data_ptr())), "dpq_query_batch")
+        t0 = time.perf_counter()
+        for i in range(args.host_steps):
+            _l.check(fn(idx._h, _ct.c_void_p(hq[i % N_BATCHES].data_ptr()), nq, k, _ct.c_void_p(h_ids.data_ptr()), _ct.c_void_p(h_d.data_ptr())), "dpq_query_batch")
+        el = time.perf_counter() - t0
+        host_to_host = {"value": nq * args.host_steps / el, "unit": "queries/s", "ms_per_step": 1e3 * el / args.host_steps,
+                        "steps": args.host_steps,
+                        "note": "dpq_query_batch: pinned host queries in (%d KB), ids + distances out (%d KB) per step, one synchronous call per batch"
+                                % (nq * args.dim * 4 // 1024, nq * k * 8 // 1024)}
+        if args.check > 0 and wl["whole"]:
+            parity_gate(args, wl, batches_np[(args.host_steps - 1) % N_BATCHES][:4], h_ids.numpy(), h_d.numpy(), budget_s=5.0)
+
     aux_steps = max(1, min(args.steps, 8))
     idx.profile_enable(1)
     idx.profile_reset()
@@ -472,6 +533,7 @@ def main():
                 "unit": "GB/s",
                 "frac": lds_gbps / (LDS_PEAK_GBPS * world),
                 "traffic": traffic,
+                "traffic_source": None if traffic is None else "committed profile profiles/%s (rocprofv3 --pmc passes of this workload on another run), not measured in this run" % pmc_name,
                 "definition": "achieved = LDS bytes of the ADC table gathers the scan launches issue (per decoded node and "
                               "%d-query group: M x %d ds_read_b128 = %d B, i.e. %d B per (code, query) pair, padding slots "
                               "included) / scan-kernel time (HIP events on the launch stream); peak = 256 CUs x 256 B/clk x "
@@ -504,6 +566,9 @@ def main():
                               "events (pipelined batches overlap on two lanes there)" % aux_steps,
             },
             "parity_checked_queries": parity,
+            "parity_checked_queries_overlapped_steps": overlap_parity,
+            "sustained": sustained,
+            "host_to_host": host_to_host,
             # SURVEY.md 8(d) "report alongside": whole-job rates of the timed regions (median repetition)
             "rates": {"code_query_pairs_per_s": global_q * args.steps / med * float(all_stats[:, 10].sum()) / (1 if sharded or world == 1 else world),
                       "raw_pq_equivalent_GBps": global_q * args.steps / med * float(all_stats[:, 10].sum()) / (1 if sharded or world == 1 else world) * args.m / 1e9,

@@ -16,7 +16,10 @@ P = ctypes.POINTER
 class OpenOpts(ctypes.Structure):
     _fields_ = [("device", c_i32), ("shard_rank", c_i32), ("shard_count", c_i32), ("chunks_per_segment", c_i32),
                 ("cand_capacity", c_i32), ("num_codes", c_i32), ("bootstrap", c_i32), ("batch_decode", c_i32),
-                ("global_offset", c_i64), ("global_n_codes", c_i64)]
+                ("global_offset", c_i64), ("global_n_codes", c_i64),
+                # plan and tiling knobs (0 = measured default), see include/deltapq_amd.h
+                ("stream_max_queries", c_i32), ("coarse_below", c_i32), ("plan_ratios", c_i32 * 3), ("boot_cap", c_i32),
+                ("boot_target", c_i32), ("flags", c_i32), ("batch_tile_nodes", c_i64)]
 
 
 class Info(ctypes.Structure):
@@ -35,7 +38,8 @@ class Profile(ctypes.Structure):
                 ("lut_launches", c_i64), ("scan_launches", c_i64), ("select_launches", c_i64),
                 ("scan_node_query_pairs", c_i64), ("scan_stream_bytes", c_i64), ("query_batches", c_i64),
                 ("queries", c_i64), ("overflow_reruns", c_i64), ("exact_checks", c_i64), ("candidates", c_i64),
-                ("quantise_ms", ctypes.c_double), ("decode_ms", ctypes.c_double)]
+                ("quantise_ms", ctypes.c_double), ("decode_ms", ctypes.c_double), ("bootstrap_ms", ctypes.c_double),
+                ("bootstrap_launches", c_i64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

@@ -208,6 +208,24 @@ def read_qnode_ids(path, n_codes):
     return out
 
 
+def _apply_tuning(opts, tune):
+    """dpq_open_opts' plan and tiling knobs by name (stream_max_queries, coarse_below, plan_ratios, boot_cap,
+    boot_target, flags, batch_tile_nodes); 0 / absent = the measured default."""
+    for name, value in tune.items():
+        if name == "plan_ratios":
+            vals = list(value) + [0, 0, 0]
+            for i in range(3):
+                opts.plan_ratios[i] = int(vals[i])
+        elif name in ("stream_max_queries", "coarse_below", "boot_cap", "boot_target", "flags", "batch_tile_nodes"):
+            setattr(opts, name, int(value))
+        else:
+            raise TypeError("unknown dpq_open_opts field %r" % name)
+    return opts
+
+
+OPT_NO_RELABEL, OPT_NO_FUSE_QUANTISE, OPT_NO_ASYNC_OVERLAP, OPT_BOOT_FULLSORT = 1, 2, 4, 8   # dpq_open_opts.flags
+
+
 class DeltaPQIndex:
     """One DTC index (or one shard) resident on one MI355X."""
 
@@ -217,37 +235,38 @@ class DeltaPQIndex:
 
     @classmethod
     def open_file(cls, path, M=8, K=256, device=0, shard_rank=0, shard_count=1, chunks_per_segment=0,
-                  cand_capacity=0, num_codes=0, bootstrap=0, batch_decode=0):
+                  cand_capacity=0, num_codes=0, bootstrap=0, batch_decode=0, **tune):
         """num_codes > 0: scan only the first num_codes codes (the reference's -N below the header's n_codes).
         bootstrap: 0 auto, 1 on, -1 off (dpq_open_opts.bootstrap).  batch_decode: 0 auto, 1 always decode once per batch
         into the plain-code scratch, -1 always decode inside the scan, n >= 2 scratch in tiles of n segments
         (dpq_open_opts.batch_decode)."""
         lib = _lib.load()
-        opts = OpenOpts(device, shard_rank, shard_count, chunks_per_segment, cand_capacity, num_codes, bootstrap, batch_decode)
+        opts = _apply_tuning(OpenOpts(device, shard_rank, shard_count, chunks_per_segment, cand_capacity, num_codes, bootstrap,
+                                      batch_decode), tune)
         h = ctypes.c_void_p()
         check(lib.dpq_open_file(path.encode(), M, K, opts, h), "dpq_open_file")
         return cls(h)
 
     @classmethod
     def open_memory(cls, payload, n_codes, M=8, K=256, device=0, shard_rank=0, shard_count=1, chunks_per_segment=0,
-                    cand_capacity=0, num_codes=0, bootstrap=0, global_offset=0, global_n_codes=0, batch_decode=0):
+                    cand_capacity=0, num_codes=0, bootstrap=0, global_offset=0, global_n_codes=0, batch_decode=0, **tune):
         """global_offset / global_n_codes: the payload is a self-contained part of a larger index (ids are
         reported as global_offset + local position; dpq_open_opts)."""
         lib = _lib.load()
         pl = np.ascontiguousarray(payload, dtype=np.uint8)
-        opts = OpenOpts(device, shard_rank, shard_count, chunks_per_segment, cand_capacity, num_codes, bootstrap,
-                        batch_decode, global_offset, global_n_codes)
+        opts = _apply_tuning(OpenOpts(device, shard_rank, shard_count, chunks_per_segment, cand_capacity, num_codes, bootstrap,
+                                      batch_decode, global_offset, global_n_codes), tune)
         h = ctypes.c_void_p()
         check(lib.dpq_open_memory(_np_ptr(pl), pl.size, n_codes, M, K, opts, h), "dpq_open_memory")
         return cls(h)
 
     @classmethod
     def open_plain(cls, codes, K=256, device=0, shard_rank=0, shard_count=1, chunks_per_segment=0, cand_capacity=0,
-                   num_codes=0, bootstrap=0):
+                   num_codes=0, bootstrap=0, **tune):
         """Uncompressed comparator index (`-task pqscan`, h:2590-2678): raw codes, fp32-accumulated distances."""
         lib = _lib.load()
         c = np.ascontiguousarray(codes, dtype=np.uint8)
-        opts = OpenOpts(device, shard_rank, shard_count, chunks_per_segment, cand_capacity, num_codes, bootstrap)
+        opts = _apply_tuning(OpenOpts(device, shard_rank, shard_count, chunks_per_segment, cand_capacity, num_codes, bootstrap), tune)
         h = ctypes.c_void_p()
         check(lib.dpq_open_plain_memory(_np_ptr(c), c.shape[0], c.shape[1], K, opts, h), "dpq_open_plain_memory")
         return cls(h)

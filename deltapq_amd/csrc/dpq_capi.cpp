@@ -67,7 +67,7 @@ int dev_alloc(T** p, size_t count) {
 }
 
 struct EventPair {
-    int kind;  // 0 lut, 1 scan, 2 select, 3 quantise
+    int kind;  // 0 lut, 1 scan, 2 select, 3 quantise, 4 per-batch decode, 5 bootstrap
     hipEvent_t a, b;
 };
 
@@ -83,7 +83,18 @@ struct dpq_tree {
     dpq::Tree tree;
 };
 
+// Plan and tiling knobs of a handle: dpq_open_opts' fields with the defaults filled in (resolve_tuning).
+struct Tuning {
+    int stream_max = 8;          // batches up to this size take stream_kernel
+    int coarse_below = 128;
+    int plan_ratios[3] = {0, 0, 0};
+    int boot_cap = 0, boot_target = 0;
+    int64_t batch_tile_nodes = (int64_t)16 << 20;
+    bool relabel = true, fuse_quantise = true, async_overlap = true, boot_fullsort = false;
+};
+
 struct dpq_index {
+    Tuning tune;
     int device = 0;
     int M = 8, K = 256, Ds = 0;
     int cap = 0;
@@ -186,6 +197,38 @@ struct dpq_index {
 
 namespace {
 
+// dpq_open_opts -> Tuning.  The environment takes part only with DPQ_DEV=1 (developer sweeps: scripts/), and only
+// here, once per dpq_open_*: a product process' plan never depends on its environment.
+Tuning resolve_tuning(const dpq_open_opts& o) {
+    Tuning t;
+    if (o.stream_max_queries != 0) t.stream_max = std::max(0, o.stream_max_queries);
+    if (o.coarse_below > 0) t.coarse_below = o.coarse_below;
+    for (int i = 0; i < 3; ++i) t.plan_ratios[i] = o.plan_ratios[i];
+    t.boot_cap = std::max(0, o.boot_cap);
+    t.boot_target = std::max(0, o.boot_target);
+    if (o.batch_tile_nodes > 0) t.batch_tile_nodes = o.batch_tile_nodes;
+    t.relabel = !(o.flags & DPQ_OPT_NO_RELABEL);
+    t.fuse_quantise = !(o.flags & DPQ_OPT_NO_FUSE_QUANTISE);
+    t.async_overlap = !(o.flags & DPQ_OPT_NO_ASYNC_OVERLAP);
+    t.boot_fullsort = (o.flags & DPQ_OPT_BOOT_FULLSORT) != 0;
+    const char* dev = getenv("DPQ_DEV");
+    if (dev && atoi(dev) != 0) {
+        auto geti = [](const char* name, int* v) { if (const char* e = getenv(name)) *v = atoi(e); };
+        geti("DPQ_STREAM_MAX_QUERIES", &t.stream_max);
+        geti("DPQ_COARSE_BELOW", &t.coarse_below);
+        if (const char* e = getenv("DPQ_PLAN_RATIOS")) sscanf(e, "%d,%d,%d", &t.plan_ratios[0], &t.plan_ratios[1], &t.plan_ratios[2]);
+        geti("DPQ_BOOT_CAP", &t.boot_cap);
+        geti("DPQ_BOOT_TARGET", &t.boot_target);
+        if (const char* e = getenv("DPQ_BATCH_TILE_NODES")) t.batch_tile_nodes = std::max<int64_t>(1, atoll(e));
+        int v = 1;
+        geti("DPQ_RELABEL", &v); t.relabel = t.relabel && v != 0;
+        v = 1; geti("DPQ_FUSE_QUANTISE", &v); t.fuse_quantise = t.fuse_quantise && v != 0;
+        v = 1; geti("DPQ_ASYNC_OVERLAP", &v); t.async_overlap = t.async_overlap && v != 0;
+        v = 0; geti("DPQ_BOOT_FULLSORT", &v); t.boot_fullsort = t.boot_fullsort || v != 0;
+    }
+    return t;
+}
+
 void switch_lane(dpq_index* x, int lane) {
     if (lane == x->active_lane) return;
     dpq_index::Lane cur;
@@ -281,14 +324,13 @@ int ensure_plan(dpq_index* x, int top_k, int cap, int coarse) {
         // The bootstrap kernel delivers the first threshold (no segments consumed: level 0 is empty), as tight
         // as the k-th of a spread sample of a quarter of a 1 M-node index; the filter levels then cover ALL
         // segments.  One level up to 2 M nodes; beyond, levels growing by 8 (a larger shard's first threshold
-        // admits more nodes in absolute terms); top_k > 512: see below.  DPQ_PLAN_RATIOS=a[,b[,c]] forces levels.
+        // admits more nodes in absolute terms); top_k > 512: see below.  dpq_open_opts.plan_ratios forces levels.
         bounds.push_back(nseg);
         std::vector<int> ratios;
-        int forced[3] = {0, 0, 0};
-        if (const char* ev = getenv("DPQ_PLAN_RATIOS")) sscanf(ev, "%d,%d,%d", &forced[0], &forced[1], &forced[2]);
+        const int* forced = x->tune.plan_ratios;
         if (forced[0] >= 2) {
-            for (int f : forced)
-                if (f >= 2) ratios.push_back(f);
+            for (int i = 0; i < 3; ++i)
+                if (forced[i] >= 2) ratios.push_back(forced[i]);
         } else {
             for (int64_t b = nseg; b * S > ((int64_t)2 << 20); b /= 8) ratios.push_back(8);
             // A large top_k takes its first threshold from a worse quantile of the bootstrap sample (the 1000th of
@@ -311,12 +353,13 @@ int ensure_plan(dpq_index* x, int top_k, int cap, int coarse) {
         bounds.push_back(nseg);
         // large batches: level sizes shrink by 4, 8, 8 from the full index down at top-100 (three filter levels
         // at 1 M codes); measured best trade between per-level fixed cost and survivor handling.
-        // DPQ_PLAN_RATIOS=a,b,c overrides it for experiments.
+        // dpq_open_opts.plan_ratios overrides it for experiments.
         // A level costs a fixed ~45 us (scan prologue, launch, select) plus ~top_k * (ratio - 1) candidates per
         // query to check and select: the best ratio falls with top_k (measured: 8 at top-100, 3 at top-1000).
         const int r = (int)std::lround(std::min(16.0, std::max(2.0, 8.0 * std::sqrt(100.0 / (double)top_k))));
         int fine[] = {r >= 16 ? r : std::max(2, r / 2), r, r};  // few candidates (small top_k): the fewest levels win
-        if (const char* ev = getenv("DPQ_PLAN_RATIOS")) sscanf(ev, "%d,%d,%d", &fine[0], &fine[1], &fine[2]);
+        for (int i = 0; i < 3; ++i)
+            if (x->tune.plan_ratios[i] >= 2) fine[i] = x->tune.plan_ratios[i];
         for (int& f : fine) f = std::max(2, f);
         // expected survivors of a level = top_k * (ratio - 1) must stay well inside the candidate buffer
         const int wide = (int)std::max<int64_t>(2, std::min<int64_t>(16, cap / (2 * (int64_t)top_k)));
@@ -398,11 +441,10 @@ struct Timer {
 // Plain-code scratch of a batch (per pipeline lane): one TILE of a filter level's segment list at a time -- decode the
 // tile, scan it with every query group, next tile -- so the scratch stays Infinity-Cache-sized whatever the shard
 // (16 M nodes = 128 MB at M = 8; the 1 M-code headline and a 12.5 M-code shard are one tile, a 125 M-code shard's
-// last level eight).  DPQ_BATCH_TILE_NODES overrides; dpq_open_opts.batch_decode >= 2 = tile of that many segments.
+// last level eight).  dpq_open_opts.batch_tile_nodes overrides; dpq_open_opts.batch_decode >= 2 = tile of that many segments.
 int64_t batch_tile_segments(const dpq_index* x) {
-    static const int64_t env_nodes = getenv("DPQ_BATCH_TILE_NODES") ? atoll(getenv("DPQ_BATCH_TILE_NODES")) : 0;
     const int64_t S = (int64_t)dpq::kChunk * x->img.chunks_per_segment;
-    int64_t t = x->batch_decode >= 2 ? x->batch_decode : std::max<int64_t>(1, (env_nodes > 0 ? env_nodes : ((int64_t)16 << 20)) / S);
+    int64_t t = x->batch_decode >= 2 ? x->batch_decode : std::max<int64_t>(1, x->tune.batch_tile_nodes / S);
     return std::min<int64_t>(t, std::max<int64_t>(1, x->img.n_segments));
 }
 int64_t batch_raw_bytes(const dpq_index* x) {
@@ -425,28 +467,34 @@ int splits_for(int n_seg_pass, int n_groups) {
     return std::max(1, std::min(n_seg_pass, want));
 }
 
-// Candidate-buffer geometry of one scan launch: region 0 (top_k keys) carries the winners of the
-// previous level, then one region per scan workgroup of a query group (no global atomics: a
-// workgroup appends to its own region).
+// Candidate-buffer geometry of one scan launch, in 8-byte words: region 0 (top_k keys) carries the winners of the
+// previous level, then one region per scan workgroup of a query group (no global atomics: a workgroup appends to
+// its own region) of region_cap ENTRIES -- filter survivors (code, id) of `words` words each, which the select kernel
+// checks exactly.
 struct Regions {
     int splits;
-    int region_cap;
-    int64_t stride;  // keys per slot
+    int region_cap;  // entries
+    int words;       // 8-byte words per entry
+    int64_t stride;  // words per slot
 };
 
 Regions regions_for(const dpq_index* x, int n_seg_pass, int n_groups, int top_k, int cap) {
     Regions r;
     r.splits = splits_for(n_seg_pass, n_groups);
+    r.words = dpq::survivor_entry_words(x->M);
     r.region_cap = (cap - top_k) / r.splits;
-    // automatic sizing: a query's candidates cluster in few segments (DFS neighbours are similar codes), so a
-    // region must absorb a few dense segments; 16 K keys per slot, at least one segment's worth per region,
+    // automatic sizing: a query's survivors cluster in few segments (DFS neighbours are similar codes), so a
+    // region must absorb a few dense segments; 16 K entries per slot, at least one segment's worth per region,
     // and four times a level's expected candidates (top_k x 16) spread over the regions
     if (x->cap_auto)
         r.region_cap = std::max(r.region_cap, std::max(std::max(256, 16384 / r.splits), 64 * top_k / r.splits));
     r.region_cap = std::max(r.region_cap, 1);
-    r.stride = (int64_t)top_k + (int64_t)r.splits * r.region_cap;
+    r.stride = (int64_t)top_k + (int64_t)r.splits * r.region_cap * r.words;
     return r;
 }
+
+// keys the select kernel holds in LDS (a longer list goes through its HBM scratch)
+int select_lds_keys(int top_k) { return std::min(dpq::kSelectMaxLdsKeys, std::max(2048, 8 * top_k)); }
 
 // One sub-batch (nq <= kMaxBatchQueries) end to end on `stream`.
 // flag_slot 0: synchronous (waits, checks the overflow word, reruns what overflowed); > 0: enqueue only,
@@ -458,8 +506,7 @@ int run_batch(dpq_index* x, const float* d_queries, int nq, int top_k, int32_t* 
     const int ngroups = nqp / QG;
     const int cap = x->cap_auto ? auto_cap(top_k) : std::max(x->cap, top_k);
     int rc;
-    static const int coarse_below = getenv("DPQ_COARSE_BELOW") ? atoi(getenv("DPQ_COARSE_BELOW")) : 128;
-    if ((rc = ensure_plan(x, top_k, cap, nq <= coarse_below ? 1 : 0))) return rc;
+    if ((rc = ensure_plan(x, top_k, cap, nq <= x->tune.coarse_below ? 1 : 0))) return rc;
     int64_t stride = top_k;
     for (size_t l = 1; l < x->level_cnt.size(); ++l)
         stride = std::max(stride, regions_for(x, x->level_cnt[l], ngroups, top_k, cap).stride);
@@ -477,9 +524,8 @@ int run_batch(dpq_index* x, const float* d_queries, int nq, int top_k, int32_t* 
     // Measured on 1 M codes x 1000 queries (16 groups): scan 0.166 -> 0.122 ms, step 0.212 -> 0.172 ms.
     // One or two queries (the reference's own call shape): one query per pass over the compressed image, every node
     // evaluated against the exact table (stream_kernel) -- no filter tables, no 64-query group machinery.
-    // DPQ_STREAM_MAX_QUERIES overrides the batch size up to which this mode is used (0 = never).
-    static const int stream_max = getenv("DPQ_STREAM_MAX_QUERIES") ? atoi(getenv("DPQ_STREAM_MAX_QUERIES")) : 2;
-    const bool direct = !x->plain && nq <= stream_max;
+    // dpq_open_opts.stream_max_queries: the batch size up to which this mode is used (-1 = never).
+    const bool direct = !x->plain && nq <= x->tune.stream_max;
     const bool scratch = !direct && use_batch_decode(x, ngroups);
     if (scratch && (rc = ensure_batch_raw(x))) return rc;
     const int64_t tile_segs = scratch ? batch_tile_segments(x) : 0;
@@ -529,6 +575,8 @@ int run_batch(dpq_index* x, const float* d_queries, int nq, int top_k, int32_t* 
     se.scratch = x->d_scratch;
     se.lut32 = x->d_lut32;
     se.slot_query = nullptr;
+    se.n_lds_keys = select_lds_keys(top_k);
+    se.counters = sa.counters;
     se.top_k = top_k;
     se.thr_key = x->d_thr_key;
     se.overflow = x->d_overflow;
@@ -552,10 +600,10 @@ int run_batch(dpq_index* x, const float* d_queries, int nq, int top_k, int32_t* 
         const bool final_pass = l + 1 == n_levels;
         if (l == 0 && x->boot) {
             // level 0 with a multi-index: the nodes of the query's best cells, evaluated exactly -> first threshold
-            static const int cap_env = getenv("DPQ_BOOT_CAP") ? atoi(getenv("DPQ_BOOT_CAP")) : 0;
+            const int cap_env = x->tune.boot_cap;
             dpq::BootArgs ba{};
             ba.cell_start = x->d_mi_cell;
-            static const bool full_sort = getenv("DPQ_BOOT_FULLSORT") && atoi(getenv("DPQ_BOOT_FULLSORT")) != 0;  // developer A/B
+            const bool full_sort = x->tune.boot_fullsort;  // developer A/B
             ba.nbr = full_sort ? nullptr : x->d_nbr;
             ba.n_classes = x->boot_classes;
             ba.mi_code = x->d_mi_code;
@@ -573,24 +621,24 @@ int run_batch(dpq_index* x, const float* d_queries, int nq, int top_k, int32_t* 
             const int cap_auto = top_k <= 256 ? (x->M <= 8 ? 3072 : 6144) : 12288;
             ba.cap = std::max(std::min(cap_env > 0 ? cap_env : cap_auto, 16384), std::max(top_k, 2048));
             ba.cap = (ba.cap + 63) / 64 * 64;
-            static const int target_env = getenv("DPQ_BOOT_TARGET") ? atoi(getenv("DPQ_BOOT_TARGET")) : 0;
+            const int target_env = x->tune.boot_target;
             ba.target = target_env > 0 ? std::min(ba.cap, std::max(target_env, top_k)) : ba.cap;
             ba.thr_key = x->d_thr_key;
             ba.cand_count = x->d_cand_count;
             ba.fp32_accum = x->plain ? 1 : 0;
             ba.stamps = x->d_boot_stamps;
             ba.n_queries = nq;
-            // DPQ_FUSE_QUANTISE=0: the first level's tables from quantise_kernel, as for every later level
-            static const bool fuse = !(getenv("DPQ_FUSE_QUANTISE") && atoi(getenv("DPQ_FUSE_QUANTISE")) == 0);
+            // DPQ_OPT_NO_FUSE_QUANTISE: the first level's tables from quantise_kernel, as for every later level
+            const bool fuse = x->tune.fuse_quantise;
             ba.qtab = fuse && !direct ? x->d_qtab : nullptr;
             ba.relabel = scratch ? x->d_relabel : nullptr;
             ba.lut_min = x->d_lut_min;
             boot_built_tables = fuse && !direct;
             {
-                Timer t(x, stream, 2);
+                Timer t(x, stream, 5);
                 DPQ_HIP(dpq::launch_bootstrap(ba, x->M, fuse && !direct ? nqp : nq, stream));
             }
-            if (x->prof) x->prof_acc.select_launches++;
+            if (x->prof) x->prof_acc.bootstrap_launches++;
             continue;
         }
         if (l == 0) {
@@ -598,6 +646,8 @@ int run_batch(dpq_index* x, const float* d_queries, int nq, int top_k, int32_t* 
             se.shared_id = x->d_l0_id;
             se.shared_code = x->d_l0_code;
             se.shared_n = (int)(x->level_cnt[0] * S);
+            se.entries = 0;
+            se.lut32 = x->d_lut32;       // the level-0 list holds code values
         } else {
             se.shared_id = nullptr;
             se.shared_code = nullptr;
@@ -607,9 +657,11 @@ int run_batch(dpq_index* x, const float* d_queries, int nq, int top_k, int32_t* 
             sa.n_seg_pass = x->level_cnt[l];
             const Regions rg = regions_for(x, sa.n_seg_pass, ngroups, top_k, cap);
             if (direct) {
-                // one region per slot behind the carried winners, filled through a global counter
+                // one region of exact keys per slot behind the carried winners, filled through a global counter
                 sa.region_cap = se.region_cap = (int32_t)std::min<int64_t>(stride - top_k, INT32_MAX);
                 se.n_regions = 2;
+                se.entries = 0;
+                se.lut32 = x->d_lut32;
                 DPQ_HIP(hipMemset2DAsync(x->d_cand_count + 1, sizeof(uint32_t) * dpq::kRegionStride, 0, sizeof(uint32_t),
                                          (size_t)nq, stream));
                 {
@@ -624,6 +676,8 @@ int run_batch(dpq_index* x, const float* d_queries, int nq, int top_k, int32_t* 
             } else {
             sa.region_cap = se.region_cap = rg.region_cap;
             se.n_regions = 1 + rg.splits;
+            se.entries = 1;              // the scan's filter survivors, checked exactly by the select kernel
+            se.lut32 = sa.lut32;         // ... against the tables whose rows follow the labels of the codes it read
             if (!(boot_built_tables && l == 1)) {  // the bootstrap kernel wrote the first level's tables itself
                 Timer t(x, stream, 3);
                 DPQ_HIP(dpq::launch_quantise(sa, ngroups, stream));
@@ -703,11 +757,11 @@ int run_batch(dpq_index* x, const float* d_queries, int nq, int top_k, int32_t* 
         slot_query[i] = over[i];
         k2[i] = h_key[(size_t)over[i]];
     }
-    // few, large regions: with a tight threshold the candidates of a query may all sit in one workgroup's share
+    // few, large regions: with a tight threshold the survivors of a query may all sit in one workgroup's share
     const int splits2 = std::min(16, splits_for(x->img.n_segments, ng2));
     int64_t rcap2 = std::max<int64_t>(2 * (int64_t)top_k, 1024);
     for (int attempt = 0;; ++attempt) {
-        const int64_t stride2 = (int64_t)top_k + (int64_t)splits2 * rcap2;
+        const int64_t stride2 = (int64_t)top_k + (int64_t)splits2 * rcap2 * dpq::survivor_entry_words(x->M);
         int32_t* d_slot_query = nullptr;
         uint32_t *c_count = nullptr, *c_over = nullptr;
         uint64_t *c_keys = nullptr, *c_scratch = nullptr, *c_tk = nullptr;
@@ -763,6 +817,8 @@ int run_batch(dpq_index* x, const float* d_queries, int nq, int top_k, int32_t* 
         se.shared_id = nullptr;
         se.shared_code = nullptr;
         se.shared_n = 0;
+        se.entries = 1;
+        se.lut32 = sa.lut32;
         se.cand_count = c_count;
         se.cand_key = c_keys;
         se.cand_stride = stride2;
@@ -794,9 +850,12 @@ int open_from_payload(const uint8_t* payload, int64_t n_bytes, int64_t n_codes, 
     if (M != 8 && M != 16)
         return fail(DPQ_ERR_ARG, "this build has scan kernels for M = 8 (reference format) and M = 16 (own extension)");
     if (K < 1 || K > 256) return fail(DPQ_ERR_ARG, "K must be in 1..256 (one byte per sub-code)");
-    if (o.global_offset < 0 || o.global_n_codes < 0 ||
-        (o.global_n_codes > 0 && (o.global_offset + n_codes > o.global_n_codes || o.global_n_codes >= (int64_t)INT32_MAX)))
-        return fail(DPQ_ERR_ARG, "global_offset / global_n_codes do not enclose this payload (or ids beyond 2^31)");
+    if (o.global_offset < 0 || o.global_n_codes < 0 || (o.global_offset != 0 && o.global_n_codes == 0) ||
+        (o.global_n_codes > 0 && o.global_offset + n_codes > o.global_n_codes))
+        return fail(DPQ_ERR_ARG, "global_offset / global_n_codes do not enclose this payload (a part of a larger index "
+                                 "needs global_n_codes > 0)");
+    if (n_codes >= (int64_t)INT32_MAX || o.global_n_codes >= (int64_t)INT32_MAX || o.global_offset + n_codes >= (int64_t)INT32_MAX)
+        return fail(DPQ_ERR_ARG, "ids beyond 2^31 - 1: results carry int32 DFS positions (h:2979)");
     if (o.chunks_per_segment > dpq::kSortMax / dpq::kChunk)
         return fail(DPQ_ERR_ARG, "chunks_per_segment must be <= 64 (a segment is the cascade's level-0 unit)");
     int ndev = 0;
@@ -823,6 +882,7 @@ int open_from_payload(const uint8_t* payload, int64_t n_bytes, int64_t n_codes, 
     x->cap_auto = o.cand_capacity <= 0;
     x->cap = o.cand_capacity;
     x->batch_decode = o.batch_decode;
+    x->tune = resolve_tuning(o);
     auto up = [&](auto** dptr, const void* src, size_t bytes) -> int {
         using T = std::remove_pointer_t<std::remove_pointer_t<decltype(dptr)>>;
         int r = dev_alloc(dptr, (bytes + sizeof(T) - 1) / sizeof(T) + 64 / sizeof(T));
@@ -849,8 +909,7 @@ int open_from_payload(const uint8_t* payload, int64_t n_bytes, int64_t n_codes, 
         x->boot = !rc;
         x->boot_classes = soa.mi_classes;
     }
-    static const bool relabel_env = !(getenv("DPQ_RELABEL") && atoi(getenv("DPQ_RELABEL")) == 0);  // developer A/B
-    if (!rc && relabel_env && soa.relabel.size() == (size_t)M * 256) {
+    if (!rc && x->tune.relabel && soa.relabel.size() == (size_t)M * 256) {
         rc = up(&x->d_relabel, soa.relabel.data(), soa.relabel.size());
     }
     if (rc) {
@@ -923,6 +982,7 @@ int open_plain(const uint8_t* codes, int64_t n_codes, int M, int K, const dpq_op
     x->M = M;
     x->K = K;
     x->plain = true;
+    x->tune = resolve_tuning(o);
     x->cap_auto = o.cand_capacity <= 0;
     x->cap = o.cand_capacity;
     const size_t padded = (size_t)(seg_hi - seg_lo) * S * M;
@@ -1189,8 +1249,9 @@ int dpq_tree_build_gpu(const uint8_t* codes, int64_t n_codes, int M, int K, int 
     int rc = dpq::find_edges_gpu(codes, n_codes, M, max_height_folds, device, &finalists, &edges, &err);
     if (rc) return fail(rc, err);
     dpq_tree* t = new dpq_tree();
-    // DPQ_BUILD_LAYOUT=host keeps the layout on the host (A/B for the tests; same tree either way)
-    static const bool host_layout = getenv("DPQ_BUILD_LAYOUT") && std::string(getenv("DPQ_BUILD_LAYOUT")) == "host";
+    // DPQ_DEV=1 DPQ_BUILD_LAYOUT=host keeps the layout on the host (developer A/B; same tree either way)
+    static const bool host_layout = getenv("DPQ_DEV") && atoi(getenv("DPQ_DEV")) != 0 && getenv("DPQ_BUILD_LAYOUT") &&
+                                    std::string(getenv("DPQ_BUILD_LAYOUT")) == "host";
     rc = host_layout ? dpq::layout_tree(codes, n_codes, M, K, max_height_folds, codewords, Ds, finalists, &edges, &t->tree, &err)
                      : dpq::layout_tree_gpu(codes, n_codes, M, K, max_height_folds, codewords, Ds, finalists, &edges, device,
                                             &t->tree, &err);
@@ -1527,19 +1588,35 @@ int dpq_finish(dpq_index* x) {
     todo.swap(x->pending);
     {
         std::vector<hipStream_t> seen;
+        hipError_t e = hipSuccess;
         for (const auto& p : todo)
             if (std::find(seen.begin(), seen.end(), p.stream) == seen.end()) {
-                DPQ_HIP(hipStreamSynchronize(p.stream));
+                const hipError_t r = hipStreamSynchronize(p.stream);
+                if (e == hipSuccess) e = r;
                 seen.push_back(p.stream);
             }
+        if (e != hipSuccess) {  // the device is in an error state: nothing can be rerun; the batches stay pending
+            x->pending.insert(x->pending.begin(), todo.begin(), todo.end());
+            return fail(DPQ_ERR_HIP, std::string("dpq_finish: ") + hipGetErrorString(e));
+        }
     }
+    // Every stream a pending batch ran on is idle from here on (synchronised above; nothing is enqueued while this
+    // function runs: a handle belongs to one thread at a time), so a rerun may use whichever lane's workspace is
+    // active.  Every batch is settled even if one fails: its callers' buffers must not keep an incomplete list behind
+    // a later dpq_finish that has nothing left to report.  The first error is returned.
+    int first_rc = DPQ_OK;
+    std::string first_msg;
     for (const auto& p : todo) {
         if (*reinterpret_cast<volatile uint32_t*>(x->h_any + p.flag_slot) == 0) continue;
         // a query of this batch dropped candidates: answer the batch again, synchronously (it reruns what overflows)
         x->finish_reruns++;
         int rc = run_batch(x, p.d_queries, p.nq, p.top_k, p.d_ids, p.d_dists, p.stream);
-        if (rc) return rc;
+        if (rc && !first_rc) {
+            first_rc = rc;
+            first_msg = g_last_error;
+        }
     }
+    if (first_rc) return fail(first_rc, first_msg);
     return DPQ_OK;
     });
 }
@@ -1577,9 +1654,8 @@ int enqueue_async(dpq_index* x, const float* d_queries, int nq, int top_k, int32
     if (rc || nq == 0) return rc;
     DPQ_HIP(hipSetDevice(x->device));
     hipStream_t user = reinterpret_cast<hipStream_t>(hip_stream);
-    // DPQ_ASYNC_OVERLAP=0: every batch on the caller's stream with one workspace (round 1's behaviour)
-    static const bool overlap_env = !(getenv("DPQ_ASYNC_OVERLAP") && atoi(getenv("DPQ_ASYNC_OVERLAP")) == 0);
-    const bool overlap = overlap_env && allow_lanes;
+    // DPQ_OPT_NO_ASYNC_OVERLAP: every batch on the caller's stream with one workspace (round 1's behaviour)
+    const bool overlap = x->tune.async_overlap && allow_lanes;
     auto in_flight_on_other_stream = [&]() {
         for (const auto& p : x->pending)
             if (p.user_stream != user) return true;
@@ -1808,7 +1884,7 @@ int dpq_debug_scan_time(dpq_index* x, int nq, int pass_all, int reps, int splits
     sa.cand_key = x->d_cand_key;
     sa.cand_stride = x->ws_cap;
     sa.region_off = 0;
-    sa.region_cap = std::max(1, x->ws_cap / splits);
+    sa.region_cap = std::max(1, x->ws_cap / splits / dpq::survivor_entry_words(x->M));
     sa.qtab = x->d_qtab;
     hipEvent_t a, b;
     DPQ_HIP(hipEventCreate(&a));
@@ -1885,7 +1961,7 @@ int dpq_debug_scan_stamps(dpq_index* x, int nq, int splits, unsigned long long* 
     sa.cand_key = x->d_cand_key;
     sa.cand_stride = x->ws_cap;
     sa.region_off = 0;
-    sa.region_cap = std::max(1, x->ws_cap / splits);
+    sa.region_cap = std::max(1, x->ws_cap / splits / dpq::survivor_entry_words(x->M));
     sa.qtab = x->d_qtab;
     sa.stamps = d_st;
     hipEvent_t a, b;
@@ -2035,6 +2111,7 @@ int dpq_profile_read(dpq_index* x, dpq_profile* out) {
         if (ep.kind == 2) x->prof_acc.select_ms += ms;
         if (ep.kind == 3) x->prof_acc.quantise_ms += ms;
         if (ep.kind == 4) x->prof_acc.decode_ms += ms;
+        if (ep.kind == 5) x->prof_acc.bootstrap_ms += ms;
         x->ev_pool.push_back(ep.a);
         x->ev_pool.push_back(ep.b);
     }

@@ -104,9 +104,31 @@ typedef struct dpq_open_opts {
                                  * identical either way. */
     int64_t global_offset;      /* the payload is a self-contained PART of a larger index (its first node carries a
                                  * whole code): ids are reported as global_offset + position in this payload */
-    int64_t global_n_codes;     /* 0 = this payload is the whole index; else N of the larger index (the even-N id
-                                 * rule h:2949, 2970 then applies to its last node only) */
+    int64_t global_n_codes;     /* 0 = this payload is the whole index (global_offset must then be 0); else N of the
+                                 * larger index (the even-N id rule h:2949, 2970 then applies to its last node only) */
+    /* ---- plan and tiling knobs.  0 = the measured default; results are identical whatever they hold.  They are
+     * part of the options (not of the environment) so that the ranks of a multi-GPU launch cannot diverge from
+     * each other through their environments.  With DPQ_DEV=1 in the environment -- developer sweeps only -- the
+     * variables named in brackets override them, read once per dpq_open_*. ---- */
+    int32_t stream_max_queries; /* batches of up to this many queries take the one-pass-per-query-set stream kernel
+                                 * (exact tables in LDS, no filter tables) instead of the 64-query filter scan: 0 = the
+                                 * measured switch-over (8), -1 = never  [DPQ_STREAM_MAX_QUERIES] */
+    int32_t coarse_below;       /* batches of up to this many queries use the coarse cascade plan on shards without a
+                                 * threshold bootstrap; 0 = 128  [DPQ_COARSE_BELOW] */
+    int32_t plan_ratios[3];     /* force the size ratios between consecutive filter levels (each >= 2); 0 = automatic
+                                 *   [DPQ_PLAN_RATIOS=a,b,c] */
+    int32_t boot_cap;           /* nodes a bootstrap block may hold (2048..16384); 0 = 3072 / 6144 (M = 16) / 12288
+                                 * (top_k > 256)  [DPQ_BOOT_CAP] */
+    int32_t boot_target;        /* nodes after which the bootstrap stops walking cells; 0 = boot_cap  [DPQ_BOOT_TARGET] */
+    int32_t flags;              /* DPQ_OPT_* bits below */
+    int64_t batch_tile_nodes;   /* nodes per tile of the per-batch plain-code scratch; 0 = 16 M  [DPQ_BATCH_TILE_NODES] */
 } dpq_open_opts;
+
+/* dpq_open_opts.flags (developer A/B switches; every combination gives the same results) */
+#define DPQ_OPT_NO_RELABEL 1u       /* plain-code scratch holds code values, not bank-aware labels  [DPQ_RELABEL=0] */
+#define DPQ_OPT_NO_FUSE_QUANTISE 2u /* first filter level's tables by quantise_kernel, not by the bootstrap  [DPQ_FUSE_QUANTISE=0] */
+#define DPQ_OPT_NO_ASYNC_OVERLAP 4u /* dpq_query_batch_device_async: one workspace, the caller's stream  [DPQ_ASYNC_OVERLAP=0] */
+#define DPQ_OPT_BOOT_FULLSORT 8u    /* bootstrap ranks all 256 centroids exactly  [DPQ_BOOT_FULLSORT=1] */
 
 typedef struct dpq_info {
     int64_t n_codes_total;     /* N of the whole index (header field 0, h:1839-1840) */
@@ -140,6 +162,8 @@ typedef struct dpq_profile {
     int64_t candidates;                /* pairs that passed the exact check (counted with dpq_profile_enable(idx, 1) only) */
     double quantise_ms;                /* filter-table builds (one per scan launch; dpq_profile_enable(idx, 1) only) */
     double decode_ms;                  /* per-batch decodes into the plain-code scratch (dpq_profile_enable(idx, 1) only) */
+    double bootstrap_ms;               /* threshold bootstrap launches (NOT part of select_ms; dpq_profile_enable(idx, 1) only) */
+    int64_t bootstrap_launches;
 } dpq_profile;
 
 typedef struct dpq_dtc_stats {
@@ -265,7 +289,7 @@ int dpq_query_batch_device(dpq_index* idx, const float* d_queries, int nq, int t
  * synchronously, any batch in which a query overflowed its candidate buffers.  A call with a different
  * `hip_stream` first finishes what is in flight; up to 63 batches may be in flight, the 64th call finishes the
  * earlier ones first.  The synchronous entry points finish pending batches before they start.
- * (Environment DPQ_ASYNC_OVERLAP=0: every batch on `hip_stream` itself, one workspace.) */
+ * (dpq_open_opts.flags & DPQ_OPT_NO_ASYNC_OVERLAP: every batch on `hip_stream` itself, one workspace.) */
 int dpq_query_batch_device_async(dpq_index* idx, const float* d_queries, int nq, int top_k, int32_t* d_ids,
                                  float* d_dists, void* hip_stream);
 int dpq_finish(dpq_index* idx);

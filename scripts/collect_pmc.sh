@@ -1,4 +1,5 @@
 #!/bin/bash
+export DPQ_DEV=1   # developer switches of the library are read only with this set
 # Runs ON THE GPU BOX (via gpurun): kernel-trace stats + two separate PMC passes (FETCH_SIZE, WRITE_SIZE) of a
 # bench.py workload, summarised into gpurun_out/<tag>/.  PMC passes use only --kernel-trace, as the pool requires.
 #   gpurun -- 'bash scripts/collect_pmc.sh r02_default'

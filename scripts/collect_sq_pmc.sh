@@ -1,4 +1,5 @@
 #!/bin/bash
+export DPQ_DEV=1   # developer switches of the library are read only with this set
 # Runs ON THE GPU BOX (via gpurun): SQ / LDS counters of the scan kernel on a bench.py workload,
 # one rocprofv3 --pmc pass per counter group (only --kernel-trace beside it, as the pool requires).
 #   gpurun -- 'bash scripts/collect_sq_pmc.sh r02_sq [bench args]'

@@ -1,5 +1,7 @@
 """End-to-end DeltaTree build time of 1 M SIFT-shaped codes (GPU box): edge search + layout on the GPU vs layout on the host."""
-import os, sys, time, subprocess
+import os
+import sys, time, subprocess
+os.environ.setdefault("DPQ_DEV", "1")   # developer switches of the library are read only with this set
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from deltapq_amd import api, synth

@@ -1,4 +1,5 @@
 #!/bin/bash
+export DPQ_DEV=1   # developer switches of the library are read only with this set
 # top-1000: bootstrap capacity beyond 8192 (M = 8 and M = 16)
 mkdir -p gpurun_out
 for m in 8 16; do

@@ -1,4 +1,5 @@
 #!/bin/bash
+export DPQ_DEV=1   # developer switches of the library are read only with this set
 mkdir -p gpurun_out
 for cap in 3072 4096 6144 3072 4096 6144; do
 DPQ_BOOT_CAP=$cap python bench.py --no-cpu-baseline --reps 5 > gpurun_out/bc.json 2>gpurun_out/bc.err || { tail -5 gpurun_out/bc.err; exit 1; }

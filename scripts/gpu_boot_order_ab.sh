@@ -1,4 +1,5 @@
 #!/bin/bash
+export DPQ_DEV=1   # developer switches of the library are read only with this set
 # A/B of the bootstrap's centroid visiting order: neighbour lists (default) against the exact 256-key sorts.
 mkdir -p gpurun_out
 python -m pytest tests -m gpu -x -q > gpurun_out/ab_pytest.log 2>&1 || { tail -30 gpurun_out/ab_pytest.log; exit 1; }

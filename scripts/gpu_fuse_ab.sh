@@ -1,4 +1,5 @@
 #!/bin/bash
+export DPQ_DEV=1   # developer switches of the library are read only with this set
 cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out/r02i
 python -m pytest tests -m gpu -x -q 2>&1 | tail -3

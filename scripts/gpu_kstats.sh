@@ -1,4 +1,5 @@
 #!/bin/bash
+export DPQ_DEV=1   # developer switches of the library are read only with this set
 # usage: gpu_kstats.sh TAG [ENV=VAL ...] -- per-kernel average times of the default bench under rocprofv3 --kernel-trace --stats
 set -o pipefail
 TAG=$1; shift

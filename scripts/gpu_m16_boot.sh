@@ -1,4 +1,5 @@
 #!/bin/bash
+export DPQ_DEV=1   # developer switches of the library are read only with this set
 # M = 16: bootstrap capacity / target against the step time (top-100 and top-1000)
 mkdir -p gpurun_out
 for cfg in "0 0" "4096 0" "6144 0" "8192 0" "3072 2048" ; do

@@ -1,4 +1,5 @@
 #!/bin/bash
+export DPQ_DEV=1   # developer switches of the library are read only with this set
 # top-1000: cascade plans behind the bootstrap (M = 8 at cap 8192 and 12288, M = 16 at cap 12288)
 mkdir -p gpurun_out
 for cfg in "8 0" "8 12288" "16 12288"; do

@@ -1,4 +1,5 @@
 #!/bin/bash
+export DPQ_DEV=1   # developer switches of the library are read only with this set
 # one query per pass (stream_kernel) against the 64-query filter path on big and small shards
 mkdir -p gpurun_out
 for cfg in "125000000 1 2" "125000000 1 0" "125000000 2 2" "125000000 4 4" "125000000 4 0" "12500000 1 2" "12500000 1 0"; do

@@ -1,4 +1,5 @@
 #!/bin/bash
+export DPQ_DEV=1   # developer switches of the library are read only with this set
 cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out/r02e
 run() { tag=$1; shift; env "$@" timeout -k 10 300 python bench.py --m 16 --topk 1000 --steps 10 --warmup 2 --reps 3 --check 4 --no-cpu-baseline $EXTRA > gpurun_out/r02e/sweep_$tag.json 2>/dev/null

@@ -1,4 +1,5 @@
 #!/bin/bash
+export DPQ_DEV=1   # developer switches of the library are read only with this set
 cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out/r02e
 run() { tag=$1; m=$2; k=$3; shift 3; env "$@" timeout -k 10 300 python bench.py --m $m --topk $k --steps 10 --warmup 2 --reps 3 --check 2 --no-cpu-baseline > gpurun_out/r02e/plan_$tag.json 2>/dev/null

@@ -340,6 +340,15 @@ def test_error_codes(gpu, codebook):
     with pytest.raises(gpu.DpqError) as e:
         gpu.DeltaPQIndex.open_memory(payload[:-1], 500, 8, 256)
     assert e.value.status == -3
+    # a part of a larger index must say how large the whole is (else the even-N rule would hit the wrong node), and its
+    # global positions must fit the int32 ids of the result
+    for kw in (dict(global_offset=1000), dict(global_offset=2**31 - 400, global_n_codes=2**31 - 2),
+               dict(global_offset=10, global_n_codes=505), dict(global_offset=-1, global_n_codes=1000)):
+        with pytest.raises(gpu.DpqError) as e:
+            gpu.DeltaPQIndex.open_memory(payload, 500, 8, 256, **kw)
+        assert e.value.status == -1, kw
+    with pytest.raises(TypeError):
+        gpu.DeltaPQIndex.open_memory(payload, 500, 8, 256, no_such_knob=1)
 
 
 def test_reference_named_entry_points(gpu, oracle, codebook, tmp_path):
