@@ -85,7 +85,7 @@ struct dpq_tree {
 
 // Plan and tiling knobs of a handle: dpq_open_opts' fields with the defaults filled in (resolve_tuning).
 struct Tuning {
-    int stream_max = 8;          // batches up to this size take stream_kernel
+    int stream_max = 2;          // batches up to this size take stream_kernel
     int coarse_below = 128;
     int plan_ratios[3] = {0, 0, 0};
     int boot_cap = 0, boot_target = 0;
@@ -193,6 +193,10 @@ struct dpq_index {
         return e;
     }
     bool prof_failed = false;        // an event could not be created / recorded: dpq_profile_read reports it
+    // developer hooks (dpq_debug_scan_time mode 3): the last batch's bootstrap and first-level scan launches as they were
+    dpq::BootArgs dbg_ba{};
+    dpq::ScanArgs dbg_sa{};
+    int dbg_boot_slots = 0, dbg_groups = 0, dbg_splits = 0;
 };
 
 namespace {
@@ -467,34 +471,28 @@ int splits_for(int n_seg_pass, int n_groups) {
     return std::max(1, std::min(n_seg_pass, want));
 }
 
-// Candidate-buffer geometry of one scan launch, in 8-byte words: region 0 (top_k keys) carries the winners of the
-// previous level, then one region per scan workgroup of a query group (no global atomics: a workgroup appends to
-// its own region) of region_cap ENTRIES -- filter survivors (code, id) of `words` words each, which the select kernel
-// checks exactly.
+// Candidate-buffer geometry of one scan launch: region 0 (top_k keys) carries the winners of the
+// previous level, then one region per scan workgroup of a query group (no global atomics: a
+// workgroup appends to its own region).
 struct Regions {
     int splits;
-    int region_cap;  // entries
-    int words;       // 8-byte words per entry
-    int64_t stride;  // words per slot
+    int region_cap;
+    int64_t stride;  // keys per slot
 };
 
 Regions regions_for(const dpq_index* x, int n_seg_pass, int n_groups, int top_k, int cap) {
     Regions r;
     r.splits = splits_for(n_seg_pass, n_groups);
-    r.words = dpq::survivor_entry_words(x->M);
     r.region_cap = (cap - top_k) / r.splits;
-    // automatic sizing: a query's survivors cluster in few segments (DFS neighbours are similar codes), so a
-    // region must absorb a few dense segments; 16 K entries per slot, at least one segment's worth per region,
+    // automatic sizing: a query's candidates cluster in few segments (DFS neighbours are similar codes), so a
+    // region must absorb a few dense segments; 16 K keys per slot, at least one segment's worth per region,
     // and four times a level's expected candidates (top_k x 16) spread over the regions
     if (x->cap_auto)
         r.region_cap = std::max(r.region_cap, std::max(std::max(256, 16384 / r.splits), 64 * top_k / r.splits));
     r.region_cap = std::max(r.region_cap, 1);
-    r.stride = (int64_t)top_k + (int64_t)r.splits * r.region_cap * r.words;
+    r.stride = (int64_t)top_k + (int64_t)r.splits * r.region_cap;
     return r;
 }
-
-// keys the select kernel holds in LDS (a longer list goes through its HBM scratch)
-int select_lds_keys(int top_k) { return std::min(dpq::kSelectMaxLdsKeys, std::max(2048, 8 * top_k)); }
 
 // One sub-batch (nq <= kMaxBatchQueries) end to end on `stream`.
 // flag_slot 0: synchronous (waits, checks the overflow word, reruns what overflowed); > 0: enqueue only,
@@ -575,8 +573,6 @@ int run_batch(dpq_index* x, const float* d_queries, int nq, int top_k, int32_t* 
     se.scratch = x->d_scratch;
     se.lut32 = x->d_lut32;
     se.slot_query = nullptr;
-    se.n_lds_keys = select_lds_keys(top_k);
-    se.counters = sa.counters;
     se.top_k = top_k;
     se.thr_key = x->d_thr_key;
     se.overflow = x->d_overflow;
@@ -639,6 +635,8 @@ int run_batch(dpq_index* x, const float* d_queries, int nq, int top_k, int32_t* 
                 DPQ_HIP(dpq::launch_bootstrap(ba, x->M, fuse && !direct ? nqp : nq, stream));
             }
             if (x->prof) x->prof_acc.bootstrap_launches++;
+            x->dbg_ba = ba;
+            x->dbg_boot_slots = fuse && !direct ? nqp : nq;
             continue;
         }
         if (l == 0) {
@@ -646,8 +644,6 @@ int run_batch(dpq_index* x, const float* d_queries, int nq, int top_k, int32_t* 
             se.shared_id = x->d_l0_id;
             se.shared_code = x->d_l0_code;
             se.shared_n = (int)(x->level_cnt[0] * S);
-            se.entries = 0;
-            se.lut32 = x->d_lut32;       // the level-0 list holds code values
         } else {
             se.shared_id = nullptr;
             se.shared_code = nullptr;
@@ -657,11 +653,9 @@ int run_batch(dpq_index* x, const float* d_queries, int nq, int top_k, int32_t* 
             sa.n_seg_pass = x->level_cnt[l];
             const Regions rg = regions_for(x, sa.n_seg_pass, ngroups, top_k, cap);
             if (direct) {
-                // one region of exact keys per slot behind the carried winners, filled through a global counter
+                // one region per slot behind the carried winners, filled through a global counter
                 sa.region_cap = se.region_cap = (int32_t)std::min<int64_t>(stride - top_k, INT32_MAX);
                 se.n_regions = 2;
-                se.entries = 0;
-                se.lut32 = x->d_lut32;
                 DPQ_HIP(hipMemset2DAsync(x->d_cand_count + 1, sizeof(uint32_t) * dpq::kRegionStride, 0, sizeof(uint32_t),
                                          (size_t)nq, stream));
                 {
@@ -676,8 +670,6 @@ int run_batch(dpq_index* x, const float* d_queries, int nq, int top_k, int32_t* 
             } else {
             sa.region_cap = se.region_cap = rg.region_cap;
             se.n_regions = 1 + rg.splits;
-            se.entries = 1;              // the scan's filter survivors, checked exactly by the select kernel
-            se.lut32 = sa.lut32;         // ... against the tables whose rows follow the labels of the codes it read
             if (!(boot_built_tables && l == 1)) {  // the bootstrap kernel wrote the first level's tables itself
                 Timer t(x, stream, 3);
                 DPQ_HIP(dpq::launch_quantise(sa, ngroups, stream));
@@ -711,6 +703,11 @@ int run_batch(dpq_index* x, const float* d_queries, int nq, int top_k, int32_t* 
             } else {
                 Timer t(x, stream, 1);
                 DPQ_HIP(dpq::launch_scan(sa, ngroups, rg.splits, stream));
+                if (l == 1) {
+                    x->dbg_sa = sa;
+                    x->dbg_groups = ngroups;
+                    x->dbg_splits = rg.splits;
+                }
             }
             if (x->prof) {
                 x->prof_acc.scan_launches++;
@@ -757,11 +754,11 @@ int run_batch(dpq_index* x, const float* d_queries, int nq, int top_k, int32_t* 
         slot_query[i] = over[i];
         k2[i] = h_key[(size_t)over[i]];
     }
-    // few, large regions: with a tight threshold the survivors of a query may all sit in one workgroup's share
+    // few, large regions: with a tight threshold the candidates of a query may all sit in one workgroup's share
     const int splits2 = std::min(16, splits_for(x->img.n_segments, ng2));
     int64_t rcap2 = std::max<int64_t>(2 * (int64_t)top_k, 1024);
     for (int attempt = 0;; ++attempt) {
-        const int64_t stride2 = (int64_t)top_k + (int64_t)splits2 * rcap2 * dpq::survivor_entry_words(x->M);
+        const int64_t stride2 = (int64_t)top_k + (int64_t)splits2 * rcap2;
         int32_t* d_slot_query = nullptr;
         uint32_t *c_count = nullptr, *c_over = nullptr;
         uint64_t *c_keys = nullptr, *c_scratch = nullptr, *c_tk = nullptr;
@@ -817,8 +814,6 @@ int run_batch(dpq_index* x, const float* d_queries, int nq, int top_k, int32_t* 
         se.shared_id = nullptr;
         se.shared_code = nullptr;
         se.shared_n = 0;
-        se.entries = 1;
-        se.lut32 = sa.lut32;
         se.cand_count = c_count;
         se.cand_key = c_keys;
         se.cand_stride = stride2;
@@ -1859,6 +1854,26 @@ int dpq_debug_scan_time(dpq_index* x, int nq, int pass_all, int reps, int splits
     return guarded([&]() -> int {
     if (!x || !ms_out || !x->d_lut32) return fail(DPQ_ERR_STATE, "run a query batch first");
     DPQ_HIP(hipSetDevice(x->device));
+    if (pass_all == 3) {
+        // the last batch's first filter level exactly as it ran: its bootstrap again (thresholds + tables), then `reps`
+        // timed launches of its scan
+        if (x->dbg_groups <= 0 || x->dbg_boot_slots <= 0) return fail(DPQ_ERR_STATE, "the last batch ran no bootstrap + scan");
+        hipEvent_t a, b;
+        DPQ_HIP(hipEventCreate(&a));
+        DPQ_HIP(hipEventCreate(&b));
+        DPQ_HIP(dpq::launch_bootstrap(x->dbg_ba, x->M, x->dbg_boot_slots, nullptr));
+        DPQ_HIP(dpq::launch_scan(x->dbg_sa, x->dbg_groups, x->dbg_splits, nullptr));
+        DPQ_HIP(hipEventRecord(a, nullptr));
+        for (int r = 0; r < reps; ++r) DPQ_HIP(dpq::launch_scan(x->dbg_sa, x->dbg_groups, x->dbg_splits, nullptr));
+        DPQ_HIP(hipEventRecord(b, nullptr));
+        DPQ_HIP(hipEventSynchronize(b));
+        float ms = 0;
+        DPQ_HIP(hipEventElapsedTime(&ms, a, b));
+        *ms_out = ms / reps;
+        hipEventDestroy(a);
+        hipEventDestroy(b);
+        return DPQ_OK;
+    }
     const int QG = dpq::queries_per_group(x->M);
     const int nqp = (nq + QG - 1) / QG * QG;
     if (nqp > x->ws_slots) return fail(DPQ_ERR_ARG, "nq exceeds the workspace");
@@ -1884,7 +1899,7 @@ int dpq_debug_scan_time(dpq_index* x, int nq, int pass_all, int reps, int splits
     sa.cand_key = x->d_cand_key;
     sa.cand_stride = x->ws_cap;
     sa.region_off = 0;
-    sa.region_cap = std::max(1, x->ws_cap / splits / dpq::survivor_entry_words(x->M));
+    sa.region_cap = std::max(1, x->ws_cap / splits);
     sa.qtab = x->d_qtab;
     hipEvent_t a, b;
     DPQ_HIP(hipEventCreate(&a));
@@ -1961,7 +1976,7 @@ int dpq_debug_scan_stamps(dpq_index* x, int nq, int splits, unsigned long long* 
     sa.cand_key = x->d_cand_key;
     sa.cand_stride = x->ws_cap;
     sa.region_off = 0;
-    sa.region_cap = std::max(1, x->ws_cap / splits / dpq::survivor_entry_words(x->M));
+    sa.region_cap = std::max(1, x->ws_cap / splits);
     sa.qtab = x->d_qtab;
     sa.stamps = d_st;
     hipEvent_t a, b;

@@ -13,8 +13,7 @@ constexpr int kSelectThreads = 512;
 constexpr int kMaxSplits = 256;                  // scan workgroups per query group
 constexpr int kRegionStride = 1 + kMaxSplits;    // candidate-count words per slot
 constexpr int kLevel0Nodes = 3840;               // level-0 list: its select block (keys + exact tables) stays under 40 KB of LDS
-constexpr int kSortMax = 4096;  // level-0 keys the select kernel holds in LDS; more -> radix select on the HBM list
-constexpr int kSelectMaxLdsKeys = 8192;  // upper bound of SelectArgs::n_lds_keys
+constexpr int kSortMax = 4096;  // candidate keys the select kernel holds in LDS; more -> radix select on the HBM list
 // queries per scan workgroup = what 128 KB of filter tables hold: 8-bit entries for M = 8, 16-bit for M = 16
 inline int queries_per_group(int M) { return M <= 8 ? 64 : 32; }
 
@@ -52,15 +51,13 @@ struct ScanArgs {
     int32_t raw_by_pos;         // img.raw is the per-batch scratch of THIS launch's list: entry s of seg_list at position s
     int32_t append;             // the launch continues a level: region counts start from cand_count instead of 0
     int32_t fp32_accum;         // plain index (-task pqscan): exact distances are fp32 sums in position order (h:2658-2662)
-    // candidate buffer of a slot, in 8-byte words: [region 0: winner KEYS carried from the previous level, region_off of
-    // them][region 1 + s: what workgroup (split) s of this launch found, region_cap entries each].  scan_kernel: an
-    // entry = a filter survivor (code, id), 2 words at M = 8 and 4 at M = 16, checked exactly by the select kernel;
-    // stream_kernel: an entry = an exact key (distance bits << 32 | DFS position), one region.
-    uint32_t* cand_count;       // [slots][kRegionStride] entries per region (region 1 + s written here, may exceed region_cap)
-    uint64_t* cand_key;         // [slots][cand_stride]
+    // candidate buffer of a slot: [region 0: winners carried from the previous level, region_off keys]
+    // [region 1 + s: what workgroup (split) s of this launch found, region_cap keys each]
+    uint32_t* cand_count;       // [slots][kRegionStride] keys per region (region 1 + s written here, may exceed region_cap)
+    uint64_t* cand_key;         // [slots][cand_stride] exact keys (distance bits << 32 | DFS position)
     int64_t cand_stride;
     int32_t region_off, region_cap;
-    unsigned long long* counters;  // statistics (may be NULL): [0] += pairs the filter let through
+    unsigned long long* counters;  // statistics (may be NULL): [0] += pairs checked exactly, [1] += candidates
     // this level's filter tables, [groups][qtab_bytes_per_group / 16] x 16 B: written by launch_quantise
     // (from lut32 / lut_min / thr_key), copied into LDS by every scan workgroup of the group
     uint4* qtab;
@@ -75,14 +72,10 @@ struct SelectArgs {
     uint32_t* cand_count;          // [slots][kRegionStride] in: keys per region; out (non-final): region 0 = carried winners
     uint64_t* cand_key;            // [slots][cand_stride], regions as in ScanArgs
     int64_t cand_stride;
-    int32_t region_off, region_cap;  // region_cap: keys (entries == 0) or survivor entries (entries == 1) per region
+    int32_t region_off, region_cap;
     int32_t n_regions;             // regions to read: 1 + splits of the level's scan launch (0 with shared_id)
-    int32_t entries;               // regions 1.. hold the scan's filter survivors (code, id: 16 B at M = 8, 32 B at M = 16)
-                                   // to be evaluated exactly against lut32 and the slot's threshold key; 0: they hold keys
-    int32_t n_lds_keys;            // keys the block holds in LDS (<= kSelectMaxLdsKeys); a longer list lives in `scratch`
-    unsigned long long* counters;  // statistics (may be NULL): [1] += survivors that passed the exact check
-    uint64_t* scratch;             // [slots][cand_stride] the slot's key list when it exceeds n_lds_keys
-    const float* lut32;            // exact tables [query][m][256] fp32, rows by the labels of the codes evaluated here
+    uint64_t* scratch;             // [slots][cand_stride] contiguous copy when a slot holds more than kSortMax keys
+    const float* lut32;            // exact tables [query][m][256] fp32
     const int32_t* slot_query;     // slot -> query index in the batch (LUT + output row), NULL = identity, -1 = skip
     int32_t top_k;
     int32_t final_pass;            // 1: write ids/dists; 0: carry winners to the next level
@@ -147,7 +140,6 @@ hipError_t launch_merge(const int32_t* d_ids, const float* d_dists, int n_lists,
 hipError_t launch_encode_pq(const float* d_vectors, int64_t n, int D, const float* d_codebook, int M, int K, int Ds,
                             uint8_t* d_codes, hipStream_t stream);
 size_t scan_lds_bytes(int M);
-size_t select_lds_bytes(int M, int top_k, int n_keys, bool tables);
-int survivor_entry_words(int M);  // 8-byte words per filter survivor entry
+size_t select_lds_bytes(int M, int top_k, int n_shared);
 
 }  // namespace dpq

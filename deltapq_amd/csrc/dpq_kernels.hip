@@ -231,8 +231,11 @@ struct Cfg {
     __host__ __device__ static constexpr uint32_t reject_entry(int m) {
         return R == 1 ? (m == 0 ? (uint32_t)FIELD_MAX : 0u) : (uint32_t)SAT;
     }
-    // a filter survivor as the scan hands it to the select kernel: (code, id), padded to whole 16-byte stores
-    static constexpr int EQ = M <= 8 ? 2 : 4;         // 8-byte words per survivor entry: 16 B (M = 8), 32 B (M = 16)
+    // refine queue of a wavefront: one entry per node with filter survivors = (code, id, survivor mask);
+    // 1920 B per wavefront (16 of them share what the 128 KB of tables leave of the 160 KB)
+    static constexpr int QE_BYTES = 4 * W + 4 + 4 * MD;
+    static constexpr int QCAP = 1920 / QE_BYTES;      // 96 entries (M = 8), 80 (M = 16)
+    static_assert(QCAP >= 64 + 16, "a step pushes up to 64 entries");
 };
 
 // a7: the reference's decoder[256] (main:312-325) as byte-permute selectors.
@@ -627,8 +630,12 @@ struct ScanLds {
     static constexpr size_t kThr = kTables;                                           // [QG] u64 threshold keys
     static constexpr size_t kBase = kThr + (size_t)C::QG * 8;                         // [QG] i32 row of the exact tables
     static constexpr size_t kCount = kBase + (size_t)C::QG * 4;                       // [QG] candidates of this workgroup
-    static constexpr size_t kChecks = kCount + (size_t)C::QG * 4;                     // [4]: filter survivors, next list entry
-    static constexpr size_t kBytes = kChecks + 16;
+    static constexpr size_t kChecks = kCount + (size_t)C::QG * 4;                     // [4]: pairs checked exactly, next list entry
+    // per-wave ring of nodes with filter survivors awaiting the exact check
+    static constexpr size_t kQCode = kChecks + 16;                                    // [waves][QCAP][W] dwords
+    static constexpr size_t kQId = kQCode + (size_t)kScanWaves * C::QCAP * M;         // [waves][QCAP] u32
+    static constexpr size_t kQMask = kQId + (size_t)kScanWaves * C::QCAP * 4;         // [waves][QCAP][MD] dwords
+    static constexpr size_t kBytes = kQMask + (size_t)kScanWaves * C::QCAP * 4 * C::MD;
     static_assert(kBytes <= 160 * 1024, "one workgroup per CU: 160 KB of LDS");
 };
 
@@ -642,15 +649,21 @@ enum { kStPrologue = 0, kStSegment, kStDecode, kStGather, kStFold, kStPush, kStR
 template <int M, bool PLAIN, bool STAMPS>
 __global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanArgs a) {
     using C = Cfg<M>;
-    constexpr int W = C::W, QG = C::QG, NG = C::NG, NA = C::NA, EB = C::AB, F = C::F, MD = C::MD, EQ = C::EQ;
+    constexpr int W = C::W, QG = C::QG, NG = C::NG, NA = C::NA, EB = C::AB, F = C::F, MD = C::MD, QCAP = C::QCAP;
     constexpr int TE = M * 256;  // table entries per query
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint4* lut = reinterpret_cast<uint4*>(smem);                                        // [NG][M][256] x 16 B = 128 KB
-    // filter survivors of this workgroup per query; the entries go straight to the workgroup's own region
-    // of the query's buffer (plain stores, no global atomics), the counts in the epilogue
+    uint64_t* s_thr = reinterpret_cast<uint64_t*>(smem + ScanLds<M>::kThr);             // [QG]
+    int32_t* s_base = reinterpret_cast<int32_t*>(smem + ScanLds<M>::kBase);             // [QG], -1 = unused slot
+    // candidates found by this workgroup per query; their keys go straight to the workgroup's own region
+    // of the query's candidate buffer (plain stores, no global atomics), the counts in the epilogue
     uint32_t* wg_count = reinterpret_cast<uint32_t*>(smem + ScanLds<M>::kCount);        // [QG]
     uint32_t* wg_checks = reinterpret_cast<uint32_t*>(smem + ScanLds<M>::kChecks);      // [1]
     uint32_t* wg_next = wg_checks + 1;                                                  // [1] next list entry of this workgroup
+    // refine ring of this wavefront
+    uint32_t* rq_code = reinterpret_cast<uint32_t*>(smem + ScanLds<M>::kQCode) + (size_t)(threadIdx.x >> 6) * QCAP * W;
+    uint32_t* rq_id = reinterpret_cast<uint32_t*>(smem + ScanLds<M>::kQId) + (size_t)(threadIdx.x >> 6) * QCAP;
+    uint32_t* rq_mask = reinterpret_cast<uint32_t*>(smem + ScanLds<M>::kQMask) + (size_t)(threadIdx.x >> 6) * QCAP * MD;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -683,8 +696,18 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanArgs a) {
 
     // ---- prologue: this level's filter tables of the group (quantise_kernel) -> LDS ----
     if (tid < QG) {
+        const int slot = slot0 + tid;
+        int qq = a.slot_query ? a.slot_query[slot] : (slot < a.n_queries ? slot : -1);
+        uint64_t key = ~0ull;
+        if (qq >= 0 && a.debug_pass != 1) {
+            if (a.debug_pass != 2) key = a.thr_key[slot];
+        } else {
+            qq = -1;
+        }
+        s_base[tid] = qq >= 0 ? qq * TE : -1;
+        s_thr[tid] = key;
         // a level scanned in several launches (tiles of its segment list) keeps appending to its regions
-        wg_count[tid] = a.append ? a.cand_count[(size_t)(slot0 + tid) * kRegionStride + 1 + split] : 0u;
+        wg_count[tid] = a.append ? a.cand_count[(size_t)slot * kRegionStride + 1 + split] : 0u;
         if (tid == 0) {
             *wg_checks = 0;
             *wg_next = 0;
@@ -709,12 +732,64 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanArgs a) {
 #pragma unroll
     for (int f = 0; f < F; ++f) live |= ((1u << C::J) - 1u) << (EB * f);
 
-    // A node the filter lets through for some query is handed to the select kernel as it is: (code, id) appended to
-    // this workgroup's region of that query's buffer.  The exact check -- M gathers from the query's fp32 table --
-    // happens THERE, with the table staged in LDS: done here (rounds 1-2) the gathers came out of L2, one cache line
-    // per lane and clock, and cost a third of the launch at bootstrap thresholds.
-    const size_t region0 = (size_t)a.region_off + (size_t)split * a.region_cap * EQ;  // 8-byte words into a slot's buffer
+    // Refine ring: one entry per node that has filter survivors.  refine(n) checks the n oldest entries
+    // (lane = entry; a lane walks the set bits of its entry's survivor mask, two per round so that their
+    // table gathers are in flight together) exactly -- same distance rule and key order as the select
+    // kernel; what passes is a candidate.
+    int rq_head = 0, rq_n = 0;  // wave-uniform
+    uint32_t my_pairs = 0;      // (node, query) pairs this lane checked exactly
+    const size_t region0 = (size_t)a.region_off + (size_t)split * a.region_cap;  // this workgroup's region in a slot's buffer
     auto bit_slot = [](int p) { return (p >> 5) * (C::J * F) + ((p & 31) / EB) * C::J + (p % EB); };  // bit -> local slot
+    // survivor bits a lane checks per round (their table gathers, M each from L2, are in flight together); 3, 4 and 6
+    // per round measured the same step time as 2
+    constexpr int RB = 2;
+    auto refine = [&](int n) {
+        __builtin_amdgcn_wave_barrier();  // ring entries were written by other lanes of this wavefront
+        int i = rq_head + lane;
+        i = i >= QCAP ? i - QCAP : i;
+        uint32_t c[W];
+        uint32_t eid = 0;
+        uint64_t pend = 0;
+        if (lane < n) {
+#pragma unroll
+            for (int w = 0; w < W; ++w) c[w] = rq_code[i * W + w];
+            eid = rq_id[i];
+            pend = rq_mask[i * MD];
+            if constexpr (MD == 2) pend |= (uint64_t)rq_mask[i * MD + 1] << 32;
+        } else {
+#pragma unroll
+            for (int w = 0; w < W; ++w) c[w] = 0;
+        }
+        my_pairs += (uint32_t)__popcll(pend);  // statistics: summed over the wavefront once, after the loop
+        while (__ballot(pend != 0)) {
+            int ls[RB];
+            bool has[RB];
+            float d[RB];
+#pragma unroll
+            for (int e = 0; e < RB; ++e) {
+                has[e] = pend != 0;
+                ls[e] = has[e] ? bit_slot(__ffsll((unsigned long long)pend) - 1) : 0;
+                pend &= pend - 1;  // 0 stays 0
+            }
+#pragma unroll
+            for (int e = 0; e < RB; ++e) d[e] = has[e] ? exact_dist<M>(a.lut32 + s_base[ls[e]], c, PLAIN && a.fp32_accum != 0) : 0.0f;
+#pragma unroll
+            for (int e = 0; e < RB; ++e) {
+                const uint64_t key = make_key(d[e], eid);
+                if (has[e] && key <= s_thr[ls[e]]) {
+                    const uint32_t li = atomicAdd(&wg_count[ls[e]], 1u);
+                    if (li < (uint32_t)a.region_cap)
+                        a.cand_key[(size_t)(slot0 + ls[e]) * a.cand_stride + region0 + li] = key;
+                }
+            }
+        }
+        rq_head += n;
+        rq_head = rq_head >= QCAP ? rq_head - QCAP : rq_head;
+        rq_n -= n;
+        if constexpr (STAMPS) st[kStRefines] += 1;
+        __builtin_amdgcn_wave_barrier();
+    };
+
     // list entry s -> workgroup s % splits (a short list still reaches every workgroup); inside the
     // workgroup the wavefronts draw their next entry from an LDS counter, so a wavefront that met
     // segments with many filter survivors does not hold the others back
@@ -917,42 +992,52 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanArgs a) {
             const uint64_t pushing = __ballot(pend != 0);
             stamp(kStFold);
             if (pushing) {
-                // ---- hand the (node, query) pairs the filter let through to the select kernel ----
-                if (a.counters || STAMPS) {
-                    uint32_t pc = (uint32_t)__popcll(pend);
+                // ---- queue the nodes the filter let through for some query: (code, id, survivor mask) ----
+                const int cnt = (int)__popcll(pushing);
+                while (rq_n + cnt > QCAP) {
+                    refine(min(rq_n, 64));
+                    stamp(kStRefine);
+                }
+                if (pend != 0) {
+                    int pos = rq_head + rq_n + (int)mbcnt64(pushing, 0);
+                    pos = pos >= QCAP ? pos - QCAP : pos;
 #pragma unroll
-                    for (int off = 32; off > 0; off >>= 1) pc += (uint32_t)__shfl_xor((int)pc, off, 64);
-                    if (a.counters && lane == 0) atomicAdd(wg_checks, pc);
-                    if constexpr (STAMPS) st[kStEntries] += pc;
+                    for (int w = 0; w < W; ++w) rq_code[pos * W + w] = code[w];
+                    rq_id[pos] = a.img.id_base + (uint32_t)node;
+                    rq_mask[pos * MD] = (uint32_t)pend;
+                    if constexpr (MD == 2) rq_mask[pos * MD + 1] = (uint32_t)(pend >> 32);
                 }
-                const uint32_t nid = a.img.id_base + (uint32_t)node;
-                while (__ballot(pend != 0)) {  // rounds = the largest number of queries one node of the chunk survives for
-                    if (pend != 0) {
-                        const int ls = bit_slot(__ffsll((unsigned long long)pend) - 1);
-                        pend &= pend - 1;
-                        const uint32_t li = atomicAdd(&wg_count[ls], 1u);
-                        if (li < (uint32_t)a.region_cap) {
-                            uint4* dst = reinterpret_cast<uint4*>(a.cand_key + (size_t)(slot0 + ls) * a.cand_stride + region0 + (size_t)li * EQ);
-                            if constexpr (W == 2) {
-                                dst[0] = make_uint4(code[0], code[1], nid, 0u);
-                            } else {
-                                dst[0] = make_uint4(code[0], code[1], code[2], code[3]);
-                                dst[1] = make_uint4(nid, 0u, 0u, 0u);
-                            }
-                        }
-                    }
-                }
+                rq_n += cnt;
                 stamp(kStPush);
             }
         }
         A = B;
         B = Cn;
     }
+    while (rq_n > 0) refine(min(rq_n, 64));
+    stamp(kStRefine);
+    if (a.counters || STAMPS) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) my_pairs += (uint32_t)__shfl_xor((int)my_pairs, off, 64);
+        if (a.counters && lane == 0) atomicAdd(wg_checks, my_pairs);
+        if constexpr (STAMPS) st[kStEntries] += my_pairs;
+    }
 
     // ---- epilogue: this workgroup's candidate counts (a count above region_cap tells the select
     // kernel that candidates were dropped) ----
     __syncthreads();
-    if (a.counters && tid == 0) atomicAdd(&a.counters[0], (unsigned long long)*wg_checks);  // statistics
+    if (a.counters && tid < 64) {  // statistics: one pair of global atomics per workgroup
+        uint32_t c = 0;
+        for (int q = tid; q < QG; q += 64)
+            c += wg_count[q] - (a.append ? a.cand_count[(size_t)(slot0 + q) * kRegionStride + 1 + split] : 0u);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) c += (uint32_t)__shfl_xor((int)c, off, 64);
+        if (tid == 0) {
+            atomicAdd(&a.counters[0], (unsigned long long)*wg_checks);
+            atomicAdd(&a.counters[1], (unsigned long long)c);
+        }
+    }
+    __syncthreads();  // the statistics above read the counts this launch started from
     if (tid < QG) a.cand_count[(size_t)(slot0 + tid) * kRegionStride + 1 + split] = wg_count[tid];
     if (a.wg_times && tid == 0) a.wg_times[2 * (blockIdx.y * gridDim.x + blockIdx.x) + 1] = __builtin_amdgcn_s_memrealtime();
     if constexpr (STAMPS) {
@@ -1249,19 +1334,18 @@ __global__ __launch_bounds__(THREADS) void select_kernel(const SelectArgs a) {
     // 2048 maximum: at top_k = 100 a block needs 35 KB and four blocks share a CU
     int KP = 1;
     while (KP < a.top_k) KP <<= 1;
-    // LDS: [candidate keys][the query's exact tables (level 0, or levels whose regions hold filter survivors)]
-    //      [winner keys, histogram][counters] -- a top-100 block stays under 40 KB and four of them fit a CU.
-    const int n_lds_keys = a.shared_id ? min(a.shared_n, kSortMax) : a.n_lds_keys;
-    const bool tables = a.shared_id != nullptr || a.entries != 0;
-    // The tables are dead once the list is evaluated, so they share their space with the winner keys.
+    // LDS: [candidate keys][winner keys, histogram | level 0: the query's exact tables][counters].
+    // The tables are dead once the level-0 list is evaluated, so they share their space with what the
+    // selection needs afterwards: a level-0 block stays under 40 KB and four of them fit a CU.
+    const int n_lds_keys = a.shared_id ? min(a.shared_n, kSortMax) : kSortMax;
     uint64_t* skeys = reinterpret_cast<uint64_t*>(smem);                              // [n_lds_keys] candidate keys
     unsigned char* shared_area = smem + (size_t)n_lds_keys * 8;
-    float* T = reinterpret_cast<float*>(shared_area);                                 // [M][256]
+    float* T = reinterpret_cast<float*>(shared_area);                                 // [M][256], level 0 only
     uint64_t* wkeys = reinterpret_cast<uint64_t*>(shared_area);                       // [KP] winner keys
-    const size_t union_bytes = max((size_t)KP * 8, tables ? (size_t)TE * 4 : (size_t)0);
-    uint32_t* hist = reinterpret_cast<uint32_t*>(shared_area + union_bytes);          // [kRegionStride + 1 <= 264]; region prefix first
+    uint32_t* hist = reinterpret_cast<uint32_t*>(wkeys + KP);                         // [kRegionStride + 1 <= 264]
     uint32_t* bcast = hist + 264;                                                     // [2]
-    uint32_t* counters = bcast + 2;                                                   // [3]: winners, padding nodes, keys in the list
+    const size_t select_bytes = (size_t)KP * 8 + 266 * 4, table_bytes = a.shared_id ? (size_t)TE * 4 : 0;
+    uint32_t* counters = reinterpret_cast<uint32_t*>(shared_area + (select_bytes > table_bytes ? select_bytes : table_bytes));  // [2]: winners, padding nodes
 
     const int slot = blockIdx.x;
     const int tid = threadIdx.x;
@@ -1280,7 +1364,6 @@ __global__ __launch_bounds__(THREADS) void select_kernel(const SelectArgs a) {
     if (tid == 0) {
         counters[0] = 0;
         counters[1] = 0;
-        counters[2] = 0;
     }
     if (shared) {
         // level 0: the query-independent list of decoded nodes, evaluated exactly here.  The query's
@@ -1344,72 +1427,29 @@ __global__ __launch_bounds__(THREADS) void select_kernel(const SelectArgs a) {
             }
         }
         __syncthreads();
-        const int n_in = (int)rstart[R];
-        // Region 0 holds KEYS (winners carried from the previous level); the other regions hold keys too (stream
-        // kernel: it checks exactly itself) or the scan's FILTER SURVIVORS (code, id): those are evaluated here --
-        // the reference's distance, fp64 sum of the M fp32 entries rounded once, gathered from the query's table in
-        // LDS -- and kept iff their (distance, id) key is <= the level's threshold key.
-        const uint64_t thr = a.thr_key[slot];
-        if (a.entries) {
-            const float4* src = reinterpret_cast<const float4*>(a.lut32 + (size_t)q * TE);
-            for (int i = tid; i < TE / 4; i += THREADS) reinterpret_cast<float4*>(T)[i] = src[i];
-            __syncthreads();
-        }
-        // flat gather: input i of the slot sits in the region r with rstart[r] <= i < rstart[r + 1]; every thread
-        // has all its loads in flight at once (a region-by-region copy is a chain of global round trips).  Keys beyond
-        // the LDS list go to the slot's HBM scratch at the same position.
-        uint64_t* spill = a.scratch + (size_t)slot * a.cand_stride;
-        constexpr int EQ = Cfg<M>::EQ;
-        for (int i0 = 0; i0 < n_in; i0 += 4 * THREADS) {
-            uint4 e[4][EQ / 2];
-            bool is_key[4];
+        n = (int)rstart[R];
+        // keys live in LDS for the usual list sizes, in HBM scratch for huge ones (overflow reruns)
+        if (n > kSortMax) keys = a.scratch + (size_t)slot * a.cand_stride;
+        // flat gather: key i of the list sits in the region r with rstart[r] <= i < rstart[r + 1]; every thread
+        // has all its loads in flight at once (a region-by-region copy is a chain of global round trips)
+        for (int i0 = 0; i0 < n; i0 += 4 * THREADS) {
+            uint64_t v[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const int i = min(i0 + tid + u * THREADS, n_in - 1);
+                const int i = min(i0 + tid + u * THREADS, n - 1);
                 int lo = 0, hi = R;  // rstart[lo] <= i < rstart[hi]
                 while (hi - lo > 1) {
                     const int mid = (lo + hi) >> 1;
                     if (rstart[mid] <= (uint32_t)i) lo = mid; else hi = mid;
                 }
-                const uint32_t off = (uint32_t)i - rstart[lo];
-                is_key[u] = lo == 0 || !a.entries;
-                if (is_key[u]) {
-                    const uint64_t* src = cand + (lo == 0 ? (size_t)0 : (size_t)a.region_off + (size_t)(lo - 1) * a.region_cap);
-                    const uint64_t kv = src[off];
-                    e[u][0] = make_uint4((uint32_t)kv, (uint32_t)(kv >> 32), 0u, 0u);
-                } else {
-                    const uint4* src = reinterpret_cast<const uint4*>(cand + (size_t)a.region_off + ((size_t)(lo - 1) * a.region_cap + off) * EQ);
-#pragma unroll
-                    for (int w = 0; w < EQ / 2; ++w) e[u][w] = src[w];
-                }
+                const uint64_t* src = cand + (lo == 0 ? (size_t)0 : (size_t)a.region_off + (size_t)(lo - 1) * a.region_cap);
+                v[u] = src[(uint32_t)i - rstart[lo]];
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int i = i0 + tid + u * THREADS;
-                if (i >= n_in) break;
-                uint64_t key;
-                if (is_key[u]) {
-                    key = ((uint64_t)e[u][0].y << 32) | e[u][0].x;
-                } else {
-                    uint32_t c[W], id;
-                    if constexpr (W == 2) {
-                        c[0] = e[u][0].x, c[1] = e[u][0].y, id = e[u][0].z;
-                    } else {
-                        c[0] = e[u][0].x, c[1] = e[u][0].y, c[2] = e[u][0].z, c[3] = e[u][0].w, id = e[u][1].x;
-                    }
-                    key = make_key(exact_dist<M>(T, c, a.fp32_accum != 0), id);
-                    if (key > thr) continue;
-                }
-                const uint32_t pos = atomicAdd(&counters[2], 1u);
-                if (pos < (uint32_t)n_lds_keys) skeys[pos] = key; else spill[pos] = key;
+                if (i < n) keys[i] = v[u];
             }
-        }
-        __syncthreads();
-        n = (int)counters[2];
-        if (a.counters && a.entries && tid == 0) atomicAdd(&a.counters[1], (unsigned long long)(n - (int)min(region_n[0], (uint32_t)a.region_off)));
-        if (n > n_lds_keys) {  // huge lists (overflow reruns, loose thresholds): the whole list in the HBM scratch
-            for (int i = tid; i < n_lds_keys; i += THREADS) spill[i] = skeys[i];
-            keys = spill;
         }
     }
     __syncthreads();
@@ -1885,14 +1925,14 @@ hipError_t launch_encode_pq(const float* d_vectors, int64_t n, int D, const floa
 }
 
 size_t scan_lds_bytes(int M) { return M <= 8 ? ScanLds<8>::kBytes : ScanLds<16>::kBytes; }
-int survivor_entry_words(int M) { return M <= 8 ? Cfg<8>::EQ : Cfg<16>::EQ; }
 
-// n_keys: candidate keys the block holds in LDS; tables: it stages the query's exact tables (M KB; level 0 and levels
-// whose regions hold filter survivors)
-size_t select_lds_bytes(int M, int top_k, int n_keys, bool tables) {
+// level 0 (n_shared > 0): the block holds n_shared keys and stages the query's exact tables (M KB)
+size_t select_lds_bytes(int M, int top_k, int n_shared) {
     size_t kp = 1;
     while (kp < (size_t)top_k) kp <<= 1;
-    return (size_t)n_keys * 8 + std::max(kp * 8, tables ? (size_t)M * 256 * 4 : (size_t)0) + (264 + 2 + 3) * 4 + 4;
+    const size_t n_keys = n_shared > 0 ? (size_t)std::min(n_shared, kSortMax) : (size_t)kSortMax;
+    const size_t select_bytes = kp * 8 + 266 * 4, table_bytes = n_shared > 0 ? (size_t)M * 256 * 4 : 0;
+    return n_keys * 8 + std::max(select_bytes, table_bytes) + 16;
 }
 
 hipError_t launch_lut_build(const float* d_codebook, const float* d_queries, int nq, int n_slots, int M, int K, int Ds,
@@ -1995,13 +2035,10 @@ template <int M, int THREADS>
 static hipError_t launch_select_m(const SelectArgs& a, int n_slots, hipStream_t stream) {
     static std::atomic<bool> done[64] = {};
     hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&select_kernel<M, THREADS>),
-                                      select_lds_bytes(M, kMaxTopK, kSelectMaxLdsKeys, true), done);
+                                      select_lds_bytes(M, kMaxTopK, kSortMax), done);
     if (e != hipSuccess) return e;
-    const bool level0 = a.shared_id != nullptr;
-    if (!level0 && (a.n_lds_keys < 1 || a.n_lds_keys > kSelectMaxLdsKeys)) return hipErrorInvalidValue;
     hipLaunchKernelGGL((select_kernel<M, THREADS>), dim3((unsigned)n_slots), dim3(THREADS),
-                       select_lds_bytes(M, a.top_k, level0 ? std::min(a.shared_n, kSortMax) : a.n_lds_keys, level0 || a.entries != 0),
-                       stream, a);
+                       select_lds_bytes(M, a.top_k, a.shared_id ? a.shared_n : 0), stream, a);
     return hipGetLastError();
 }
 
