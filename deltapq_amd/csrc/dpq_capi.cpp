@@ -85,12 +85,12 @@ struct dpq_tree {
 
 // Plan and tiling knobs of a handle: dpq_open_opts' fields with the defaults filled in (resolve_tuning).
 struct Tuning {
-    int stream_max = 2;          // batches up to this size take stream_kernel
+    int stream_max = 8;          // batches up to this size take stream_kernel (1, 2, 4 or 8 queries per pass)
     int coarse_below = 128;
     int plan_ratios[3] = {0, 0, 0};
     int boot_cap = 0, boot_target = 0;
     int64_t batch_tile_nodes = (int64_t)16 << 20;
-    bool relabel = true, fuse_quantise = true, async_overlap = true, boot_fullsort = false;
+    bool relabel = true, fuse_quantise = true, async_overlap = true, boot_fullsort = false, tighten = true;
 };
 
 struct dpq_index {
@@ -215,6 +215,7 @@ Tuning resolve_tuning(const dpq_open_opts& o) {
     t.fuse_quantise = !(o.flags & DPQ_OPT_NO_FUSE_QUANTISE);
     t.async_overlap = !(o.flags & DPQ_OPT_NO_ASYNC_OVERLAP);
     t.boot_fullsort = (o.flags & DPQ_OPT_BOOT_FULLSORT) != 0;
+    t.tighten = !(o.flags & DPQ_OPT_NO_TIGHTEN);
     const char* dev = getenv("DPQ_DEV");
     if (dev && atoi(dev) != 0) {
         auto geti = [](const char* name, int* v) { if (const char* e = getenv(name)) *v = atoi(e); };
@@ -229,6 +230,7 @@ Tuning resolve_tuning(const dpq_open_opts& o) {
         v = 1; geti("DPQ_FUSE_QUANTISE", &v); t.fuse_quantise = t.fuse_quantise && v != 0;
         v = 1; geti("DPQ_ASYNC_OVERLAP", &v); t.async_overlap = t.async_overlap && v != 0;
         v = 0; geti("DPQ_BOOT_FULLSORT", &v); t.boot_fullsort = t.boot_fullsort || v != 0;
+        v = 1; geti("DPQ_TIGHTEN", &v); t.tighten = t.tighten && v != 0;
     }
     return t;
 }
@@ -291,7 +293,8 @@ int ensure_workspace(dpq_index* x, int slots, int cap) {
     if ((rc = dev_alloc(&x->d_cand_count, (size_t)slots * dpq::kRegionStride))) return rc;
     if ((rc = dev_alloc(&x->d_cand_key, (size_t)slots * cap))) return rc;
     if ((rc = dev_alloc(&x->d_scratch, (size_t)slots * cap))) return rc;
-    if ((rc = dev_alloc(&x->d_overflow, (size_t)slots))) return rc;
+    // [slots] overflow flags, then [slots][kTightWords] tightening counters of the level being scanned
+    if ((rc = dev_alloc(&x->d_overflow, (size_t)slots * (1 + dpq::kTightWords)))) return rc;
     if ((rc = dev_alloc(&x->d_thr_key, (size_t)slots))) return rc;
     if (!x->h_overflow) DPQ_HIP(hipHostMalloc(reinterpret_cast<void**>(&x->h_overflow), sizeof(uint32_t) * 4096));
     if (!x->d_counters) {
@@ -548,7 +551,8 @@ int run_batch(dpq_index* x, const float* d_queries, int nq, int top_k, int32_t* 
         // also clears the overflow flags of the nqp slots
         // batches that scan the plain-code scratch also get the tables in the scratch's label order
         DPQ_HIP(dpq::launch_lut_build(x->d_codebook, d_queries, nq, nqp, x->M, x->K, x->Ds, x->d_lut32, x->d_lut_min,
-                                      nullptr, x->d_overflow, scratch ? x->d_relabel : nullptr, x->d_lut32r, stream));
+                                      nullptr, x->d_overflow, scratch ? x->d_relabel : nullptr, x->d_lut32r,
+                                      x->tune.tighten ? x->d_overflow + x->ws_slots : nullptr, stream));
     }
     if (x->prof) x->prof_acc.lut_launches++;
     x->h_any[flag_slot] = 0;  // the slot is free: its previous batch has been finished
@@ -564,6 +568,13 @@ int run_batch(dpq_index* x, const float* d_queries, int nq, int top_k, int32_t* 
     sa.region_off = top_k;
     sa.counters = x->prof && !x->prof_scan_only ? x->d_counters : nullptr;
     sa.qtab = x->d_qtab;
+    // in-scan threshold tightening (plain-code scans of this batch; scan_kernel): histograms behind the overflow flags
+    // Measured (1 M codes x 1000 queries): top-100 +2 % queries/s (exact checks 3002 -> 1813 and candidates 802 -> 404 per
+    // query, select 21 -> 16 us); top-1000 -2 % at M = 8 and -7 % at M = 16: there the plan's two short levels in front
+    // already do the tightening, and the helper wavefront and the counting only cost.  So: plans of one level after a
+    // bootstrap, i.e. top_k <= 256 (ensure_plan).
+    sa.tight_hist = x->tune.tighten && top_k <= 256 ? x->d_overflow + x->ws_slots : nullptr;
+    sa.tight_k = top_k;
 
     dpq::SelectArgs se{};
     se.cand_count = x->d_cand_count;
@@ -787,6 +798,7 @@ int run_batch(dpq_index* x, const float* d_queries, int nq, int top_k, int32_t* 
         chk(hipMemsetAsync(c_over, 0, sizeof(uint32_t) * slots2, stream));
         sa.seg_list = nullptr;
         sa.n_seg_pass = x->img.n_segments;
+        sa.tight_hist = nullptr;  // the rerun starts from final thresholds
         if (!one_tile) {  // a tiled scratch holds the last tile only: the rerun decodes inside the scan, code values as labels
             sa.img.raw = x->img.raw;
             sa.lut32 = x->d_lut32;
@@ -1864,7 +1876,13 @@ int dpq_debug_scan_time(dpq_index* x, int nq, int pass_all, int reps, int splits
         DPQ_HIP(dpq::launch_bootstrap(x->dbg_ba, x->M, x->dbg_boot_slots, nullptr));
         DPQ_HIP(dpq::launch_scan(x->dbg_sa, x->dbg_groups, x->dbg_splits, nullptr));
         DPQ_HIP(hipEventRecord(a, nullptr));
-        for (int r = 0; r < reps; ++r) DPQ_HIP(dpq::launch_scan(x->dbg_sa, x->dbg_groups, x->dbg_splits, nullptr));
+        for (int r = 0; r < reps; ++r) {
+            // every launch starts its in-scan tightening from empty histograms, as a batch's first level does (the fill
+            // is a 1-2 us kernel inside the timed region)
+            if (x->dbg_sa.tight_hist)
+                DPQ_HIP(hipMemsetAsync(x->dbg_sa.tight_hist, 0, sizeof(uint32_t) * dpq::kTightWords * (size_t)x->dbg_boot_slots, nullptr));
+            DPQ_HIP(dpq::launch_scan(x->dbg_sa, x->dbg_groups, x->dbg_splits, nullptr));
+        }
         DPQ_HIP(hipEventRecord(b, nullptr));
         DPQ_HIP(hipEventSynchronize(b));
         float ms = 0;

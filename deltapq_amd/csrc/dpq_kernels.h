@@ -16,6 +16,11 @@ constexpr int kLevel0Nodes = 3840;               // level-0 list: its select blo
 constexpr int kSortMax = 4096;  // candidate keys the select kernel holds in LDS; more -> radix select on the HBM list
 // queries per scan workgroup = what 128 KB of filter tables hold: 8-bit entries for M = 8, 16-bit for M = 16
 inline int queries_per_group(int M) { return M <= 8 ? 64 : 32; }
+// In-scan threshold tightening: per slot and filter level a histogram of the candidates found so far, by how many
+// steps the level's cut could be lowered without losing them (scan_kernel).
+constexpr int kTightBuckets = 8;
+constexpr int kTightSplits = 32;                 // scan workgroups of a query group that can share their counts
+constexpr int kTightWords = kTightSplits * kTightBuckets / 4;  // u32 words per slot: [split][bucket] saturating bytes
 
 // The SoA image of one shard in HBM (see DESIGN.md "Data layout").
 struct DeviceImage {
@@ -62,6 +67,11 @@ struct ScanArgs {
     // (from lut32 / lut_min / thr_key), copied into LDS by every scan workgroup of the group
     uint4* qtab;
     unsigned long long* stamps;    // developer diagnostics (NULL in every query call): per-section cycle sums
+    // In-scan threshold tightening (NULL = off): [groups][kTightSplits][slots of a group][kTightBuckets] saturating byte
+    // counters (one row per scan workgroup of the group, written by that workgroup alone), zero when the level starts
+    // (lut_build_kernel / quantise_kernel clear them); tight_k = top_k.
+    uint32_t* tight_hist;
+    int32_t tight_k;
 };
 
 struct SelectArgs {
@@ -118,7 +128,7 @@ struct BootArgs {
 // slots [0, n_slots) (either may be NULL).
 hipError_t launch_lut_build(const float* d_codebook, const float* d_queries, int nq, int n_slots, int M, int K, int Ds,
                             float* d_lut32, float* d_lut_min, uint32_t* d_cand_count, uint32_t* d_overflow,
-                            const uint8_t* d_relabel, float* d_lut_labels,
+                            const uint8_t* d_relabel, float* d_lut_labels, uint32_t* d_tight_hist,
                             hipStream_t stream);
 hipError_t launch_decode_list(const DeviceImage& img, const uint32_t* seg_list, int n_seg, const uint8_t* relabel,
                               uint32_t* out_code, hipStream_t stream);
@@ -127,6 +137,7 @@ hipError_t launch_decode_segments(const DeviceImage& img, const uint32_t* seg_li
 // launch_quantise builds the level's filter tables of every query group (needs the level's thresholds in
 // thr_key); launch_scan must follow it on the same stream.
 hipError_t launch_stream(const ScanArgs& a, int n_slots, hipStream_t stream);
+int stream_queries_per_pass(int M, int n_slots);  // 1, 2, 4 or 8 (M = 16: at most 4)
 hipError_t launch_quantise(const ScanArgs& a, int n_slot_groups, hipStream_t stream);
 hipError_t launch_scan(const ScanArgs& a, int n_slot_groups, int splits, hipStream_t stream);
 size_t qtab_bytes_per_group(int M);

@@ -54,6 +54,7 @@
 #include "dpq_kernels.h"
 
 #include <atomic>
+#include <type_traits>
 #include <cfloat>
 #include <cmath>
 
@@ -108,12 +109,16 @@ __global__ __launch_bounds__(256) void lut_build_kernel(const float* __restrict_
                                                          int K, int Ds, float* __restrict__ lut,
                                                          float* __restrict__ lut_min, uint32_t* __restrict__ cand_count,
                                                          uint32_t* __restrict__ overflow, const uint8_t* __restrict__ relabel,
-                                                         float* __restrict__ lut_labels) {
+                                                         float* __restrict__ lut_labels, uint32_t* __restrict__ tight_hist) {
     const int q0 = blockIdx.x * kLutQueries, m = blockIdx.y, k = threadIdx.x;
     if (m == 0 && k < kLutQueries && q0 + k < n_slots) {
         if (cand_count) cand_count[q0 + k] = 0;
         if (overflow) overflow[q0 + k] = 0;
     }
+    // the first filter level's tightening histograms of these slots (scan_kernel)
+    if (m == 0 && tight_hist)
+        for (int i = k; i < kLutQueries * kTightWords; i += 256)
+            if (q0 * kTightWords + i < n_slots * kTightWords) tight_hist[(size_t)q0 * kTightWords + i] = 0;
     if (q0 >= nq) return;  // padding slots only
     float acc[kLutQueries];
 #pragma unroll
@@ -210,13 +215,26 @@ struct Cfg {
 #define DPQ_SAT16 63
 #define DPQ_PRE16 4
 #endif
-    static constexpr int QT = M <= 8 ? 80 : DPQ_QT16;   // filter units that span (tau - sum of minima)
-    static constexpr int SAT = M <= 8 ? 26 : DPQ_SAT16; // entry saturation
+    // M = 8 with the in-scan tightening's headroom (8 SAT + BIAS + XMAX XU <= 255), scripts/sim_filter_nibbles.py, survivors
+    // per query at a threshold of rank 800 / 400 / 200: 80/26 (no headroom) 2241 / 1139 / 550, 64/24 (none) 2156 / 1066 /
+    // 501, 64/22 2414 / 1211 / 574, 72/23 2515 / 1284 / 620, 80/23 3113 / 1639 / 818
+#ifndef DPQ_QT8
+#define DPQ_QT8 64
+#define DPQ_SAT8 22
+#endif
+    static constexpr int QT = M <= 8 ? DPQ_QT8 : DPQ_QT16;   // filter units that span (tau - sum of minima)
+    static constexpr int SAT = M <= 8 ? DPQ_SAT8 : DPQ_SAT16; // entry saturation
+    // In-scan tightening: a slot's cut can be lowered by e * XU filter units, e = 1 .. XMAX, while a scan launch runs
+    // (the additive term of its accumulator field grows by as much): the field sums need that much headroom.
+    static constexpr int XMAX = kTightBuckets - 1;
+    static constexpr int XU = M <= 8 ? 2 : 8;  // about a quarter of QT at XMAX steps: the k-th distance of a bootstrap
+                                               // threshold of rank 8 k lies 17 % of (tau - minima) above the final one
     // field sum >= 2^(AB-1) (its top bit) <=> sum of entries > QT + 1.  R = 1: added to every m = 0 entry;
     // R = 2: the accumulator fields start from it.
     static constexpr int BIAS = (1 << (AB - 1)) - 1 - (QT + 1);
     static constexpr int FIELD_MAX = (1 << EB) - 1;
-    static_assert(BIAS >= 0 && M * SAT + BIAS < (1 << AB), "a field sum must not carry into its neighbour");
+    static_assert(BIAS >= 0 && M * SAT + BIAS + XMAX * XU < (1 << AB), "a field sum must not carry into its neighbour");
+    static_assert(XMAX * XU < QT, "cuts stay above zero");
     static constexpr int PRE = R == 1 ? M : DPQ_PRE16;  // entries summed as bytes before they are widened
     static_assert(R == 1 || (PRE * SAT <= FIELD_MAX && M * SAT > QT + 1 && M % PRE == 0), "byte sums of PRE entries; all-SAT rejects");
     static constexpr uint32_t LOW = AB == 8 ? 0x01010101u : 0x00010001u;  // bit 0 of every accumulator field
@@ -232,9 +250,9 @@ struct Cfg {
         return R == 1 ? (m == 0 ? (uint32_t)FIELD_MAX : 0u) : (uint32_t)SAT;
     }
     // refine queue of a wavefront: one entry per node with filter survivors = (code, id, survivor mask);
-    // 1920 B per wavefront (16 of them share what the 128 KB of tables leave of the 160 KB)
+    // (16 wavefronts share what the 128 KB of tables and the tightening's 1-2 KB histogram leave of the 160 KB)
     static constexpr int QE_BYTES = 4 * W + 4 + 4 * MD;
-    static constexpr int QCAP = 1920 / QE_BYTES;      // 96 entries (M = 8), 80 (M = 16)
+    static constexpr int QCAP = M <= 8 ? 88 : 80;
     static_assert(QCAP >= 64 + 16, "a step pushes up to 64 entries");
 };
 
@@ -506,17 +524,19 @@ __device__ __forceinline__ float exact_dist(const float* __restrict__ T, const u
 struct FilterScale {
     float s32;      // 0: all fields 0, everything passes the filter
     uint32_t bias;  // added to the m = 0 fields
+    double B;       // sum of the per-sub-space minima
 };
 
 template <int M>
 __device__ __forceinline__ FilterScale filter_scale(uint64_t key, const float* __restrict__ lut_min, size_t q) {
     using C = Cfg<M>;
-    FilterScale r{0.0f, 0u};
+    FilterScale r{0.0f, 0u, 0.0};
     double B = 0.0;
 #pragma unroll
     for (int mm = 0; mm < M; ++mm) B += (double)lut_min_of(lut_min, q, M, mm);
     const double taup = (double)__uint_as_float((uint32_t)(key >> 32)) * (1.0 + 0x1p-20);
     const double R = taup - B;
+    r.B = B;
     if (key != ~0ull && R > 0.0 && R < 1e300) {  // else: no threshold yet (or degenerate), keep everything
         r.s32 = (float)((double)C::QT / R * (1.0 - 0x1p-20));
         r.bias = C::R == 1 ? (uint32_t)C::BIAS : 0u;  // R = 2: the accumulators carry it
@@ -578,11 +598,13 @@ __global__ __launch_bounds__(256) void quantise_kernel(const ScanArgs a) {
     __shared__ int32_t s_row[NS];
     __shared__ uint32_t s_bias[NS];
     const int g = blockIdx.x / M, m = blockIdx.x % M, group = blockIdx.y, k = threadIdx.x;
+    if (blockIdx.x == 0 && a.tight_hist)  // this level's tightening histograms of the group's slots (scan_kernel)
+        for (int i = k; i < QG * kTightWords; i += 256) a.tight_hist[(size_t)group * QG * kTightWords + i] = 0;
     if (k < NS) {
         const int ls = C::slot_of_table(g, k >> 2, k & 3);
         const int slot = group * QG + ls;
         int qq = a.slot_query ? a.slot_query[slot] : (slot < a.n_queries ? slot : -1);
-        FilterScale fs{0.0f, 0u};
+        FilterScale fs{0.0f, 0u, 0.0};
         float mn_m = 0.0f;
         if (qq >= 0 && a.debug_pass != 1) {
             uint64_t key = ~0ull;
@@ -622,6 +644,18 @@ __global__ __launch_bounds__(256) void quantise_kernel(const ScanArgs a) {
     a.qtab[((size_t)group * NG * M + blockIdx.x) * 256 + k] = make_uint4(out[0], out[1], out[2], out[3]);
 }
 
+// Read window of the scan's ADC gathers at M = 8 (ds_read_b128 in flight before the first pair is summed; 0 = leave
+// the order to the compiler).  See scan_kernel.
+#ifndef DPQ_TIGHT_DBG
+#define DPQ_TIGHT_DBG 0
+#endif
+#ifndef DPQ_TIGHT_SLEEP
+#define DPQ_TIGHT_SLEEP 32  // s_sleep units of 64 cycles between two looks of the helper wavefront
+#endif
+#ifndef DPQ_GATHER_PIPE
+#define DPQ_GATHER_PIPE 0
+#endif
+
 // LDS map of the scan workgroup
 template <int M>
 struct ScanLds {
@@ -632,7 +666,14 @@ struct ScanLds {
     static constexpr size_t kCount = kBase + (size_t)C::QG * 4;                       // [QG] candidates of this workgroup
     static constexpr size_t kChecks = kCount + (size_t)C::QG * 4;                     // [4]: pairs checked exactly, next list entry
     // per-wave ring of nodes with filter survivors awaiting the exact check
-    static constexpr size_t kQCode = kChecks + 16;                                    // [waves][QCAP][W] dwords
+    // in-scan tightening: a slot's filter scale and (rounded-down) sum of minima, the additive terms of the NA
+    // accumulator dwords (a field grows by the units its slot's cut was lowered by), their version
+    static constexpr size_t kScale = kChecks + 16;                                    // [QG] f32
+    static constexpr size_t kBdn = kScale + (size_t)C::QG * 4;                        // [QG] f32
+    static constexpr size_t kExtra = kBdn + (size_t)C::QG * 4;                        // [NA] u32
+    // candidates of this workgroup not yet added to the global histograms: 16-bit counters, two per word
+    static constexpr size_t kHist = kExtra + (size_t)C::NA * 4;                       // [QG][kTightBuckets / 2] u32
+    static constexpr size_t kQCode = kHist + (size_t)C::QG * kTightBuckets * 2;       // [waves][QCAP][W] dwords
     static constexpr size_t kQId = kQCode + (size_t)kScanWaves * C::QCAP * M;         // [waves][QCAP] u32
     static constexpr size_t kQMask = kQId + (size_t)kScanWaves * C::QCAP * 4;         // [waves][QCAP][MD] dwords
     static constexpr size_t kBytes = kQMask + (size_t)kScanWaves * C::QCAP * 4 * C::MD;
@@ -646,8 +687,11 @@ struct ScanLds {
 enum { kStPrologue = 0, kStSegment, kStDecode, kStGather, kStFold, kStPush, kStRefine, kStTotal, kStSteps, kStRefines,
        kStWaves, kStEntries, kStCount };
 
-template <int M, bool PLAIN, bool STAMPS>
-__global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanArgs a) {
+// Register budget: the plain-code instantiations at M = 8 stay within 96 VGPRs (second launch bound: five wavefronts per
+// SIMD), although a workgroup only ever brings four: the fifth slot's registers are what the NEXT pipelined batch's
+// table build and decode run in, under this scan (at 121 VGPRs the pipelined step was 18 us longer).
+template <int M, bool PLAIN, bool STAMPS, bool TIGHT>
+__global__ __launch_bounds__(kScanThreads, (PLAIN && !STAMPS && M <= 8) ? 5 : 4) void scan_kernel(const ScanArgs a) {
     using C = Cfg<M>;
     constexpr int W = C::W, QG = C::QG, NG = C::NG, NA = C::NA, EB = C::AB, F = C::F, MD = C::MD, QCAP = C::QCAP;
     constexpr int TE = M * 256;  // table entries per query
@@ -660,6 +704,10 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanArgs a) {
     uint32_t* wg_count = reinterpret_cast<uint32_t*>(smem + ScanLds<M>::kCount);        // [QG]
     uint32_t* wg_checks = reinterpret_cast<uint32_t*>(smem + ScanLds<M>::kChecks);      // [1]
     uint32_t* wg_next = wg_checks + 1;                                                  // [1] next list entry of this workgroup
+    float* s_scale = reinterpret_cast<float*>(smem + ScanLds<M>::kScale);               // [QG] 0 = no tightening for the slot
+    float* s_bdn = reinterpret_cast<float*>(smem + ScanLds<M>::kBdn);                   // [QG]
+    uint32_t* s_extra = reinterpret_cast<uint32_t*>(smem + ScanLds<M>::kExtra);         // [NA]
+    uint32_t* s_hist = reinterpret_cast<uint32_t*>(smem + ScanLds<M>::kHist);           // [QG][kTightBuckets / 2]
     // refine ring of this wavefront
     uint32_t* rq_code = reinterpret_cast<uint32_t*>(smem + ScanLds<M>::kQCode) + (size_t)(threadIdx.x >> 6) * QCAP * W;
     uint32_t* rq_id = reinterpret_cast<uint32_t*>(smem + ScanLds<M>::kQId) + (size_t)(threadIdx.x >> 6) * QCAP;
@@ -706,21 +754,37 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanArgs a) {
         }
         s_base[tid] = qq >= 0 ? qq * TE : -1;
         s_thr[tid] = key;
+        // in-scan tightening works in the units of the slot's filter tables: the same scale the tables were built with
+        float sc = 0.0f, bdn = 0.0f;
+        if (TIGHT && qq >= 0 && key != ~0ull) {
+            const FilterScale fs = filter_scale<M>(key, a.lut_min, (size_t)qq);
+            sc = fs.s32;
+            bdn = __double2float_rd(fs.B);
+        }
+        s_scale[tid] = sc;
+        s_bdn[tid] = bdn;
+        if (tid < NA) s_extra[tid] = C::R == 1 ? 0u : (uint32_t)C::BIAS * C::LOW;
+#pragma unroll
+        for (int w = 0; w < kTightBuckets / 2; ++w) s_hist[tid * (kTightBuckets / 2) + w] = 0;
         // a level scanned in several launches (tiles of its segment list) keeps appending to its regions
         wg_count[tid] = a.append ? a.cand_count[(size_t)slot * kRegionStride + 1 + split] : 0u;
         if (tid == 0) {
             *wg_checks = 0;
             *wg_next = 0;
+            wg_checks[2] = 0;
         }
     }
     {
         const uint4* src = a.qtab + (size_t)group * (NG * TE);
         constexpr int PER = NG * TE / kScanThreads;  // 8
-        uint4 v[PER];
-#pragma unroll
-        for (int i = 0; i < PER; ++i) v[i] = src[tid + i * kScanThreads];
-#pragma unroll
-        for (int i = 0; i < PER; ++i) lut[tid + i * kScanThreads] = v[i];
+        static_assert(PER == 8, "eight 16-byte entries per thread");
+        // (named values, not an array: next to the other local arrays of this kernel an array here was left in scratch)
+        const uint4 v0 = src[tid], v1 = src[tid + kScanThreads], v2 = src[tid + 2 * kScanThreads], v3 = src[tid + 3 * kScanThreads];
+        const uint4 v4 = src[tid + 4 * kScanThreads], v5 = src[tid + 5 * kScanThreads], v6 = src[tid + 6 * kScanThreads],
+                    v7 = src[tid + 7 * kScanThreads];
+        lut[tid] = v0, lut[tid + kScanThreads] = v1, lut[tid + 2 * kScanThreads] = v2, lut[tid + 3 * kScanThreads] = v3;
+        lut[tid + 4 * kScanThreads] = v4, lut[tid + 5 * kScanThreads] = v5, lut[tid + 6 * kScanThreads] = v6,
+                                 lut[tid + 7 * kScanThreads] = v7;
     }
     __syncthreads();
     stamp(kStPrologue);
@@ -771,6 +835,12 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanArgs a) {
                 ls[e] = has[e] ? bit_slot(__ffsll((unsigned long long)pend) - 1) : 0;
                 pend &= pend - 1;  // 0 stays 0
             }
+            float t_sc[RB], t_bd[RB];  // TIGHT: the slot's filter scale and minima, read while the gathers are in flight
+#pragma unroll
+            for (int e = 0; e < RB; ++e) {
+                t_sc[e] = TIGHT && has[e] ? s_scale[ls[e]] : 0.0f;
+                t_bd[e] = TIGHT && has[e] ? s_bdn[ls[e]] : 0.0f;
+            }
 #pragma unroll
             for (int e = 0; e < RB; ++e) d[e] = has[e] ? exact_dist<M>(a.lut32 + s_base[ls[e]], c, PLAIN && a.fp32_accum != 0) : 0.0f;
 #pragma unroll
@@ -780,6 +850,17 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanArgs a) {
                     const uint32_t li = atomicAdd(&wg_count[ls[e]], 1u);
                     if (li < (uint32_t)a.region_cap)
                         a.cand_key[(size_t)(slot0 + ls[e]) * a.cand_stride + region0 + li] = key;
+                    const float sc = t_sc[e];
+                    if (sc != 0.0f) {
+                        // by how many steps of XU filter units the slot's cut could be lowered with this node still
+                        // below it: u = (d (1 + 2^-20) - minima) * scale, its distance in units of the slot's tables,
+                        // in fp32 with 2e-3 units of margin against the node (the roundings are below 1e-4 units)
+                        const float u = __fmaf_rn(d[e] * sc, 0x1.000002p-20f, (d[e] - t_bd[e]) * sc);
+                        const int steps = min((int)(((float)C::QT - u) * (1.0f / C::XU) - 2e-3f), C::XMAX);
+                        // counted in LDS (a global atomic here sits in the wavefront's in-order memory queue in front of the
+                        // next round's table gathers); wave 0 moves the counts to the global histograms
+                        if (steps >= 1 && !(DPQ_TIGHT_DBG & 1)) atomicAdd(&s_hist[ls[e] * (kTightBuckets / 2) + (steps >> 1)], 1u << (16 * (steps & 1)));
+                    }
                 }
             }
         }
@@ -789,6 +870,120 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanArgs a) {
         if constexpr (STAMPS) st[kStRefines] += 1;
         __builtin_amdgcn_wave_barrier();
     };
+
+    // ---- in-scan threshold tightening ----
+    // The level's thresholds come from the bootstrap (the k-th best of ~3 K sampled nodes: about rank 8 k of the
+    // index) or from the previous level; while a launch runs, the candidates all workgroups of a query group have found
+    // say more.  Every candidate is counted (refine above) under the number of steps its slot's cut could be lowered
+    // with the node still below it; once the nodes that survive a cut of e steps number top_k, the final k-th key cannot
+    // lie above that cut.  Wave 0 of every workgroup, every few wave steps: moves the workgroup's counts from LDS to the
+    // group's global histograms (atomics), reads those back, lowers threshold keys (exact checks) and raises the additive
+    // terms of the filter's accumulator fields (a field's top bit then rejects at QT + 1 - e * XU units instead of
+    // QT + 1).  Thresholds only ever tighten and every one of them is an upper bound of the final k-th key, so the result
+    // does not depend on when a workgroup looks or on how fresh the counts it sees are: a count that lags still counts
+    // real nodes.  The reads are workgroup-scope loads (vector L1 bypassed, this XCD's L2): the workgroups of a query
+    // group run on one XCD (the remap above), and agent-scope loads of lines that L2 atomics keep dirty were measured
+    // at 3 x the whole scan.
+    int my_steps = 0;    // lane = local slot (wave 0): steps its cut has been lowered by
+    static_assert(kTightBuckets == 8, "a slot's LDS counters are one 16-byte read, its global row one 8-byte store");
+    uint2 row = make_uint2(0, 0);  // helper, lane = slot: this workgroup's row of the slot's counters as last written
+    bool frozen = false;
+    auto tighten = [&]() {  // the helper wavefront
+        const int ls = lane;
+        uint32_t raise = 0;
+        int field = 0;  // byte (R = 1) / halfword (R = 2) of s_extra that stands for the slot
+        if (ls < QG && s_scale[ls] != 0.0f) {
+            // This workgroup's running counts (LDS, 16 bits per bucket) go, saturated to bytes, to ITS row of the slot's
+            // counters -- a plain 8-byte store, one writer per row -- and the rows of the group's workgroups are read back
+            // and summed.  No atomics: agent-scope atomics on these lines from one wavefront per workgroup were measured
+            // to double the scan time (they sit in the CU's memory pipeline in front of the exact checks' gathers).
+            // layout [group][workgroup (split)][slot of the group] x 8 bytes: a row is what one workgroup writes, and the
+            // lanes (slots) of a look read consecutive addresses of it
+            uint2* h = reinterpret_cast<uint2*>(a.tight_hist + (size_t)slot0 * kTightWords) + ls;
+            asm volatile("" ::: "memory");
+            const uint4 now = reinterpret_cast<const uint4*>(s_hist)[ls];
+            auto sat = [](uint32_t v) { return min(v & 0xffffu, 255u) | (min(v >> 16, 255u) << 8); };
+            // (a 16-bit counter that passed 0x8000 could wrap into its neighbour before the next look: from then on this
+            // workgroup's row stays as it is -- counts may lag, they must never run ahead)
+            if ((now.x | now.y | now.z | now.w) & 0x80008000u) frozen = true;
+            if (!frozen) row = make_uint2(sat(now.x) | sat(now.y) << 16, sat(now.z) | sat(now.w) << 16);
+            const uint2 mine = row;
+            if (!frozen) h[(size_t)split * QG] = mine;
+            uint32_t cnt[kTightBuckets];
+#pragma unroll
+            for (int e = 0; e < kTightBuckets; ++e) cnt[e] = 0;
+            const int n_rows = (int)gridDim.x;  // <= kTightSplits (launch_scan)
+            for (int r0 = 0; r0 < n_rows; r0 += 4) {  // four rows per round: two 16-byte loads in flight
+                uint32_t w[8];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint64_t g = r0 + j < n_rows ? __hip_atomic_load(reinterpret_cast<const uint64_t*>(h + (size_t)(r0 + j) * QG),
+                                                                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0ull;
+                    w[2 * j] = (uint32_t)g, w[2 * j + 1] = (uint32_t)(g >> 32);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t lo = r0 + j == split ? mine.x : w[2 * j], hi = r0 + j == split ? mine.y : w[2 * j + 1];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) cnt[e] += (lo >> (8 * e)) & 0xffu, cnt[4 + e] += (hi >> (8 * e)) & 0xffu;
+                }
+            }
+            uint32_t c = 0;
+            int best = 0;
+#pragma unroll
+            for (int e = C::XMAX; e >= 1; --e) {
+                c += cnt[e];
+                if (best == 0 && c >= (uint32_t)a.tight_k) best = e;
+            }
+            if (best > my_steps && !(DPQ_TIGHT_DBG & 2)) {
+                raise = (DPQ_TIGHT_DBG & 8) ? 0u : (uint32_t)((best - my_steps) * C::XU);
+                my_steps = best;
+                // the cut in distance terms: nodes counted under >= best steps have d <= t2 (see refine)
+                const double t2 = ((double)s_bdn[ls] + (double)(C::QT - best * C::XU) / (double)s_scale[ls]) / (1.0 + 0x1p-20);
+                const uint64_t key = ((uint64_t)__float_as_uint(__double2float_ru(t2)) << 32) | 0xffffffffull;
+                if (key < s_thr[ls]) s_thr[ls] = key;
+                // the slot's accumulator field (inverse of Cfg::slot_of)
+                const int f = (ls % (C::J * F)) / C::J, acc = (ls / (C::J * F)) * EB + ls % C::J;
+                field = C::R == 1 ? acc * 4 + f : acc * 2 + f;
+            }
+        }
+        if constexpr (C::R == 1) {
+            // M = 8: the additive term of a slot's field lives in its m = 0 table entries (that is where the bias is).  The
+            // raises of this look are gathered into the 16 dwords of s_extra (byte = slot's field), and every entry of the
+            // rows (g, m = 0) that have one takes its four dwords' worth in one 16-byte read-add-write: this wavefront is the
+            // tables' only writer, byte fields cannot carry (Cfg: M SAT + BIAS + XMAX XU <= 255), and a gather that runs
+            // meanwhile sees the old or the new entry -- both are valid cuts.
+            if (__ballot(raise != 0)) {
+                if (raise != 0) reinterpret_cast<volatile uint8_t*>(s_extra)[field] = (uint8_t)raise;
+                __builtin_amdgcn_wave_barrier();
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+                    const uint4 d = reinterpret_cast<const uint4*>(s_extra)[g];  // broadcast
+                    if ((d.x | d.y | d.z | d.w) == 0) continue;  // wave-uniform
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        uint4 v = lut[(g * M) * 256 + lane + 64 * i];
+                        v.x += d.x, v.y += d.y, v.z += d.z, v.w += d.w;
+                        lut[(g * M) * 256 + lane + 64 * i] = v;
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+                if (lane < NA) s_extra[lane] = 0;
+                __builtin_amdgcn_wave_barrier();
+            }
+        } else {
+            if (raise != 0) reinterpret_cast<volatile uint16_t*>(s_extra)[field] = (uint16_t)(C::BIAS + my_steps * C::XU);
+        }
+    };
+    // The LAST wavefront of the workgroup does nothing but this (it draws no segments).  Measured alternatives, scan launch
+    // at bootstrap thresholds (no tightening: 0.121 ms): this helper 0.117; the looks inlined into the last wavefront's
+    // scan loop every 2 / 4 / 8 steps 0.128-0.130 (96 VGPRs with spills; without the register cap 121 VGPRs, which pushes
+    // the next pipelined batch's table build out from under the scan); a second copy of the scan loop for the last
+    // wavefront, with the looks, beside a clean copy for the other fifteen 0.122.  What the helper costs is its share of the
+    // exact checks' latency hiding: fifteen scanning wavefronts without any tightening take 0.126.
+    const bool helper = TIGHT && __builtin_amdgcn_readfirstlane(tid) >= kScanThreads - 64;  // scalar condition
+    uint32_t* wg_done = wg_checks + 2;  // scanning wavefronts that have finished
 
     // list entry s -> workgroup s % splits (a short list still reaches every workgroup); inside the
     // workgroup the wavefronts draw their next entry from an LDS counter, so a wavefront that met
@@ -875,7 +1070,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanArgs a) {
         return n;
     };
     Chunk A, B, Cn;
-    A.seg = next_entry();
+    A.seg = helper ? -1 : next_entry();  // the helper draws no segments: its scan loop below is empty
     A.pos = entry_pos;
     A.c = 0;
     stage1(A);
@@ -928,6 +1123,55 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanArgs a) {
             // ---- ADC lower bound: M LDS gathers per 4 * F queries; the fields of a dword are
             // summed with 3-input integer adds (no carry can cross a field) ----
             uint32_t acc[NA];
+            uint32_t fold_h[MD] = {};  // R == 1 with the pipelined gathers: the fold below is done as the groups complete
+            if constexpr (C::R == 1 && DPQ_GATHER_PIPE > 0) {
+                // The NG * 8 gathers of a wave step as ONE rolling window over the LDS queue: DPQ_GATHER_PIPE reads are
+                // issued up front, then every pair of reads that is summed into its accumulators is replaced by the next
+                // pair, so the queue never drains inside the step (the compiler's own order issued 16 + 8 + 8 reads with
+                // an s_waitcnt lgkmcnt(0) behind each group: three full drains per step at four wavefronts per SIMD).
+                // The scheduling fences pin the program order; the waits are the compiler's counted lgkmcnt(N).  The
+                // reject-bit fold of a group's four accumulators follows the group's last pair, under the later reads.
+                static_assert(NG * 8 == 32 && (DPQ_GATHER_PIPE % 2) == 0 && DPQ_GATHER_PIPE >= 2 && DPQ_GATHER_PIPE <= 14, "window of read pairs");
+                uint32_t off[8];
+#pragma unroll
+                for (int m = 0; m < 8; ++m) off[m] = (code[m >> 2] >> (8 * (m & 3))) & 0xffu;
+                uint4 gv[32];
+#define DPQ_RD(r) gv[r] = lut[(((r) >> 3) * M + ((r) & 7)) * 256 + off[(r) & 7]]
+#pragma unroll
+                for (int r = 0; r < DPQ_GATHER_PIPE; r += 2) {
+                    DPQ_RD(r);
+                    DPQ_RD(r + 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int p = 0; p < 16; ++p) {  // pair p = reads 2p, 2p + 1 = sub-spaces 2 (p & 3), + 1 of group p >> 2
+                    if (2 * p + DPQ_GATHER_PIPE < 32) {
+                        DPQ_RD(2 * p + DPQ_GATHER_PIPE);
+                        DPQ_RD(2 * p + DPQ_GATHER_PIPE + 1);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    const int g = p >> 2;
+                    const uint4 x = gv[2 * p], y = gv[2 * p + 1];
+                    if ((p & 3) == 0) {
+                        acc[4 * g + 0] = x.x + y.x;
+                        acc[4 * g + 1] = x.y + y.y;
+                        acc[4 * g + 2] = x.z + y.z;
+                        acc[4 * g + 3] = x.w + y.w;
+                    } else {
+                        acc[4 * g + 0] += x.x + y.x;
+                        acc[4 * g + 1] += x.y + y.y;
+                        acc[4 * g + 2] += x.z + y.z;
+                        acc[4 * g + 3] += x.w + y.w;
+                    }
+                    if ((p & 3) == 3) {
+#pragma unroll
+                        for (int j = 4 * g; j < 4 * g + 4; ++j)
+                            fold_h[j / EB] = and_or(acc[j], C::LOW << (EB - 1), fold_h[j / EB] >> 1);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#undef DPQ_RD
+            } else
 #pragma unroll
             for (int g = 0; g < NG; ++g) {
                 if constexpr (C::R == 1) {
@@ -945,8 +1189,14 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanArgs a) {
                     // byte sums of four sub-spaces (no carry: 4 * SAT <= 255), widened into 16-bit fields:
                     // even bytes -> accumulator 2 (4 g + c), odd bytes -> the next one; the fields start at BIAS
                     uint32_t lo[4], hi[4];
+                    if constexpr (TIGHT) {  // BIAS + what the slots' cuts were lowered by: broadcast reads of 16 words
+                        asm volatile("" ::: "memory");  // wave 0 of the workgroup rewrites them: re-read every step
+                        const uint4 e0 = reinterpret_cast<const uint4*>(s_extra)[2 * g], e1 = reinterpret_cast<const uint4*>(s_extra)[2 * g + 1];
+                        lo[0] = e0.x, hi[0] = e0.y, lo[1] = e0.z, hi[1] = e0.w, lo[2] = e1.x, hi[2] = e1.y, lo[3] = e1.z, hi[3] = e1.w;
+                    } else {
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) lo[c] = hi[c] = (uint32_t)C::BIAS * C::LOW;
+                        for (int c = 0; c < 4; ++c) lo[c] = hi[c] = (uint32_t)C::BIAS * C::LOW;
+                    }
 #pragma unroll
                     for (int m0 = 0; m0 < M; m0 += C::PRE) {
                         uint32_t p[4] = {0, 0, 0, 0};
@@ -984,8 +1234,12 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanArgs a) {
 #pragma unroll
             for (int h = 0; h < MD; ++h) {
                 uint32_t fail = 0;
+                if constexpr (C::R == 1 && DPQ_GATHER_PIPE > 0) {
+                    fail = fold_h[h];
+                } else {
 #pragma unroll
-                for (int j = 0; j < C::J; ++j) fail = and_or(acc[EB * h + j], C::LOW << (EB - 1), fail >> 1);
+                    for (int j = 0; j < C::J; ++j) fail = and_or(acc[EB * h + j], C::LOW << (EB - 1), fail >> 1);
+                }
                 fail >>= EB - C::J;
                 pend |= (uint64_t)(valid ? (~fail & live) : 0u) << (32 * h);
             }
@@ -1016,6 +1270,18 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanArgs a) {
     }
     while (rq_n > 0) refine(min(rq_n, 64));
     stamp(kStRefine);
+    if constexpr (TIGHT) {
+        // the helper keeps looking (about every microsecond) until the other fifteen wavefronts are done
+        if (helper) {
+            for (;;) {
+                tighten();
+                if (__builtin_amdgcn_readfirstlane((int)*reinterpret_cast<volatile uint32_t*>(wg_done)) >= kScanWaves - 1) break;
+                __builtin_amdgcn_s_sleep(DPQ_TIGHT_SLEEP);
+            }
+        } else if (lane == 0) {
+            atomicAdd(wg_done, 1u);
+        }
+    }
     if (a.counters || STAMPS) {
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) my_pairs += (uint32_t)__shfl_xor((int)my_pairs, off, 64);
@@ -1049,35 +1315,53 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanArgs a) {
 }
 
 // ---------------------------------------------------------------------------
-// stream: ONE query per pass (batches of one or two queries -- the reference's own call shape, main:328-339).
-// The 64-query filter machinery does not pay for a single query (a 128 KB table set of which one column is used);
-// here a wavefront decodes its chunks exactly as the scan does (same WaveDecoder, same three chunks in flight) and
-// evaluates every node against the query's EXACT table in LDS: an fp32 sum of the M entries first, the reference's
-// fp64 sum only for nodes within 2^-19 of the threshold; what passes the threshold key is a candidate, appended to
-// the slot's single region through one global atomic per wave step that found any (a tight bootstrap threshold
-// leaves a few per thousand nodes).  8 or 16 KB of LDS and ~64 VGPRs per wavefront: 32 wavefronts per CU stream the
-// compressed image -- this is the mode in which the path is bound by the decode and by HBM, not by the LDS array.
-// grid = (workgroups, slots), block = 256; the segments of the launch's list are dealt round-robin to the grid's
-// wavefronts.
+// stream: Q queries per pass over the COMPRESSED image, Q = 1, 2, 4, 8 (batches of up to kStreamMaxQ queries -- Q = 1 is
+// the reference's own call shape, main:328-339; the idea of one decode serving several queries is the reference's batch
+// variant, h:3223-3447).  The 64-query filter machinery does not pay for a handful of queries (a 128 KB table set of
+// which a few columns are used); here a wavefront decodes its chunks exactly as the scan does (same WaveDecoder, same
+// three chunks in flight) and evaluates every node against the queries' EXACT tables in LDS, interleaved by query
+// (T[m][code][Q]: one ds_read_b32 / _b64 / _b128 fetches a sub-space's entry for every query of the pass): an fp32
+// sum of the M entries first, the reference's fp64 sum only for nodes within 2^-19 of the query's threshold; what
+// passes the threshold key is a candidate, appended to the slot's single region through one global atomic per wave
+// step and query that found any (a tight bootstrap threshold leaves a few per thousand nodes).  Q * M KB of LDS:
+// this is the mode in which the path is bound by the decode's instruction count and by HBM, not by the LDS array.
+// grid = (workgroups, ceil(slots / Q)), block = 256; the segments of the launch's list are dealt round-robin to the
+// grid's wavefronts.
 // ---------------------------------------------------------------------------
-constexpr int kStreamThreads = 256;
+// Block size: the decode is a chain of global and crossbar round trips, so the kernel lives on wavefronts per CU.  Q <= 2:
+// 256 threads, 8-16 KB of tables, 32 wavefronts per CU at <= 64 VGPRs.  Q = 4 (32 KB of tables at M = 8): 512 threads share
+// one table set, four blocks = 32 wavefronts per CU as long as the kernel stays within 64 VGPRs (launch bounds).
+template <int Q>
+constexpr int stream_threads() { return Q >= 4 ? 512 : 256; }
 
-template <int M>
-__global__ __launch_bounds__(kStreamThreads, M <= 8 ? 8 : 4) void stream_kernel(const ScanArgs a) {
+template <int M, int Q>
+#ifndef DPQ_STREAM_Q4_WAVES
+#define DPQ_STREAM_Q4_WAVES 8
+#endif
+__global__ __launch_bounds__(stream_threads<Q>(), M > 8 ? 4 : Q >= 4 ? DPQ_STREAM_Q4_WAVES : 8) void stream_kernel(const ScanArgs a) {
+    constexpr int kStreamThreads = stream_threads<Q>();
     using C = Cfg<M>;
     constexpr int W = C::W, TE = M * 256;
-    __shared__ float T[TE];
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* T = reinterpret_cast<float*>(smem);  // [M][256][Q]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int slot = blockIdx.y;
-    int qq = a.slot_query ? a.slot_query[slot] : (slot < a.n_queries ? slot : -1);
-    if (qq < 0) return;  // block-uniform
-    {
-        const float4* src = reinterpret_cast<const float4*>(a.lut32 + (size_t)qq * TE);
-        for (int i = tid; i < TE / 4; i += kStreamThreads) reinterpret_cast<float4*>(T)[i] = src[i];
+    const int slot0 = blockIdx.y * Q;
+    uint64_t thr[Q];
+    float quick[Q];
+    bool any = false;
+#pragma unroll
+    for (int j = 0; j < Q; ++j) {
+        const int slot = slot0 + j;
+        const int qq = a.slot_query ? (slot < a.n_queries ? a.slot_query[slot] : -1) : (slot < a.n_queries ? slot : -1);
+        any |= qq >= 0;
+        // a slot nobody asks for: nothing passes (-inf), its table column is never looked at
+        thr[j] = qq >= 0 ? a.thr_key[slot] : 0ull;
+        // fp32 sums are within M * 2^-24 (relative) of the exact distance: everything that can pass lies below this
+        quick[j] = qq < 0 ? -INFINITY : thr[j] == ~0ull ? INFINITY : __uint_as_float((uint32_t)(thr[j] >> 32)) * (1.0f + 0x1p-19f);
+        const float* src = a.lut32 + (size_t)(qq >= 0 ? qq : 0) * TE;
+        for (int i = tid; i < TE; i += kStreamThreads) T[i * Q + j] = qq >= 0 ? src[i] : 0.0f;
     }
-    const uint64_t thr = a.thr_key[slot];
-    // fp32 sums are within M * 2^-24 (relative) of the exact distance: everything that can pass lies below this
-    const float quick = thr == ~0ull ? INFINITY : __uint_as_float((uint32_t)(thr >> 32)) * (1.0f + 0x1p-19f);
+    if (!any) return;  // block-uniform
     __syncthreads();
 
     const int cps = a.img.chunks_per_segment;
@@ -1132,8 +1416,6 @@ __global__ __launch_bounds__(kStreamThreads, M <= 8 ? 8 : 4) void stream_kernel(
         }
         return n;
     };
-    uint32_t* count = a.cand_count + (size_t)slot * kRegionStride + 1;      // the slot's single region
-    uint64_t* region = a.cand_key + (size_t)slot * a.cand_stride + a.region_off;
     Chunk A, B, Cn;
     A.seg = next_entry();
     A.c = 0;
@@ -1158,22 +1440,49 @@ __global__ __launch_bounds__(kStreamThreads, M <= 8 ? 8 : 4) void stream_kernel(
             for (int w = 0; w < W; ++w) dec.stk[w] = A.h_stk[w];
         }
         dec.finish(A.ld, lane, A.carry_lane, code);
-        float d32 = 0.0f;
+        float d32[Q];
 #pragma unroll
-        for (int m = 0; m < M; ++m) d32 += T[m * 256 + ((code[m >> 2] >> (8 * (m & 3))) & 0xffu)];
-        bool pass = node < a.img.n_local && d32 <= quick;
-        uint64_t key = 0;
-        if (pass) {  // the reference's distance (fp64 sum rounded once) and the whole (distance, id) key
-            key = make_key(exact_dist<M>(T, code, false), a.img.id_base + (uint32_t)node);
-            pass = key <= thr;
+        for (int j = 0; j < Q; ++j) d32[j] = 0.0f;
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+            const float* row = T + (size_t)(m * 256 + ((code[m >> 2] >> (8 * (m & 3))) & 0xffu)) * Q;
+            if constexpr (Q == 1) {
+                d32[0] += row[0];
+            } else if constexpr (Q == 2) {
+                const float2 v = *reinterpret_cast<const float2*>(row);
+                d32[0] += v.x, d32[1] += v.y;
+            } else {
+#pragma unroll
+                for (int j0 = 0; j0 < Q; j0 += 4) {
+                    const float4 v = *reinterpret_cast<const float4*>(row + j0);
+                    d32[j0] += v.x, d32[j0 + 1] += v.y, d32[j0 + 2] += v.z, d32[j0 + 3] += v.w;
+                }
+            }
         }
-        const uint64_t found = __ballot(pass);
-        if (found) {
-            uint32_t base = 0;
-            if (lane == 0) base = atomicAdd(count, (uint32_t)__popcll(found));
-            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-            const uint32_t li = base + mbcnt64(found, 0);
-            if (pass && li < (uint32_t)a.region_cap) region[li] = key;
+        const bool valid = node < a.img.n_local;
+#pragma unroll
+        for (int j = 0; j < Q; ++j) {
+            bool pass = valid && d32[j] <= quick[j];
+            if (__ballot(pass) == 0) continue;  // wave-uniform: nothing of this step can pass for query j
+            uint64_t key = 0;
+            if (pass) {  // the reference's distance (fp64 sum rounded once) and the whole (distance, id) key
+                double dsum = 0.0;
+#pragma unroll
+                for (int m = 0; m < M; ++m)
+                    dsum = __dadd_rn(dsum, (double)T[(size_t)(m * 256 + ((code[m >> 2] >> (8 * (m & 3))) & 0xffu)) * Q + j]);
+                key = make_key((float)dsum, a.img.id_base + (uint32_t)node);
+                pass = key <= thr[j];
+            }
+            const uint64_t found = __ballot(pass);
+            if (found) {
+                uint32_t* count = a.cand_count + (size_t)(slot0 + j) * kRegionStride + 1;  // the slot's single region
+                uint64_t* region = a.cand_key + (size_t)(slot0 + j) * a.cand_stride + a.region_off;
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(count, (uint32_t)__popcll(found));
+                base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                const uint32_t li = base + mbcnt64(found, 0);
+                if (pass && li < (uint32_t)a.region_cap) region[li] = key;
+            }
         }
         A = B;
         B = Cn;
@@ -1937,12 +2246,12 @@ size_t select_lds_bytes(int M, int top_k, int n_shared) {
 
 hipError_t launch_lut_build(const float* d_codebook, const float* d_queries, int nq, int n_slots, int M, int K, int Ds,
                             float* d_lut32, float* d_lut_min, uint32_t* d_cand_count, uint32_t* d_overflow,
-                            const uint8_t* d_relabel, float* d_lut_labels, hipStream_t stream) {
+                            const uint8_t* d_relabel, float* d_lut_labels, uint32_t* d_tight_hist, hipStream_t stream) {
     if (nq <= 0) return hipSuccess;
     n_slots = std::max(n_slots, nq);
     hipLaunchKernelGGL(lut_build_kernel, dim3((unsigned)((n_slots + kLutQueries - 1) / kLutQueries), (unsigned)M),
                        dim3(256), 0, stream, d_codebook, d_queries, nq, n_slots, M, K, Ds, d_lut32, d_lut_min,
-                       d_cand_count, d_overflow, d_relabel, d_relabel ? d_lut_labels : nullptr);
+                       d_cand_count, d_overflow, d_relabel, d_relabel ? d_lut_labels : nullptr, d_tight_hist);
     return hipGetLastError();
 }
 
@@ -1973,29 +2282,58 @@ hipError_t launch_decode_list(const DeviceImage& img, const uint32_t* seg_list, 
     return hipGetLastError();
 }
 
-template <int M, bool PLAIN, bool STAMPS>
+template <int M, bool PLAIN, bool STAMPS, bool TIGHT = false>
 static hipError_t launch_scan_m(const ScanArgs& a, int n_slot_groups, int splits, hipStream_t stream) {
     static std::atomic<bool> done[64] = {};
-    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&scan_kernel<M, PLAIN, STAMPS>), scan_lds_bytes(M), done);
+    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&scan_kernel<M, PLAIN, STAMPS, TIGHT>), scan_lds_bytes(M), done);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((scan_kernel<M, PLAIN, STAMPS>), dim3((unsigned)splits, (unsigned)n_slot_groups),
+    hipLaunchKernelGGL((scan_kernel<M, PLAIN, STAMPS, TIGHT>), dim3((unsigned)splits, (unsigned)n_slot_groups),
                        dim3(kScanThreads), scan_lds_bytes(M), stream, a);
     return hipGetLastError();
 }
 
-// One query per pass: n_slots passes over the launch's segment list (stream_kernel).  The slot's region 1 count must be
-// zero before the launch.
+// Q queries per pass (stream_kernel): ceil(n_slots / Q) passes over the launch's segment list; Q = the smallest of
+// 1, 2, 4 that covers the batch (eight per pass were measured too: 64 KB of tables leave 8-16 wavefronts per CU, and
+// the batched filter path answers eight queries in half the time).  The slots' region 1 counts must
+// be zero before the launch.
+template <int M, int Q>
+static hipError_t launch_stream_mq(const ScanArgs& a, int n_slots, hipStream_t stream) {
+    const size_t lds = (size_t)Q * M * 256 * sizeof(float);
+    static std::atomic<bool> done[64] = {};
+    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&stream_kernel<M, Q>), lds, done);
+    if (e != hipSuccess) return e;
+    const int passes = (n_slots + Q - 1) / Q;
+    constexpr int threads = stream_threads<Q>(), waves = threads / 64;
+    // enough workgroups to fill 256 CUs at the occupancy the tables' LDS allows, never more wavefronts than segments
+    const int per_cu = std::max(1, std::min(32 / waves, (int)(160 * 1024 / lds)));
+    const int wgs = std::max(1, std::min(256 * per_cu / std::max(1, std::min(passes, 8)), (a.n_seg_pass + waves - 1) / waves));
+    hipLaunchKernelGGL((stream_kernel<M, Q>), dim3((unsigned)wgs, (unsigned)passes), dim3(threads), lds, stream, a);
+    return hipGetLastError();
+}
+
+int stream_queries_per_pass(int M, int n_slots) {
+    (void)M;
+    return n_slots <= 1 ? 1 : n_slots <= 2 ? 2 : 4;
+}
+
 hipError_t launch_stream(const ScanArgs& a, int n_slots, hipStream_t stream) {
     if (a.n_seg_pass <= 0 || n_slots <= 0) return hipSuccess;
-    // enough workgroups for 32 wavefronts per CU on 256 CUs, never more wavefronts than segments
-    const int wgs = std::max(1, std::min(2048 / std::max(1, std::min(n_slots, 8)), (a.n_seg_pass + 3) / 4));
-    if (a.img.M == 8)
-        hipLaunchKernelGGL(stream_kernel<8>, dim3((unsigned)wgs, (unsigned)n_slots), dim3(kStreamThreads), 0, stream, a);
-    else if (a.img.M == 16)
-        hipLaunchKernelGGL(stream_kernel<16>, dim3((unsigned)wgs, (unsigned)n_slots), dim3(kStreamThreads), 0, stream, a);
-    else
-        return hipErrorInvalidValue;
-    return hipGetLastError();
+    const int q = stream_queries_per_pass(a.img.M, n_slots);
+    if (a.img.M == 8) {
+        switch (q) {
+            case 1: return launch_stream_mq<8, 1>(a, n_slots, stream);
+            case 2: return launch_stream_mq<8, 2>(a, n_slots, stream);
+            default: return launch_stream_mq<8, 4>(a, n_slots, stream);
+        }
+    }
+    if (a.img.M == 16) {
+        switch (q) {
+            case 1: return launch_stream_mq<16, 1>(a, n_slots, stream);
+            case 2: return launch_stream_mq<16, 2>(a, n_slots, stream);
+            default: return launch_stream_mq<16, 4>(a, n_slots, stream);
+        }
+    }
+    return hipErrorInvalidValue;
 }
 
 hipError_t launch_quantise(const ScanArgs& a, int n_slot_groups, hipStream_t stream) {
@@ -2021,10 +2359,14 @@ hipError_t launch_scan(const ScanArgs& a, int n_slot_groups, int splits, hipStre
         return plain ? launch_scan_m<8, true, true>(a, n_slot_groups, splits, stream)
                      : launch_scan_m<8, false, true>(a, n_slot_groups, splits, stream);
     }
-    if (a.img.M == 8) return plain ? launch_scan_m<8, true, false>(a, n_slot_groups, splits, stream)
-                                   : launch_scan_m<8, false, false>(a, n_slot_groups, splits, stream);
-    if (a.img.M == 16) return plain ? launch_scan_m<16, true, false>(a, n_slot_groups, splits, stream)
-                                    : launch_scan_m<16, false, false>(a, n_slot_groups, splits, stream);
+    // in-scan threshold tightening: plain-code instantiations only (the decode's registers leave no room for it)
+    const bool tight = plain && a.tight_hist != nullptr && a.tight_k > 0 && a.debug_pass == 0 && splits <= kTightSplits;
+    if (a.img.M == 8) return !plain ? launch_scan_m<8, false, false>(a, n_slot_groups, splits, stream)
+                             : tight ? launch_scan_m<8, true, false, true>(a, n_slot_groups, splits, stream)
+                                     : launch_scan_m<8, true, false>(a, n_slot_groups, splits, stream);
+    if (a.img.M == 16) return !plain ? launch_scan_m<16, false, false>(a, n_slot_groups, splits, stream)
+                              : tight ? launch_scan_m<16, true, false, true>(a, n_slot_groups, splits, stream)
+                                      : launch_scan_m<16, true, false>(a, n_slot_groups, splits, stream);
     return hipErrorInvalidValue;
 }
 

@@ -129,6 +129,8 @@ typedef struct dpq_open_opts {
 #define DPQ_OPT_NO_FUSE_QUANTISE 2u /* first filter level's tables by quantise_kernel, not by the bootstrap  [DPQ_FUSE_QUANTISE=0] */
 #define DPQ_OPT_NO_ASYNC_OVERLAP 4u /* dpq_query_batch_device_async: one workspace, the caller's stream  [DPQ_ASYNC_OVERLAP=0] */
 #define DPQ_OPT_BOOT_FULLSORT 8u    /* bootstrap ranks all 256 centroids exactly  [DPQ_BOOT_FULLSORT=1] */
+#define DPQ_OPT_NO_TIGHTEN 16u      /* filter scans keep a level's thresholds as they were when it started instead of lowering
+                                     * them as candidates accumulate  [DPQ_TIGHTEN=0] */
 
 typedef struct dpq_info {
     int64_t n_codes_total;     /* N of the whole index (header field 0, h:1839-1840) */

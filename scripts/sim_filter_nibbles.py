@@ -21,7 +21,7 @@ else:
     del base
     np.savez(cache, cb=cb, codes=codes, queries=queries)
 Ds = 128 // M
-CONFIGS = [(80, 26), (80, 15), (64, 15), (56, 15), (48, 15), (40, 15), (32, 15), (100, 15), (120, 15), (24, 7), (16, 7)]
+CONFIGS = [(80, 26), (80, 24), (80, 23), (80, 22), (72, 23), (72, 22), (64, 24), (64, 23), (64, 22), (64, 21), (56, 23)]
 
 
 def survivors(T, tau, qt, sat, codes):

@@ -574,26 +574,37 @@ def test_batch_decode_in_tiles(gpu, oracle, codebook, n, tile, k):
 
 @pytest.mark.parametrize("n,M,k", [(200_000, 8, 50), (9_000, 8, 10), (2_300_000, 8, 100), (150_000, 16, 30)])
 def test_one_query_per_pass_matches_the_batched_path(gpu, oracle, n, M, k):
-    """Batches of one or two queries run stream_kernel (one query per pass over the compressed image, every node
-    against the exact table); the same queries inside a larger batch run the 64-query filter path.  Same lists, bit
-    for bit; and against the oracle.  Shapes: bootstrap shard, small cascade shard, a shard beyond 2 M nodes (two
-    levels), M = 16; also as shard 1 of 2."""
+    """Batches of up to eight queries run stream_kernel (1, 2, 4 or 8 queries per pass over the compressed image, every
+    decoded node against the queries' exact tables in LDS); the same queries inside a larger batch run the 64-query
+    filter path.  Same lists, bit for bit; and against the oracle.  Batch sizes 1, 2, 3 (a pass of four with an unused
+    slot), 4, 5, 8 (M = 16: two passes of four) and 9 (back on the filter path).  Shapes: bootstrap shard, small cascade
+    shard, a shard beyond 2 M nodes (two levels), M = 16; also as shard 1 of 2."""
     from deltapq_amd import synth
     cb = synth.make_codebook(M, 256, 128 // M, seed=3)
     tree = synth.synth_tree(n, M, seed=n + 5, mean_diffs=3.0 if M == 8 else 5.0)
     payload, _ = synth.encode_dtc(tree)
     qs = synth.make_queries(70, 128, seed=n + 6)
+    cuts = [(0, 1), (5, 7), (10, 13), (20, 24), (30, 35), (40, 48), (50, 59)]
     for kw in ({}, {"shard_rank": 1, "shard_count": 2}):
         with gpu.DeltaPQIndex.open_memory(payload, n, M, 256, **kw) as idx:
             idx.set_codebook(cb)
             ids_b, d_b = idx.query_batch(qs, k)                # 70 queries: filter path
-            ids_1, d_1 = idx.query_batch(qs[:1], k)            # stream
-            ids_2, d_2 = idx.query_batch(qs[5:7], k)           # stream, two passes
-        assert np.array_equal(ids_1, ids_b[:1]) and np.array_equal(d_1.view(np.uint32), d_b[:1].view(np.uint32))
-        assert np.array_equal(ids_2, ids_b[5:7]) and np.array_equal(d_2.view(np.uint32), d_b[5:7].view(np.uint32))
+            got = [idx.query_batch(qs[lo:hi], k) for lo, hi in cuts]
+            idx.profile_enable(1)
+            idx.profile_reset()
+            idx.query_batch(qs[20:24], k)
+            prof = idx.profile_read()
+        for (lo, hi), (ids_s, d_s) in zip(cuts, got):
+            assert np.array_equal(ids_s, ids_b[lo:hi]), (lo, hi, kw)
+            assert np.array_equal(d_s.view(np.uint32), d_b[lo:hi].view(np.uint32)), (lo, hi, kw)
+        # the stream path visits every (node, query) pair once and checks nothing through the filter
+        assert prof["exact_checks"] == 0 and prof["scan_launches"] >= 1
         if not kw:
-            assert_parity(np.concatenate([ids_1, ids_2]), np.concatenate([d_1, d_2]),
-                          oracle_topk(oracle, payload, n, cb, qs[[0, 5, 6]], k), n)
+            pick = [0, 5, 6, 10, 12, 23, 34, 47]
+            sel = {q: (i, q - lo) for i, (lo, hi) in enumerate(cuts) for q in range(lo, hi)}
+            ids_p = np.stack([got[sel[q][0]][0][sel[q][1]] for q in pick])
+            d_p = np.stack([got[sel[q][0]][1][sel[q][1]] for q in pick])
+            assert_parity(ids_p, d_p, oracle_topk(oracle, payload, n, cb, qs[pick], k), n)
 
 
 def test_codebook_can_be_set_again_between_scratch_batches(gpu, oracle, codebook):
