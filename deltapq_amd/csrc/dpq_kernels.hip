@@ -1330,13 +1330,14 @@ __global__ __launch_bounds__(kScanThreads, (PLAIN && !STAMPS && M <= 8) ? 5 : 4)
 // ---------------------------------------------------------------------------
 // Block size: the decode is a chain of global and crossbar round trips, so the kernel lives on wavefronts per CU.  Q <= 2:
 // 256 threads, 8-16 KB of tables, 32 wavefronts per CU at <= 64 VGPRs.  Q = 4 (32 KB of tables at M = 8): 512 threads share
-// one table set, four blocks = 32 wavefronts per CU as long as the kernel stays within 64 VGPRs (launch bounds).
+// one table set; the kernel wants 78 VGPRs: three blocks = 24 wavefronts per CU (squeezed into 64 VGPRs for 32 wavefronts
+// it spills: four queries x 125 M codes 1.74 ms against 0.85; 256-thread blocks, 20 wavefronts: 1.00).
 template <int Q>
 constexpr int stream_threads() { return Q >= 4 ? 512 : 256; }
 
 template <int M, int Q>
 #ifndef DPQ_STREAM_Q4_WAVES
-#define DPQ_STREAM_Q4_WAVES 8
+#define DPQ_STREAM_Q4_WAVES 6
 #endif
 __global__ __launch_bounds__(stream_threads<Q>(), M > 8 ? 4 : Q >= 4 ? DPQ_STREAM_Q4_WAVES : 8) void stream_kernel(const ScanArgs a) {
     constexpr int kStreamThreads = stream_threads<Q>();
