@@ -85,7 +85,10 @@ struct dpq_tree {
 
 // Plan and tiling knobs of a handle: dpq_open_opts' fields with the defaults filled in (resolve_tuning).
 struct Tuning {
-    int stream_max = 8;          // batches up to this size take stream_kernel (1, 2, 4 or 8 queries per pass)
+    // batches up to this size take stream_kernel (1, 2 or 4 queries per pass).  Measured at 125 M codes (ms per call,
+    // stream / 64-query filter path): 1 query 0.64 / 1.26, 2: 0.66 / 1.22, 4: 0.85 / 1.22, 8 (two passes of four, or one of
+    // eight at 8 wavefronts per CU): 1.7-2.3 / 1.21, 16: 4.3 / 1.23 -- the switch-over sits behind four
+    int stream_max = 4;
     int coarse_below = 128;
     int plan_ratios[3] = {0, 0, 0};
     int boot_cap = 0, boot_target = 0;

@@ -110,9 +110,9 @@ typedef struct dpq_open_opts {
      * part of the options (not of the environment) so that the ranks of a multi-GPU launch cannot diverge from
      * each other through their environments.  With DPQ_DEV=1 in the environment -- developer sweeps only -- the
      * variables named in brackets override them, read once per dpq_open_*. ---- */
-    int32_t stream_max_queries; /* batches of up to this many queries take the one-pass-per-query-set stream kernel
-                                 * (exact tables in LDS, no filter tables) instead of the 64-query filter scan: 0 = the
-                                 * measured switch-over, -1 = never  [DPQ_STREAM_MAX_QUERIES] */
+    int32_t stream_max_queries; /* batches of up to this many queries take the stream kernel (1, 2 or 4 queries per pass over
+                                 * the compressed image, exact tables in LDS, no filter tables) instead of the 64-query
+                                 * filter scan: 0 = the measured switch-over (4), -1 = never  [DPQ_STREAM_MAX_QUERIES] */
     int32_t coarse_below;       /* batches of up to this many queries use the coarse cascade plan on shards without a
                                  * threshold bootstrap; 0 = 128  [DPQ_COARSE_BELOW] */
     int32_t plan_ratios[3];     /* force the size ratios between consecutive filter levels (each >= 2); 0 = automatic

@@ -509,15 +509,49 @@ def test_bench_two_ranks_rehearsal(gpu, built, mode):
         assert "index shards x2" in line["config"]["sharding"]
 
 
-def test_bench_two_gpus_over_rccl(gpu, built):
+@pytest.mark.parametrize("mode", ["index_pipeline", "index_stream_parts", "query"])
+def test_bench_two_gpus_over_rccl(gpu, built, mode):
     """The RCCL branch of the exchange (all_gather_into_tensor on device tensors + device merge): only where two
-    GPUs are visible (the driver's multi-GPU node); the 1-GPU box skips it."""
+    GPUs are visible (the driver's multi-GPU node); the 1-GPU box skips it.  Three shapes: a pipeline-built index cut
+    into DFS-range shards, every rank synthesising only its own part of a larger index (BASELINE configs[3]/[4]:
+    --data stream), and query replicas (no collective on the data path)."""
     import torch
     if torch.cuda.device_count() < 2:
         pytest.skip("needs 2 visible GPUs (RCCL wants one device per rank)")
-    line = _run_bench(["--backend", "nccl", "--data", "pipeline", "--codes", "300000", "--queries", "200", "--steps", "3",
-                       "--warmup", "1", "--reps", "2", "--check", "8", "--no-cpu-baseline"])
-    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["parity_checked_queries"] == 8
+    args = {"index_pipeline": ["--data", "pipeline", "--codes", "300000"],
+            "index_stream_parts": ["--data", "stream", "--codes", "600000"],
+            "query": ["--data", "pipeline", "--codes", "300000", "--shard", "query"]}[mode]
+    line = _run_bench(["--backend", "nccl"] + args + ["--queries", "200", "--steps", "3", "--warmup", "1", "--reps", "2",
+                                                      "--check", "8", "--no-cpu-baseline"])
+    assert line["n_gpus"] == 2 and line["parity_checked_queries"] == 8 and line["value"] > 0
+    assert line["scaling"] == ("weak" if mode == "query" else "strong")
+    if mode != "query":
+        assert line["config"]["collectives"].startswith("RCCL (backend nccl)"), line["config"]["collectives"]
+
+
+def test_cli_two_gpus_shards_and_merges(gpu, oracle, tmp_path):
+    """`deltapq -task query -gpus 2`: one process, a host thread per device, each device a DFS-range shard, partial
+    lists merged on the host (dpq_merge_topk_host) -- the north star's host-merged decomposition.  Needs two visible
+    devices; with one the tool must refuse and say why."""
+    import torch
+    from deltapq_amd import synth
+    d = str(tmp_path)
+    n, k = 60_000, 20
+    tree, cb, queries = synth.make_dataset_dir(d, n, 40, seed=77)
+    n_codes, payload = gpu.read_dtc_file(synth.dtc_file_name(d, 8, 256, n))
+    exe = os.path.join(ROOT, "deltapq_amd", "csrc", "deltapq")
+    out = os.path.join(d, "results2.bin")
+    r = subprocess.run([exe, "-dataset", d, "-task", "query", "-m", "8", "-k", "256", "-h", "1", "-diff", "8", "-N", str(n),
+                        "-query_size", "40", "-topk", str(k), "-gpus", "2", "-out", out], capture_output=True, text=True, timeout=300)
+    if torch.cuda.device_count() < 2:
+        assert r.returncode != 0 and "only 1 device(s) visible" in r.stdout, r.stdout + r.stderr
+        pytest.skip("needs 2 visible GPUs for the sharded run itself")
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "index resident on 2 GPU(s)" in r.stdout
+    raw = np.fromfile(out, dtype=np.uint8)
+    ids = np.frombuffer(raw[16:16 + 40 * k * 4], np.int32).reshape(40, k)
+    dists = np.frombuffer(raw[16 + 40 * k * 4:], np.float32).reshape(40, k)
+    assert_parity(ids, dists, oracle_topk(oracle, payload, n, cb, queries[:40], k), n)
 
 
 def test_bench_survives_an_unusable_rccl(gpu, built):
@@ -574,11 +608,12 @@ def test_batch_decode_in_tiles(gpu, oracle, codebook, n, tile, k):
 
 @pytest.mark.parametrize("n,M,k", [(200_000, 8, 50), (9_000, 8, 10), (2_300_000, 8, 100), (150_000, 16, 30)])
 def test_one_query_per_pass_matches_the_batched_path(gpu, oracle, n, M, k):
-    """Batches of up to eight queries run stream_kernel (1, 2, 4 or 8 queries per pass over the compressed image, every
-    decoded node against the queries' exact tables in LDS); the same queries inside a larger batch run the 64-query
-    filter path.  Same lists, bit for bit; and against the oracle.  Batch sizes 1, 2, 3 (a pass of four with an unused
-    slot), 4, 5, 8 (M = 16: two passes of four) and 9 (back on the filter path).  Shapes: bootstrap shard, small cascade
-    shard, a shard beyond 2 M nodes (two levels), M = 16; also as shard 1 of 2."""
+    """Small batches run stream_kernel (1, 2 or 4 queries per pass over the compressed image, every decoded node against
+    the queries' exact tables in LDS); the same queries inside a larger batch run the 64-query filter path.  Same lists,
+    bit for bit; and against the oracle.  The index is opened with stream_max_queries = 8 (the default switch-over is
+    4) so that multi-pass batches are covered too: 1, 2, 3 (a pass of four with an unused slot), 4, 5 (4 + 1), 8
+    (two passes of four) and 9 (back on the filter path).  Shapes: bootstrap shard, small cascade shard, a shard beyond
+    2 M nodes (two levels), M = 16; also as shard 1 of 2."""
     from deltapq_amd import synth
     cb = synth.make_codebook(M, 256, 128 // M, seed=3)
     tree = synth.synth_tree(n, M, seed=n + 5, mean_diffs=3.0 if M == 8 else 5.0)
@@ -586,7 +621,7 @@ def test_one_query_per_pass_matches_the_batched_path(gpu, oracle, n, M, k):
     qs = synth.make_queries(70, 128, seed=n + 6)
     cuts = [(0, 1), (5, 7), (10, 13), (20, 24), (30, 35), (40, 48), (50, 59)]
     for kw in ({}, {"shard_rank": 1, "shard_count": 2}):
-        with gpu.DeltaPQIndex.open_memory(payload, n, M, 256, **kw) as idx:
+        with gpu.DeltaPQIndex.open_memory(payload, n, M, 256, stream_max_queries=8, **kw) as idx:
             idx.set_codebook(cb)
             ids_b, d_b = idx.query_batch(qs, k)                # 70 queries: filter path
             got = [idx.query_batch(qs[lo:hi], k) for lo, hi in cuts]
