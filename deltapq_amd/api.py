@@ -88,14 +88,16 @@ class HostSoA:
         info = Info()
         check(lib.dpq_soa_info(h, info), "dpq_soa_info")
         self.info = info.as_dict()
-        names = ["nib", "mask", "delta", "seg_delta_off", "seg_ckpt", "mi_cell_start", "mi_code", "mi_id", "par", "carry"]
+        names = ["nib", "mask", "delta", "seg_delta_off", "seg_ckpt", "mi_cell_start", "mi_code", "mi_id", "par", "carry",
+                 "st_ckpt", "st_hdr", "st_poff", "st_pbase", "st_delta"]
+        views = {"seg_delta_off": np.uint64, "st_ckpt": np.uint64, "st_hdr": np.uint64, "st_poff": np.uint16, "st_pbase": np.uint32}
         for which, name in enumerate(names):
             ptr, nb = ctypes.c_void_p(), _lib.c_i64()
             check(lib.dpq_soa_array(h, which, ptr, nb), "dpq_soa_array")
             buf = (ctypes.c_ubyte * nb.value).from_address(ptr.value) if nb.value else b""
             arr = np.frombuffer(buf, dtype=np.uint8).copy()
-            if name == "seg_delta_off":
-                arr = arr.view(np.uint64)
+            if name in views:
+                arr = arr.view(views[name])
             if name.startswith("mi_"):
                 arr = arr.view(np.uint32)
             setattr(self, name, arr)

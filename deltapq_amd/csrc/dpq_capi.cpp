@@ -93,7 +93,7 @@ struct Tuning {
     int plan_ratios[3] = {0, 0, 0};
     int boot_cap = 0, boot_target = 0;
     int64_t batch_tile_nodes = (int64_t)16 << 20;
-    bool relabel = true, fuse_quantise = true, async_overlap = true, boot_fullsort = false, tighten = true;
+    bool relabel = true, fuse_quantise = true, async_overlap = true, boot_fullsort = false, tighten = true, strands = true;
 };
 
 struct dpq_index {
@@ -105,6 +105,12 @@ struct dpq_index {
     dpq_info info{};
     dpq::DeviceImage img;
     // owned device memory of the image
+    // strand image (dpq_format.h): the stream pass's own layout of the same nodes (M = 8, shards with a bootstrap)
+    uint64_t *d_st_ckpt = nullptr, *d_st_hdr = nullptr;
+    uint16_t* d_st_poff = nullptr;
+    uint32_t *d_st_pbase = nullptr, *d_strip_order = nullptr;
+    uint8_t* d_st_delta = nullptr;
+    int64_t strand_bytes = 0;
     uint8_t *d_nib = nullptr, *d_par = nullptr, *d_carry = nullptr, *d_mask = nullptr, *d_delta = nullptr, *d_ckpt = nullptr,
             *d_raw = nullptr;
     bool plain = false;  // uncompressed comparator index (fp32-accumulate rule, no id quirk)
@@ -219,6 +225,7 @@ Tuning resolve_tuning(const dpq_open_opts& o) {
     t.async_overlap = !(o.flags & DPQ_OPT_NO_ASYNC_OVERLAP);
     t.boot_fullsort = (o.flags & DPQ_OPT_BOOT_FULLSORT) != 0;
     t.tighten = !(o.flags & DPQ_OPT_NO_TIGHTEN);
+    t.strands = !(o.flags & DPQ_OPT_NO_STRANDS);
     const char* dev = getenv("DPQ_DEV");
     if (dev && atoi(dev) != 0) {
         auto geti = [](const char* name, int* v) { if (const char* e = getenv(name)) *v = atoi(e); };
@@ -234,6 +241,7 @@ Tuning resolve_tuning(const dpq_open_opts& o) {
         v = 1; geti("DPQ_ASYNC_OVERLAP", &v); t.async_overlap = t.async_overlap && v != 0;
         v = 0; geti("DPQ_BOOT_FULLSORT", &v); t.boot_fullsort = t.boot_fullsort || v != 0;
         v = 1; geti("DPQ_TIGHTEN", &v); t.tighten = t.tighten && v != 0;
+        v = 1; geti("DPQ_STRANDS", &v); t.strands = t.strands && v != 0;
     }
     return t;
 }
@@ -672,7 +680,18 @@ int run_batch(dpq_index* x, const float* d_queries, int nq, int top_k, int32_t* 
                 se.n_regions = 2;
                 DPQ_HIP(hipMemset2DAsync(x->d_cand_count + 1, sizeof(uint32_t) * dpq::kRegionStride, 0, sizeof(uint32_t),
                                          (size_t)nq, stream));
-                {
+                if (x->img.st_ckpt) {
+                    // the pass over the strand image: the level's share of the strips (every strip exactly once over
+                    // the levels, like the segments; the bootstrap consumed none)
+                    const int64_t nseg = x->img.n_segments, ns = x->img.n_strips;
+                    const int64_t lo = (int64_t)x->level_off[l] * ns / nseg;
+                    const int64_t hi = final_pass ? ns : ((int64_t)x->level_off[l] + x->level_cnt[l]) * ns / nseg;
+                    dpq::ScanArgs st = sa;
+                    st.seg_list = x->d_strip_order + lo;
+                    st.n_seg_pass = (int32_t)(hi - lo);
+                    Timer t(x, stream, 1);
+                    DPQ_HIP(dpq::launch_strand(st, nq, stream));
+                } else {
                     Timer t(x, stream, 1);
                     DPQ_HIP(dpq::launch_stream(sa, nq, stream));
                 }
@@ -921,6 +940,32 @@ int open_from_payload(const uint8_t* payload, int64_t n_bytes, int64_t n_codes, 
     }
     if (!rc && x->tune.relabel && soa.relabel.size() == (size_t)M * 256) {
         rc = up(&x->d_relabel, soa.relabel.data(), soa.relabel.size());
+    }
+    if (!rc && x->boot && x->tune.strands && soa.n_strips > 0 && soa.n_strips < INT32_MAX) {
+        rc = up(&x->d_st_ckpt, soa.st_ckpt.data(), soa.st_ckpt.size() * 8);
+        if (!rc) rc = up(&x->d_st_hdr, soa.st_hdr.data(), soa.st_hdr.size() * 8);
+        if (!rc) rc = up(&x->d_st_poff, soa.st_poff.data(), soa.st_poff.size() * 2);
+        if (!rc) rc = up(&x->d_st_pbase, soa.st_pbase.data(), soa.st_pbase.size() * 4);
+        if (!rc) rc = up(&x->d_st_delta, soa.st_delta.data(), soa.st_delta.size());
+        if (!rc) {
+            // strips are visited in a low-discrepancy order too (every prefix a spread sample of the shard)
+            const int64_t ns = soa.n_strips;
+            std::vector<uint32_t> order((size_t)ns);
+            int64_t P = std::max<int64_t>(1, (int64_t)((double)ns * 0.6180339887498949));
+            auto gcd = [](int64_t a, int64_t b) { while (b) { int64_t t = a % b; a = b; b = t; } return a; };
+            while (gcd(P, ns) != 1) ++P;
+            for (int64_t j = 0; j < ns; ++j) order[(size_t)j] = (uint32_t)((j * P) % ns);
+            rc = up(&x->d_strip_order, order.data(), order.size() * 4);
+        }
+        if (!rc) {
+            x->img.st_ckpt = x->d_st_ckpt;
+            x->img.st_hdr = x->d_st_hdr;
+            x->img.st_poff = x->d_st_poff;
+            x->img.st_pbase = x->d_st_pbase;
+            x->img.st_delta = x->d_st_delta;
+            x->img.n_strips = (int32_t)soa.n_strips;
+            x->strand_bytes = soa.strand_bytes();
+        }
     }
     if (rc) {
         dpq_close(x);
@@ -1211,7 +1256,12 @@ int dpq_soa_array(const dpq_soa* soa, int which, const void** ptr, int64_t* n_by
         case 7: *ptr = s.mi_id.data(); *n_bytes = (int64_t)s.mi_id.size() * 4; break;
         case 8: *ptr = s.par.data(); *n_bytes = (int64_t)s.par.size(); break;
         case 9: *ptr = s.carry.data(); *n_bytes = (int64_t)s.carry.size(); break;
-        default: return fail(DPQ_ERR_ARG, "which must be 0..9");
+        case 10: *ptr = s.st_ckpt.data(); *n_bytes = (int64_t)s.st_ckpt.size() * 8; break;
+        case 11: *ptr = s.st_hdr.data(); *n_bytes = (int64_t)s.st_hdr.size() * 8; break;
+        case 12: *ptr = s.st_poff.data(); *n_bytes = (int64_t)s.st_poff.size() * 2; break;
+        case 13: *ptr = s.st_pbase.data(); *n_bytes = (int64_t)s.st_pbase.size() * 4; break;
+        case 14: *ptr = s.st_delta.data(); *n_bytes = (int64_t)s.st_delta.size(); break;
+        default: return fail(DPQ_ERR_ARG, "which must be 0..14");
     }
     return DPQ_OK;
     });
@@ -1546,6 +1596,12 @@ int dpq_close(dpq_index* x) {
         if (x->lane_stream[l]) hipStreamDestroy(x->lane_stream[l]);
         if (x->lane_ready[l]) hipEventDestroy(x->lane_ready[l]);
     }
+    hipFree(x->d_st_ckpt);
+    hipFree(x->d_st_hdr);
+    hipFree(x->d_st_poff);
+    hipFree(x->d_st_pbase);
+    hipFree(x->d_st_delta);
+    hipFree(x->d_strip_order);
     hipFree(x->d_nib);
     hipFree(x->d_par);
     hipFree(x->d_carry);

@@ -241,11 +241,48 @@ int transcode(const uint8_t* payload, int64_t n_bytes, int64_t n_codes, int M, i
         mi_ids.reserve((size_t)((o.node_hi - o.node_lo) / multi_index_stride + 1));
         mi_codes.reserve((size_t)((o.node_hi - o.node_lo) / multi_index_stride + 1) * M);
     }
+    // strand image (see dpq_format.h): filled strip by strip
+    const bool want_strands = multi_index_stride > 0 && M == 8;
+    constexpr int kPhases = kRunLen / kPhaseLen;
+    std::vector<uint8_t> strip_bytes;                      // changed bytes of the current strip, [lane][step][<= 8]
+    std::vector<uint8_t> strip_cnt;                        // their counts
+    if (want_strands) {
+        o.n_strips = (o.node_hi - o.node_lo + kStripNodes - 1) / kStripNodes;
+        o.st_ckpt.assign((size_t)o.n_strips * levels * 64, 0);
+        // padding nodes: depth 1, mask 0 (a copy of stack[0]); the kernel never reports them
+        o.st_hdr.assign((size_t)o.n_strips * (kRunLen / 4) * 64, 0x0100010001000100ull);
+        o.st_poff.assign((size_t)o.n_strips * kPhases * 64, 0);
+        o.st_pbase.assign((size_t)o.n_strips * kPhases + 1, 0);
+        strip_bytes.assign((size_t)kStripNodes * 8, 0);
+        strip_cnt.assign((size_t)kStripNodes, 0);
+    }
+    auto flush_strip = [&](int64_t strip) {  // phases of the strip: for every phase the lanes' bytes, lane after lane
+        for (int ph = 0; ph < kPhases; ++ph) {
+            o.st_pbase[(size_t)(strip * kPhases + ph)] = (uint32_t)(o.st_delta.size() / 16);
+            size_t used = 0;
+            for (int lane = 0; lane < 64; ++lane) {
+                o.st_poff[(size_t)((strip * kPhases + ph) * 64 + lane)] = (uint16_t)used;
+                for (int st = ph * kPhaseLen; st < (ph + 1) * kPhaseLen; ++st) {
+                    const size_t node = (size_t)lane * kRunLen + st;
+                    o.st_delta.insert(o.st_delta.end(), &strip_bytes[node * 8], &strip_bytes[node * 8] + strip_cnt[node]);
+                    used += strip_cnt[node];
+                }
+            }
+            o.st_delta.resize((o.st_delta.size() + 15) / 16 * 16, 0);
+        }
+        std::fill(strip_cnt.begin(), strip_cnt.end(), 0);
+    };
     DtcWalker w(payload, n_bytes, n_codes, M);
     NodeRec r;
     while (!w.done()) {
         const int64_t i = w.pos();
         if ((shard_count > 1 || prefix) && i >= o.node_hi) break;  // the rest was validated by the first pass / is not scanned
+        if (want_strands && i >= o.node_lo && i < o.node_hi && (i - o.node_lo) % kRunLen == 0) {
+            // a run starts: the ancestor stack as it stands, level-major and lane-interleaved
+            const int64_t l = i - o.node_lo, strip = l / kStripNodes;
+            const int lane = (int)((l % kStripNodes) / kRunLen);
+            for (int lv = 0; lv < levels; ++lv) memcpy(&o.st_ckpt[(size_t)((strip * levels + lv) * 64 + lane)], &stack[(size_t)lv * M], 8);
+        }
         if (i >= o.node_lo && i < o.node_hi && (i - o.node_lo) % S == 0) {
             const int64_t t = (i - o.node_lo) / S;
             memcpy(&o.seg_ckpt[(size_t)(t * levels * M)], stack.data(), (size_t)levels * M);
@@ -282,6 +319,16 @@ int transcode(const uint8_t* payload, int64_t n_bytes, int64_t n_codes, int M, i
             o.mask[(size_t)(l * mb)] = (uint8_t)(r.mask & 0xFF);
             if (mb == 2) o.mask[(size_t)(l * mb + 1)] = (uint8_t)(r.mask >> 8);
             o.delta.insert(o.delta.end(), r.deltas, r.deltas + r.n_diff);
+            if (want_strands) {
+                const int64_t strip = l / kStripNodes, in_strip = l % kStripNodes;
+                const int s_lane = (int)(in_strip / kRunLen), step = (int)(in_strip % kRunLen);
+                // (the root, depth 0, arrives with mask 0xFF and its 8 bytes: every position "changes")
+                uint16_t* h = reinterpret_cast<uint16_t*>(&o.st_hdr[(size_t)((strip * (kRunLen / 4) + step / 4) * 64 + s_lane)]);
+                h[step % 4] = (uint16_t)((r.mask & 0xFFu) | ((unsigned)r.depth << 8));
+                memcpy(&strip_bytes[(size_t)in_strip * 8], r.deltas, (size_t)r.n_diff);
+                strip_cnt[(size_t)in_strip] = (uint8_t)r.n_diff;
+                if (in_strip + 1 == kStripNodes || i + 1 == o.node_hi) flush_strip(strip);
+            }
             o.algorithmic_bytes += r.payload_end - r.payload_begin;
             if (i > 0) o.n_diffs += r.n_diff;
             if (r.depth > o.max_depth) o.max_depth = r.depth;
@@ -351,6 +398,14 @@ int transcode(const uint8_t* payload, int64_t n_bytes, int64_t n_codes, int M, i
     }
     o.seg_delta_off[(size_t)o.n_segments] = o.delta.size();
     o.delta.resize(o.delta.size() + 32, 0);  // lanes read up to 20 bytes past their first delta
+    if (want_strands) {
+        o.st_pbase[(size_t)o.n_strips * kPhases] = (uint32_t)(o.st_delta.size() / 16);
+        o.st_delta.resize(o.st_delta.size() + 48, 0);  // a lane reads 32 bytes from its offset
+        if (o.st_delta.size() / 16 > 0xffffffffull) {
+            if (err) *err = "strand image beyond 64 GB of changed bytes";
+            return DPQ_ERR_NOMEM;
+        }
+    }
     return DPQ_OK;
 }
 

@@ -15,6 +15,9 @@ namespace dpq {
 
 constexpr int kChunk = 64;  // nodes per wavefront step
 constexpr int kBootPairs = 4;  // classes of the threshold-bootstrap multi-index (sub-space pairs)
+constexpr int kRunLen = 64;                     // strand image: nodes a lane decodes one after the other
+constexpr int kStripNodes = 64 * kRunLen;       // nodes per strip (64 lanes)
+constexpr int kPhaseLen = 4;                    // steps whose changed bytes are staged in LDS together (at most 64 * 4 * 8 = 2 KB)
 // chunks per independently decodable segment: 128-node segments balance the scan's wavefronts better than 256
 // (0.431 vs 0.451 ms per 1000-query step at 1 M codes) for 0.56 B/node of checkpoints and offsets
 constexpr int kDefaultChunksPerSegment = 2;
@@ -91,6 +94,21 @@ struct SoA {
     // The scan reads a 16-byte table row per (sub-space, label): rows whose labels agree mod 16 share an LDS bank
     // quad, so values that often meet inside a 16-node read group are given different residues.
     std::vector<uint8_t> relabel;
+    // ---- strand image (M = 8; built with multi_index_stride > 0): the SAME nodes laid out for the stream kernel, in
+    // which a LANE decodes a run of kRunLen consecutive nodes one after the other -- the reference's own stack machine
+    // (h:2876-2905), 64 of them side by side -- instead of a wavefront resolving a 64-node chunk cooperatively.
+    // A strip = 64 runs = kStripNodes consecutive nodes of the shard; lane l of a strip owns nodes [l kRunLen, (l+1) kRunLen).
+    // Everything a wavefront reads per step is lane-interleaved (coalesced); the changed bytes come in PHASES of kPhaseLen
+    // steps: the bytes all 64 lanes need for those steps lie together (lane after lane) and are staged in LDS.
+    int64_t n_strips = 0;
+    std::vector<uint64_t> st_ckpt;   // [n_strips][levels][64]: the ancestor stack (one code per level) at a run's first node
+    std::vector<uint64_t> st_hdr;    // [n_strips][kRunLen / 4][64]: four 16-bit (mask | depth << 8) of the lane's next four nodes
+    std::vector<uint16_t> st_poff;   // [n_strips][kRunLen / kPhaseLen][64]: offset of the lane's bytes inside the phase
+    std::vector<uint32_t> st_pbase;  // [n_strips * phases + 1]: start of a phase in st_delta, in units of 16 bytes
+    std::vector<uint8_t> st_delta;   // the phases, each padded to 16 bytes; 16 bytes of tail padding
+    int64_t strand_bytes() const {
+        return (int64_t)(st_ckpt.size() * 8 + st_hdr.size() * 8 + st_poff.size() * 2 + st_pbase.size() * 4 + st_delta.size());
+    }
     int64_t nodes_per_segment() const { return (int64_t)kChunk * chunks_per_segment; }
     int64_t device_bytes() const {
         return (int64_t)(nib.size() + par.size() + carry.size() + mask.size() + delta.size() + seg_delta_off.size() * 8 +

@@ -4,6 +4,8 @@
 
 #include <cstdint>
 
+#include "dpq_format.h"  // layout constants of the images (kChunk, kRunLen, kStripNodes, kPhaseLen)
+
 namespace dpq {
 
 constexpr int kScanThreads = 1024;  // 16 wavefronts, one workgroup per CU (LDS-bound residency)
@@ -32,6 +34,13 @@ struct DeviceImage {
     const uint64_t* seg_delta_off = nullptr;  // [n_segments + 1]
     const uint8_t* seg_ckpt = nullptr;        // [n_segments][levels][M]
     const uint8_t* raw = nullptr;             // non-NULL: plain (uncompressed) index, codes[n][M], padded to whole segments
+    // strand image (dpq_format.h; NULL = not built): the same nodes, a lane per run of 64
+    const uint64_t* st_ckpt = nullptr;        // [n_strips][8][64]
+    const uint64_t* st_hdr = nullptr;         // [n_strips][16][64]
+    const uint16_t* st_poff = nullptr;        // [n_strips][16][64]
+    const uint32_t* st_pbase = nullptr;       // [n_strips * 16 + 1], units of 16 bytes
+    const uint8_t* st_delta = nullptr;
+    int32_t n_strips = 0;
     int64_t n_local = 0;                      // nodes in this shard
     int64_t n_codes_total = 0;                // N of the whole index (even-N id quirk)
     uint32_t id_base = 0;                     // global DFS position of local node 0
@@ -137,6 +146,8 @@ hipError_t launch_decode_segments(const DeviceImage& img, const uint32_t* seg_li
 // launch_quantise builds the level's filter tables of every query group (needs the level's thresholds in
 // thr_key); launch_scan must follow it on the same stream.
 hipError_t launch_stream(const ScanArgs& a, int n_slots, hipStream_t stream);
+// The same pass over the strand image (M = 8, img.st_* set): a.seg_list / a.n_seg_pass name STRIPS here.
+hipError_t launch_strand(const ScanArgs& a, int n_slots, hipStream_t stream);
 int stream_queries_per_pass(int M, int n_slots);  // 1, 2, 4 or 8 (M = 16: at most 4)
 hipError_t launch_quantise(const ScanArgs& a, int n_slot_groups, hipStream_t stream);
 hipError_t launch_scan(const ScanArgs& a, int n_slot_groups, int splits, hipStream_t stream);

@@ -1491,6 +1491,168 @@ __global__ __launch_bounds__(stream_threads<Q>(), M > 8 ? 4 : Q >= 4 ? DPQ_STREA
 }
 
 // ---------------------------------------------------------------------------
+// strand: the stream pass over the STRAND image (dpq_format.h; M = 8, shards with a bootstrap): Q = 1, 2, 4 queries per
+// pass like stream_kernel, but a LANE decodes a run of 64 consecutive nodes one after the other -- the reference's own
+// stack machine (h:2876-2905: code = stack[depth - 1] with the masked positions replaced; stack[depth] = code), 64 of
+// them side by side, the ancestor stacks in LDS ([level][lane]: conflict-free 8-byte rows) -- instead of a wavefront
+// resolving a 64-node chunk cooperatively.  Per 64 decoded nodes that is ~45 instructions of decode instead of ~270 (no
+// prefix scan over the masks, no pointer jumping over the LDS crossbar, no carry between chunks): the pass is bound by
+// the exact-table gathers in LDS instead of by instruction issue.
+// A wavefront takes a strip (4096 nodes) at a time: loads the 64 runs' checkpoints into its stack rows, then per group
+// of four steps one coalesced 8-byte header load (four 16-bit mask | depth << 8), one 2-byte offset, and the lane's
+// changed bytes of the group (<= 32: two 16-byte loads at ITS byte offset inside the group's bytes, which lie lane after
+// lane: the wavefront's loads touch a few hundred contiguous bytes), a group ahead.  They are parked in LDS as dword
+// ROWS [k][lane] -- lane l's k-th dword in bank l mod 32 whatever k, so the three dwords a node reads around its byte
+// pointer never conflict (an unaligned ds_read_b64 at the pointer, tried first, cost 40 % of the pass) -- funnel-shifted
+// to the pointer, scattered by the mask's byte-permute selectors (the decoder[256] of main:312-325, here a 2 KB LDS
+// table) and merged into the parent code with two v_perm.
+// Same distances, keys and candidate handling as stream_kernel.  grid = (workgroups, ceil(slots / Q)), block = 256.
+// ---------------------------------------------------------------------------
+constexpr int kStrandThreads = 256;
+constexpr int kStrandRows = kPhaseLen * 2 + 2;         // dword rows of a phase in LDS: a lane's <= 32 bytes + the overshoot of a 3-dword read
+constexpr int kStrandBuf = kStrandRows * 64 * 4;
+static_assert(kPhaseLen == 4 && kRunLen == 64, "headers come four to an 8-byte load; a phase is two 16-byte loads per lane at most");
+
+template <int Q>
+struct StrandLds {
+    static constexpr size_t kT = 0;                                        // [8][256][Q] f32
+    static constexpr size_t kDtab = kT + (size_t)Q * 8 * 256 * 4;          // [256] x 8 B selectors
+    static constexpr size_t kWave = kDtab + 256 * 8;                       // per wavefront: stack [8][64] x 8 B, then the phase buffer
+    static constexpr size_t kPerWave = 8 * 64 * 8 + kStrandBuf;
+    static constexpr size_t kBytes = kWave + (kStrandThreads / 64) * kPerWave;
+};
+
+template <int Q>
+__global__ __launch_bounds__(kStrandThreads, Q >= 4 ? 2 : 4) void strand_kernel(const ScanArgs a) {
+    constexpr int M = 8, TE = M * 256, LEVELS = 8, GROUPS = kRunLen / kPhaseLen;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* T = reinterpret_cast<float*>(smem + StrandLds<Q>::kT);
+    uint2* dtab = reinterpret_cast<uint2*>(smem + StrandLds<Q>::kDtab);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint2* stk = reinterpret_cast<uint2*>(smem + StrandLds<Q>::kWave + (size_t)wave * StrandLds<Q>::kPerWave);  // [level][lane]
+    uint32_t* drow = reinterpret_cast<uint32_t*>(stk + LEVELS * 64);  // [kStrandRows][64] dwords of the current group
+    const int slot0 = blockIdx.y * Q;
+    uint64_t thr[Q];
+    float quick[Q];
+    bool any = false;
+#pragma unroll
+    for (int j = 0; j < Q; ++j) {
+        const int slot = slot0 + j;
+        const int qq = a.slot_query ? (slot < a.n_queries ? a.slot_query[slot] : -1) : (slot < a.n_queries ? slot : -1);
+        any |= qq >= 0;
+        thr[j] = qq >= 0 ? a.thr_key[slot] : 0ull;
+        quick[j] = qq < 0 ? -INFINITY : thr[j] == ~0ull ? INFINITY : __uint_as_float((uint32_t)(thr[j] >> 32)) * (1.0f + 0x1p-19f);
+        const float* src = a.lut32 + (size_t)(qq >= 0 ? qq : 0) * TE;
+        for (int i = tid; i < TE; i += kStrandThreads) T[i * Q + j] = qq >= 0 ? src[i] : 0.0f;
+    }
+    if (!any) return;  // block-uniform
+    dtab[tid] = *reinterpret_cast<const uint2*>(g_dtab.e[tid]);
+    __syncthreads();
+
+    const int n_waves = (int)gridDim.x * (kStrandThreads / 64);
+    for (int entry = (int)blockIdx.x * (kStrandThreads / 64) + wave; entry < a.n_seg_pass; entry += n_waves) {
+        const int64_t sid = __builtin_amdgcn_readfirstlane(a.seg_list ? (int)a.seg_list[entry] : entry);
+        // the runs' ancestor stacks
+#pragma unroll
+        for (int lv = 0; lv < LEVELS; ++lv) {
+            const uint64_t c = a.img.st_ckpt[(sid * LEVELS + lv) * 64 + lane];
+            stk[lv * 64 + lane] = make_uint2((uint32_t)c, (uint32_t)(c >> 32));
+        }
+        const uint32_t* pbase = a.img.st_pbase + sid * GROUPS;
+        // group g's header, offset and changed bytes, fetched while group g - 1 is decoded
+        struct Group {
+            uint64_t hdr;
+            uint4 b0, b1;
+        };
+        auto fetch = [&](int g) {
+            Group r;
+            r.hdr = a.img.st_hdr[(sid * GROUPS + g) * 64 + lane];
+            const uint32_t off = a.img.st_poff[(sid * GROUPS + g) * 64 + lane];
+            const unsigned char* src = a.img.st_delta + (size_t)pbase[g] * 16 + off;  // byte address: unaligned 16-byte loads
+            __builtin_memcpy(&r.b0, src, 16);
+            __builtin_memcpy(&r.b1, src + 16, 16);
+            return r;
+        };
+        Group cur = fetch(0);
+        for (int g = 0; g < GROUPS; ++g) {
+            // stage the group's bytes (the previous group's reads of the buffer were issued before: LDS keeps a
+            // wavefront's operations in order)
+            __builtin_amdgcn_wave_barrier();
+            {
+                const uint32_t w[8] = {cur.b0.x, cur.b0.y, cur.b0.z, cur.b0.w, cur.b1.x, cur.b1.y, cur.b1.z, cur.b1.w};
+#pragma unroll
+                for (int k = 0; k < 8; ++k) drow[k * 64 + lane] = w[k];
+            }
+            __builtin_amdgcn_wave_barrier();
+            const uint64_t hdr = cur.hdr;
+            uint32_t ptr = 0;  // bytes of this lane's group consumed so far
+            if (g + 1 < GROUPS) cur = fetch(g + 1);
+#pragma unroll
+            for (int st = 0; st < kPhaseLen; ++st) {
+                const uint32_t hw = (uint32_t)(hdr >> (16 * st)) & 0xffffu;
+                const uint32_t mask = hw & 0xffu, depth = hw >> 8;
+                const uint2 parent = stk[(depth > 0 ? depth - 1 : 0) * 64 + lane];
+                const uint32_t* at = drow + (ptr >> 2) * 64 + lane;
+                const uint32_t w0 = at[0], w1 = at[64], w2 = at[128];
+                uint2 raw;
+                raw.x = __builtin_amdgcn_alignbyte(w1, w0, ptr & 3u);
+                raw.y = __builtin_amdgcn_alignbyte(w2, w1, ptr & 3u);
+                const uint2 sel = dtab[mask];
+                ptr += __popc(mask);
+                const uint32_t pv0 = __builtin_amdgcn_perm(raw.y, raw.x, sel.x), pv1 = __builtin_amdgcn_perm(raw.y, raw.x, sel.y);
+                uint32_t code[2];
+                code[0] = __builtin_amdgcn_perm(parent.x, pv0, own_sel(mask & 15u));
+                code[1] = __builtin_amdgcn_perm(parent.y, pv1, own_sel(mask >> 4));
+                stk[depth * 64 + lane] = make_uint2(code[0], code[1]);
+                // ADC against the queries' exact tables
+                float d32[Q];
+#pragma unroll
+                for (int j = 0; j < Q; ++j) d32[j] = 0.0f;
+#pragma unroll
+                for (int m = 0; m < M; ++m) {
+                    const float* row = T + (size_t)(m * 256 + ((code[m >> 2] >> (8 * (m & 3))) & 0xffu)) * Q;
+                    if constexpr (Q == 1) {
+                        d32[0] += row[0];
+                    } else if constexpr (Q == 2) {
+                        const float2 v = *reinterpret_cast<const float2*>(row);
+                        d32[0] += v.x, d32[1] += v.y;
+                    } else {
+                        const float4 v = *reinterpret_cast<const float4*>(row);
+                        d32[0] += v.x, d32[1] += v.y, d32[2] += v.z, d32[3] += v.w;
+                    }
+                }
+                const int64_t node = sid * kStripNodes + lane * kRunLen + g * kPhaseLen + st;
+                const bool valid = node < a.img.n_local;
+#pragma unroll
+                for (int j = 0; j < Q; ++j) {
+                    bool pass = valid && d32[j] <= quick[j];
+                    if (__ballot(pass) == 0) continue;  // wave-uniform
+                    uint64_t key = 0;
+                    if (pass) {  // the reference's distance (fp64 sum rounded once) and the whole (distance, id) key
+                        double dsum = 0.0;
+#pragma unroll
+                        for (int m = 0; m < M; ++m)
+                            dsum = __dadd_rn(dsum, (double)T[(size_t)(m * 256 + ((code[m >> 2] >> (8 * (m & 3))) & 0xffu)) * Q + j]);
+                        key = make_key((float)dsum, a.img.id_base + (uint32_t)node);
+                        pass = key <= thr[j];
+                    }
+                    const uint64_t found = __ballot(pass);
+                    if (found) {
+                        uint32_t* count = a.cand_count + (size_t)(slot0 + j) * kRegionStride + 1;
+                        uint64_t* region = a.cand_key + (size_t)(slot0 + j) * a.cand_stride + a.region_off;
+                        uint32_t base = 0;
+                        if (lane == 0) base = atomicAdd(count, (uint32_t)__popcll(found));
+                        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                        const uint32_t li = base + mbcnt64(found, 0);
+                        if (pass && li < (uint32_t)a.region_cap) region[li] = key;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // a6: select.  grid = slots, block = 512 (level 0) or 256 threads, dynamic LDS
 // ---------------------------------------------------------------------------
 
@@ -1856,7 +2018,7 @@ constexpr int kBootCells = 736;  // cells per round (their node prefix, clamped 
                                  // 736: the block stays at 40 912 B of LDS at cap = 3072, four blocks per CU
 constexpr int kBootCellsPerThread = 2;
 constexpr int kBootBatch = 6;    // nodes a thread has in flight: cap / threads at the default cap (every step of the chain is a global or LDS round trip)
-constexpr int kBootPairs = 4;    // multi-index classes = sub-space pairs (dpq_format.h)
+// kBootPairs (multi-index classes = sub-space pairs): dpq_format.h
 
 template <int M>
 // M = 8: four blocks per CU (40 KB of LDS each) = 8 wavefronts per SIMD: the register budget (SGPRs included:
@@ -2335,6 +2497,29 @@ hipError_t launch_stream(const ScanArgs& a, int n_slots, hipStream_t stream) {
         }
     }
     return hipErrorInvalidValue;
+}
+
+template <int Q>
+static hipError_t launch_strand_q(const ScanArgs& a, int n_slots, hipStream_t stream) {
+    const size_t lds = StrandLds<Q>::kBytes;
+    static std::atomic<bool> done[64] = {};
+    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&strand_kernel<Q>), lds, done);
+    if (e != hipSuccess) return e;
+    const int passes = (n_slots + Q - 1) / Q;
+    const int per_cu = std::max(1, std::min(8, (int)(160 * 1024 / lds)));
+    const int wgs = std::max(1, std::min(256 * per_cu / std::max(1, std::min(passes, 8)), (a.n_seg_pass + 3) / 4));
+    hipLaunchKernelGGL((strand_kernel<Q>), dim3((unsigned)wgs, (unsigned)passes), dim3(kStrandThreads), lds, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_strand(const ScanArgs& a, int n_slots, hipStream_t stream) {
+    if (a.n_seg_pass <= 0 || n_slots <= 0) return hipSuccess;
+    if (a.img.M != 8 || !a.img.st_ckpt) return hipErrorInvalidValue;
+    switch (stream_queries_per_pass(8, n_slots)) {
+        case 1: return launch_strand_q<1>(a, n_slots, stream);
+        case 2: return launch_strand_q<2>(a, n_slots, stream);
+        default: return launch_strand_q<4>(a, n_slots, stream);
+    }
 }
 
 hipError_t launch_quantise(const ScanArgs& a, int n_slot_groups, hipStream_t stream) {

@@ -131,6 +131,8 @@ typedef struct dpq_open_opts {
 #define DPQ_OPT_BOOT_FULLSORT 8u    /* bootstrap ranks all 256 centroids exactly  [DPQ_BOOT_FULLSORT=1] */
 #define DPQ_OPT_NO_TIGHTEN 16u      /* filter scans keep a level's thresholds as they were when it started instead of lowering
                                      * them as candidates accumulate  [DPQ_TIGHTEN=0] */
+#define DPQ_OPT_NO_STRANDS 32u      /* no second, lane-per-run layout of the index for batches of up to four queries (they then
+                                     * take the wavefront-per-chunk decode; saves ~1.2 x the payload in HBM)  [DPQ_STRANDS=0] */
 
 typedef struct dpq_info {
     int64_t n_codes_total;     /* N of the whole index (header field 0, h:1839-1840) */
@@ -204,7 +206,9 @@ int dpq_soa_build(const uint8_t* payload, int64_t n_bytes, int64_t n_codes, int 
 int dpq_soa_info(const dpq_soa* soa, dpq_info* info);
 /* Borrowed pointers into the image (valid until dpq_soa_free):
  * which = 0 depth nibbles, 1 masks, 2 deltas, 3 segment delta offsets (u64[n_seg+1]),
- * 4 segment ancestor checkpoints (u8[n_seg][levels][M]). */
+ * 4 segment ancestor checkpoints (u8[n_seg][levels][M]), 5-7 the bootstrap multi-index (cell starts, codes, ids),
+ * 8 parent lanes, 9 carry lanes, 10-14 the strand image of the stream pass (checkpoints u64[strips][8][64], headers
+ * u64[strips][16][64], phase offsets u16[strips][16][64], phase starts u32[strips*16+1] in 16-byte units, changed bytes). */
 int dpq_soa_array(const dpq_soa* soa, int which, const void** ptr, int64_t* n_bytes);
 void dpq_soa_free(dpq_soa* soa);
 /* Serialise a tree given as per-node arrays into the reference DTC payload

@@ -228,6 +228,53 @@ def test_bootstrap_multi_index_layout(lib, stride, shards, n):
     assert len(np.unique(np.concatenate(seen))) == sum(len(s) for s in seen)
 
 
+def decode_strands(soa, n_local):
+    """The strand image as strand_kernel reads it: per strip 64 lanes, each running the reference's stack machine
+    (h:2876-2905) over its 64 nodes -- header (mask | depth << 8) four to an 8-byte word, the changed bytes of a
+    four-step phase at st_pbase (16-byte units) + st_poff, ancestor stacks from st_ckpt [strip][level][lane]."""
+    n_strips = len(soa.st_ckpt) // (8 * 64)
+    out = np.zeros((n_strips * 4096, 8), dtype=np.uint8)
+    hdr = soa.st_hdr.view(np.uint16).reshape(n_strips, 16, 64, 4)
+    ck = soa.st_ckpt.view(np.uint8).reshape(n_strips, 8, 64, 8)
+    poff = soa.st_poff.reshape(n_strips, 16, 64)
+    for s in range(n_strips):
+        for lane in range(64):
+            stack = [ck[s, lv, lane].copy() for lv in range(8)]
+            for g in range(16):
+                ptr = int(soa.st_pbase[s * 16 + g]) * 16 + int(poff[s, g, lane])
+                for st in range(4):
+                    hw = int(hdr[s, g, lane, st])
+                    mask, depth = hw & 0xFF, hw >> 8
+                    code = stack[max(depth, 1) - 1].copy()
+                    for m in range(8):
+                        if mask >> m & 1:
+                            code[m] = soa.st_delta[ptr]
+                            ptr += 1
+                    stack[depth] = code
+                    out[s * 4096 + lane * 64 + g * 4 + st] = code
+                assert ptr <= int(soa.st_pbase[s * 16 + g + 1]) * 16                 # a lane stays inside its phase
+    return out[:n_local]
+
+
+@pytest.mark.parametrize("n,shards", [(1, 1), (2, 1), (4095, 1), (4096, 1), (4097, 1), (20000, 1), (30000, 3)])
+def test_strand_image_is_lossless(lib, n, shards):
+    """The stream pass's lane-per-run layout (built next to the multi-index, M = 8) decodes to the same codes as the
+    stream itself, on whole shards and on shards cut by payload bytes; a phase never exceeds 2 KB; padding nodes are
+    copies of stack level 0."""
+    from deltapq_amd import api, synth
+    tree, payload, nb = make_case(n, seed=n + 3)
+    codes = synth.decode_tree_codes(tree)
+    for r in range(shards):
+        soa = api.HostSoA(payload, n, 8, shard_rank=r, shard_count=shards, multi_index_stride=1)
+        lo, hi = soa.info["node_lo"], soa.info["node_hi"]
+        n_strips = -(-(hi - lo) // 4096)
+        assert len(soa.st_ckpt) == n_strips * 8 * 64 and len(soa.st_hdr) == n_strips * 16 * 64 and len(soa.st_pbase) == n_strips * 16 + 1
+        assert np.all(np.diff(soa.st_pbase.astype(np.int64)) * 16 <= 2048) and len(soa.st_delta) == int(soa.st_pbase[-1]) * 16 + 48
+        assert np.array_equal(decode_strands(soa, hi - lo), codes[lo:hi])
+    # without the multi-index (small shards, bootstrap off) there is no strand image
+    assert len(api.HostSoA(payload, n, 8).st_ckpt) == 0
+
+
 @pytest.mark.parametrize("n_scan", [1, 2, 63, 64, 65, 999, 1000, 2500, 2501])
 def test_prefix_transcode(lib, n_scan):
     """`-N` below the header's n_codes (h:2825-2829): the image holds the first n_scan nodes of the stream."""
