@@ -577,19 +577,30 @@ def main():
             "index": {"device_bytes_rank0": int(all_stats[0, 3]), "segments_rank0": info["n_segments"],
                       "codes_rank0": int(all_stats[0, 10]), "gen_seconds": wl["gen_s"]},
         }
-        stream_max = int(os.environ.get("DPQ_STREAM_MAX_QUERIES", "2"))
+        dev = os.environ.get("DPQ_DEV", "0") not in ("", "0")
+        stream_max = int(os.environ.get("DPQ_STREAM_MAX_QUERIES", "4")) if dev else 4   # the library's measured switch-over
         if nq <= stream_max:
-            # one or two queries: one query per pass over the compressed image (stream_kernel) -- the mode in which the
-            # path is bound by the decode and by HBM, not by the LDS array
+            # up to four queries: the stream pass -- 1, 2 or 4 queries per pass over the compressed image, every decoded node
+            # against the queries' exact tables in LDS -- the mode in which the path is bound by the decode and by HBM,
+            # not by the filter tables' LDS gathers
             r = result["roofline"]
-            alg = (nq * alg_bytes_total) / (scan_ms_step * 1e-3) / 1e9 if scan_ms_step > 0 else 0.0
-            r.update({"bound": "hbm", "kernel": "stream_kernel", "achieved": alg, "peak": HBM_PEAK_GBPS * world, "frac": alg / (HBM_PEAK_GBPS * world),
-                      "definition": "one query per pass: achieved = queries x DTC payload bytes (SURVEY.md 8(d): every pass streams the "
-                                    "compressed image once) / stream-kernel time (HIP events on the launch stream); peak = 8 TB/s HBM3E.  "
-                                    "`hbm` holds the physical bytes of the counters where a matching PMC summary is committed."})
+            per_pass = 1 if nq <= 1 else 2 if nq <= 2 else 4
+            passes = -(-nq // per_pass)
+            strands = args.m == 8 and info["bootstrap_bytes"] > 0 and not (dev and os.environ.get("DPQ_STRANDS", "1") == "0")
+            alg = (passes * alg_bytes_total) / (scan_ms_step * 1e-3) / 1e9 if scan_ms_step > 0 else 0.0
+            r.update({"bound": "hbm", "kernel": "strand_kernel" if strands else "stream_kernel", "achieved": alg, "peak": HBM_PEAK_GBPS * world,
+                      "frac": alg / (HBM_PEAK_GBPS * world),
+                      "definition": "stream pass, %d quer%s per pass, %d pass(es): achieved = passes x DTC payload bytes (SURVEY.md 8(d): every "
+                                    "pass streams the compressed index once) / kernel time of the pass's launches (HIP events on the launch "
+                                    "stream); peak = 8 TB/s HBM3E.  `hbm` holds the physical bytes of the counters where a matching PMC "
+                                    "summary is committed." % (per_pass, "y" if per_pass == 1 else "ies", passes),
+                      "queries_per_pass": per_pass, "passes": passes})
             r.pop("lds_gather_bytes_per_step", None)
-            result["config"]["decode"] = "inside the stream kernel, once per query (one query per pass)"
-            result["config"]["queries_per_decode_pass"] = 1
+            r["algorithmic_hbm"]["note"] = ("queries x DTC payload bytes / kernel time: with %d quer%s per pass this is %d x the bytes the "
+                                            "passes stream" % (per_pass, "y" if per_pass == 1 else "ies", per_pass))
+            result["config"]["decode"] = ("lane per run of 64 nodes over the strand image (strand_kernel)" if strands else
+                                          "wavefront per 64-node chunk (stream_kernel)") + ", once per pass of %d quer%s" % (per_pass, "y" if per_pass == 1 else "ies")
+            result["config"]["queries_per_decode_pass"] = per_pass
         if replicas:
             result["query_replicas"] = replicas
         if world == 1 and not args.no_cpu_baseline:
