@@ -349,6 +349,8 @@ int ensure_plan(dpq_index* x, int top_k, int cap, int coarse) {
         if (forced[0] >= 2) {
             for (int i = 0; i < 3; ++i)
                 if (forced[i] >= 2) ratios.push_back(forced[i]);
+        } else if (forced[0] == 1) {
+            // one level whatever the shard size (experiments)
         } else {
             for (int64_t b = nseg; b * S > ((int64_t)2 << 20); b /= 8) ratios.push_back(8);
             // A large top_k takes its first threshold from a worse quantile of the bootstrap sample (the 1000th of

@@ -45,7 +45,11 @@ if "FETCH_SIZE" in sc and "WRITE_SIZE" in sc:
     summary["scan_kernel_avg_launch_ms_under_pmc"] = sc.get("avg_ns_under_pmc_fetch", sc["stats"]["avg_ns"]) / 1e6
     summary["scan_kernel_avg_launch_ms_kernel_trace"] = sc["stats"]["avg_ns"] / 1e6
     summary["scan_kernel_hbm_GBps"] = summary["scan_kernel_hbm_bytes_per_launch"] / (summary["scan_kernel_avg_launch_ms_kernel_trace"] * 1e-3) / 1e9
-st = next((v for k, v in summary["kernels"].items() if k.startswith("dpq::stream_kernel")), {})
+# the stream pass: strand_kernel (lane per run, M = 8 with a bootstrap) or stream_kernel (wavefront per chunk)
+st = next((v for k, v in summary["kernels"].items() if k.startswith("dpq::strand_kernel")), None) or \
+     next((v for k, v in summary["kernels"].items() if k.startswith("dpq::stream_kernel")), {})
+summary["stream_pass_kernel"] = next((k for k in summary["kernels"] if k.startswith("dpq::strand_kernel")), None) or \
+                                next((k for k in summary["kernels"] if k.startswith("dpq::stream_kernel")), None)
 if "FETCH_SIZE" in st and "WRITE_SIZE" in st:   # one query per pass
     summary["stream_kernel_hbm_bytes_per_launch"] = 2 * st["FETCH_SIZE"]["mean_kib"] * 1024 + st["WRITE_SIZE"]["mean_kib"] * 1024
     summary["stream_kernel_avg_launch_ms_kernel_trace"] = st["stats"]["avg_ns"] / 1e6
