@@ -93,7 +93,8 @@ struct Tuning {
     int plan_ratios[3] = {0, 0, 0};
     int boot_cap = 0, boot_target = 0;
     int64_t batch_tile_nodes = (int64_t)16 << 20;
-    bool relabel = true, fuse_quantise = true, async_overlap = true, boot_fullsort = false, tighten = true, strands = true;
+    bool relabel = true, fuse_quantise = true, async_overlap = true, boot_fullsort = false, tighten = true, strands = true,
+         force_strands = false;
 };
 
 struct dpq_index {
@@ -226,6 +227,7 @@ Tuning resolve_tuning(const dpq_open_opts& o) {
     t.boot_fullsort = (o.flags & DPQ_OPT_BOOT_FULLSORT) != 0;
     t.tighten = !(o.flags & DPQ_OPT_NO_TIGHTEN);
     t.strands = !(o.flags & DPQ_OPT_NO_STRANDS);
+    t.force_strands = (o.flags & DPQ_OPT_FORCE_STRANDS) != 0;
     const char* dev = getenv("DPQ_DEV");
     if (dev && atoi(dev) != 0) {
         auto geti = [](const char* name, int* v) { if (const char* e = getenv(name)) *v = atoi(e); };
@@ -242,6 +244,7 @@ Tuning resolve_tuning(const dpq_open_opts& o) {
         v = 0; geti("DPQ_BOOT_FULLSORT", &v); t.boot_fullsort = t.boot_fullsort || v != 0;
         v = 1; geti("DPQ_TIGHTEN", &v); t.tighten = t.tighten && v != 0;
         v = 1; geti("DPQ_STRANDS", &v); t.strands = t.strands && v != 0;
+        t.force_strands = t.force_strands || v == 2;
     }
     return t;
 }
@@ -682,7 +685,15 @@ int run_batch(dpq_index* x, const float* d_queries, int nq, int top_k, int32_t* 
                 se.n_regions = 2;
                 DPQ_HIP(hipMemset2DAsync(x->d_cand_count + 1, sizeof(uint32_t) * dpq::kRegionStride, 0, sizeof(uint32_t),
                                          (size_t)nq, stream));
-                if (x->img.st_ckpt) {
+                // Which stream pass: the strand image (a lane per run of 64 nodes) has 64 x fewer, 64 x longer work items than
+                // the chunk-per-wavefront decode, so it wants a big shard.  Measured, us per call (strand / chunk), one query:
+                // 1 M codes 36 / 40 pipelined but 89 / 56 as a single synchronous call, 4 M 56 / 53, 12.5 M 73 / 98, 32 M
+                // 113 / 173, 125 M 353 / 613; four queries per pass (8 wavefronts per CU): 4 M 81 / 63, 12.5 M 116 / 121,
+                // 32 M 254 / 234, 125 M 708 / 832.
+                const int per_pass = dpq::stream_queries_per_pass(x->M, nq);
+                const bool strands = x->img.st_ckpt != nullptr &&
+                                     (x->tune.force_strands || x->img.n_local >= (per_pass <= 2 ? (int64_t)8 << 20 : (int64_t)64 << 20));
+                if (strands) {
                     // the pass over the strand image: the level's share of the strips (every strip exactly once over
                     // the levels, like the segments; the bootstrap consumed none)
                     const int64_t nseg = x->img.n_segments, ns = x->img.n_strips;

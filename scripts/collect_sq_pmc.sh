@@ -18,18 +18,19 @@ for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SA
   i=$((i+1))
   timeout -k 10 300 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $OUT/p$i -- python bench.py --steps 3 --warmup 1 --reps 1 --no-cpu-baseline --check 0 "$@" > /dev/null 2> $OUT/p$i.err || echo "pass $i failed" >> $OUT/failed.txt
 done
-python - "$OUT" <<'PY'
+python - "$OUT" "${KERNEL:-scan_kernel}" <<'PY'
 import collections, csv, glob, json, sys
-out = sys.argv[1]
+out, kernel = sys.argv[1], sys.argv[2]
 agg = collections.defaultdict(list)
 dur = []
 for f in glob.glob(out + "/p*/*/*_counter_collection.csv"):
     for r in csv.DictReader(open(f)):
-        if "scan_kernel" in r["Kernel_Name"]:
+        if kernel in r["Kernel_Name"]:
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
             if "Start_Timestamp" in r:
                 dur.append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
 res = {k: {"dispatches": len(v), "mean": sum(v) / len(v), "max": max(v)} for k, v in agg.items()}
+res["_kernel"] = kernel
 res["_scan_kernel_mean_ns_under_pmc"] = sum(dur) / max(1, len(dur))
 json.dump(res, open(out + "/sq_summary.json", "w"), indent=1)
 for k, v in sorted(res.items()):

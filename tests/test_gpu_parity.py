@@ -621,10 +621,17 @@ def test_one_query_per_pass_matches_the_batched_path(gpu, oracle, n, M, k):
     qs = synth.make_queries(70, 128, seed=n + 6)
     cuts = [(0, 1), (5, 7), (10, 13), (20, 24), (30, 35), (40, 48), (50, 59)]
     for kw in ({}, {"shard_rank": 1, "shard_count": 2}):
-        with gpu.DeltaPQIndex.open_memory(payload, n, M, 256, stream_max_queries=8, **kw) as idx:
+        # flags = 64: DPQ_OPT_FORCE_STRANDS, the lane-per-run stream pass (strand_kernel) on shards far below the size from
+        # which it is the default (M = 8 shards with a bootstrap have the image; the others run stream_kernel)
+        with gpu.DeltaPQIndex.open_memory(payload, n, M, 256, stream_max_queries=8, flags=64, **kw) as idx:
             idx.set_codebook(cb)
             ids_b, d_b = idx.query_batch(qs, k)                # 70 queries: filter path
             got = [idx.query_batch(qs[lo:hi], k) for lo, hi in cuts]
+        with gpu.DeltaPQIndex.open_memory(payload, n, M, 256, stream_max_queries=8, **kw) as idx:   # stream_kernel at these sizes
+            idx.set_codebook(cb)
+            for (lo, hi), (ids_s, d_s) in zip(cuts[:4], got[:4]):
+                ids_c, d_c = idx.query_batch(qs[lo:hi], k)
+                assert np.array_equal(ids_c, ids_s) and np.array_equal(d_c.view(np.uint32), d_s.view(np.uint32)), (lo, hi, kw)
             idx.profile_enable(1)
             idx.profile_reset()
             idx.query_batch(qs[20:24], k)
