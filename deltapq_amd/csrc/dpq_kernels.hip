@@ -646,9 +646,6 @@ __global__ __launch_bounds__(256) void quantise_kernel(const ScanArgs a) {
 
 // Read window of the scan's ADC gathers at M = 8 (ds_read_b128 in flight before the first pair is summed; 0 = leave
 // the order to the compiler).  See scan_kernel.
-#ifndef DPQ_TIGHT_DBG
-#define DPQ_TIGHT_DBG 0
-#endif
 #ifndef DPQ_TIGHT_SLEEP
 #define DPQ_TIGHT_SLEEP 32  // s_sleep units of 64 cycles between two looks of the helper wavefront
 #endif
@@ -859,7 +856,7 @@ __global__ __launch_bounds__(kScanThreads, (PLAIN && !STAMPS && M <= 8) ? 5 : 4)
                         const int steps = min((int)(((float)C::QT - u) * (1.0f / C::XU) - 2e-3f), C::XMAX);
                         // counted in LDS (a global atomic here sits in the wavefront's in-order memory queue in front of the
                         // next round's table gathers); wave 0 moves the counts to the global histograms
-                        if (steps >= 1 && !(DPQ_TIGHT_DBG & 1)) atomicAdd(&s_hist[ls[e] * (kTightBuckets / 2) + (steps >> 1)], 1u << (16 * (steps & 1)));
+                        if (steps >= 1) atomicAdd(&s_hist[ls[e] * (kTightBuckets / 2) + (steps >> 1)], 1u << (16 * (steps & 1)));
                     }
                 }
             }
@@ -935,8 +932,8 @@ __global__ __launch_bounds__(kScanThreads, (PLAIN && !STAMPS && M <= 8) ? 5 : 4)
                 c += cnt[e];
                 if (best == 0 && c >= (uint32_t)a.tight_k) best = e;
             }
-            if (best > my_steps && !(DPQ_TIGHT_DBG & 2)) {
-                raise = (DPQ_TIGHT_DBG & 8) ? 0u : (uint32_t)((best - my_steps) * C::XU);
+            if (best > my_steps) {
+                raise = (uint32_t)((best - my_steps) * C::XU);
                 my_steps = best;
                 // the cut in distance terms: nodes counted under >= best steps have d <= t2 (see refine)
                 const double t2 = ((double)s_bdn[ls] + (double)(C::QT - best * C::XU) / (double)s_scale[ls]) / (1.0 + 0x1p-20);
@@ -1523,7 +1520,7 @@ struct StrandLds {
 };
 
 template <int Q>
-__global__ __launch_bounds__(kStrandThreads, Q >= 4 ? 2 : 4) void strand_kernel(const ScanArgs a) {
+__global__ __launch_bounds__(kStrandThreads, Q >= 4 ? 2 : Q == 2 ? 3 : 4) void strand_kernel(const ScanArgs a) {
     constexpr int M = 8, TE = M * 256, LEVELS = 8, GROUPS = kRunLen / kPhaseLen;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* T = reinterpret_cast<float*>(smem + StrandLds<Q>::kT);
@@ -1587,6 +1584,10 @@ __global__ __launch_bounds__(kStrandThreads, Q >= 4 ? 2 : 4) void strand_kernel(
             const uint64_t hdr = cur.hdr;
             uint32_t ptr = 0;  // bytes of this lane's group consumed so far
             if (g + 1 < GROUPS) cur = fetch(g + 1);
+            // The group's four steps in two sweeps: decode + exact-table sums first, straight-line (a step's gathers run
+            // under the next step's decode: a branch after every step kept them apart), then what may pass.
+            uint32_t codes[kPhaseLen][2];
+            float d32[kPhaseLen][Q];
 #pragma unroll
             for (int st = 0; st < kPhaseLen; ++st) {
                 const uint32_t hw = (uint32_t)(hdr >> (16 * st)) & 0xffffu;
@@ -1600,32 +1601,36 @@ __global__ __launch_bounds__(kStrandThreads, Q >= 4 ? 2 : 4) void strand_kernel(
                 const uint2 sel = dtab[mask];
                 ptr += __popc(mask);
                 const uint32_t pv0 = __builtin_amdgcn_perm(raw.y, raw.x, sel.x), pv1 = __builtin_amdgcn_perm(raw.y, raw.x, sel.y);
-                uint32_t code[2];
+                uint32_t* code = codes[st];
                 code[0] = __builtin_amdgcn_perm(parent.x, pv0, own_sel(mask & 15u));
                 code[1] = __builtin_amdgcn_perm(parent.y, pv1, own_sel(mask >> 4));
                 stk[depth * 64 + lane] = make_uint2(code[0], code[1]);
                 // ADC against the queries' exact tables
-                float d32[Q];
 #pragma unroll
-                for (int j = 0; j < Q; ++j) d32[j] = 0.0f;
+                for (int j = 0; j < Q; ++j) d32[st][j] = 0.0f;
 #pragma unroll
                 for (int m = 0; m < M; ++m) {
                     const float* row = T + (size_t)(m * 256 + ((code[m >> 2] >> (8 * (m & 3))) & 0xffu)) * Q;
                     if constexpr (Q == 1) {
-                        d32[0] += row[0];
+                        d32[st][0] += row[0];
                     } else if constexpr (Q == 2) {
                         const float2 v = *reinterpret_cast<const float2*>(row);
-                        d32[0] += v.x, d32[1] += v.y;
+                        d32[st][0] += v.x, d32[st][1] += v.y;
                     } else {
                         const float4 v = *reinterpret_cast<const float4*>(row);
-                        d32[0] += v.x, d32[1] += v.y, d32[2] += v.z, d32[3] += v.w;
+                        d32[st][0] += v.x, d32[st][1] += v.y, d32[st][2] += v.z, d32[st][3] += v.w;
                     }
                 }
+            }
+            asm volatile("" ::: "memory");  // the rare exact sums below re-read their entries (else all 32 stay in registers)
+#pragma unroll
+            for (int st = 0; st < kPhaseLen; ++st) {
+                const uint32_t* code = codes[st];
                 const int64_t node = sid * kStripNodes + lane * kRunLen + g * kPhaseLen + st;
                 const bool valid = node < a.img.n_local;
 #pragma unroll
                 for (int j = 0; j < Q; ++j) {
-                    bool pass = valid && d32[j] <= quick[j];
+                    bool pass = valid && d32[st][j] <= quick[j];
                     if (__ballot(pass) == 0) continue;  // wave-uniform
                     uint64_t key = 0;
                     if (pass) {  // the reference's distance (fp64 sum rounded once) and the whole (distance, id) key

@@ -649,6 +649,36 @@ def test_one_query_per_pass_matches_the_batched_path(gpu, oracle, n, M, k):
             assert_parity(ids_p, d_p, oracle_topk(oracle, payload, n, cb, qs[pick], k), n)
 
 
+@pytest.mark.parametrize("n,M,k,dup", [(300_000, 8, 100, False), (300_000, 8, 10, True), (150_000, 16, 50, False)])
+def test_in_scan_tightening_changes_nothing_but_the_work(gpu, oracle, n, M, k, dup):
+    """dpq_open_opts.flags & DPQ_OPT_NO_TIGHTEN (16): a one-level filter scan that keeps the bootstrap's thresholds and
+    one that lowers them from the candidates found so far (scan_kernel's helper wavefront) return the
+    same lists bit for bit -- every tightened threshold is an upper bound of the final k-th key -- while the tightened
+    scan checks fewer pairs and keeps fewer candidates.  Also on a duplicate-heavy index (thousands of equal keys at the
+    cut) and at M = 16 (the cut lives in the 16-bit accumulators' start values)."""
+    from deltapq_amd import synth
+    cb = synth.make_codebook(M, 256, 128 // M, seed=5)
+    tree = synth.synth_tree(n, M, seed=n + M, mean_diffs=(0.4 if dup else 3.0) if M == 8 else 5.0)
+    payload, _ = synth.encode_dtc(tree)
+    qs = synth.make_queries(640, 128, seed=n + 1)
+    res = {}
+    for flags in (0, 16):
+        with gpu.DeltaPQIndex.open_memory(payload, n, M, 256, flags=flags) as idx:
+            idx.set_codebook(cb)
+            idx.profile_enable(1)
+            idx.profile_reset()
+            ids, d = idx.query_batch(qs, k)
+            res[flags] = (ids, d, idx.profile_read())
+    assert np.array_equal(res[0][0], res[16][0]) and np.array_equal(res[0][1].view(np.uint32), res[16][1].view(np.uint32))
+    on, off = res[0][2], res[16][2]
+    assert on["scan_node_query_pairs"] == off["scan_node_query_pairs"]          # every pair is still visited
+    assert on["candidates"] <= off["candidates"] and on["exact_checks"] <= off["exact_checks"]
+    if not dup:
+        assert on["candidates"] < 0.9 * off["candidates"]                       # it really tightened
+    sample = [0, 63, 64, 300, 639]
+    assert_parity(res[0][0][sample], res[0][1][sample], oracle_topk(oracle, payload, n, cb, qs[sample], k), n)
+
+
 def test_codebook_can_be_set_again_between_scratch_batches(gpu, oracle, codebook):
     """dpq_set_codebook after batches that used the plain-code scratch and the relabelled tables (it once freed them):
     the same index answers for a second codebook and again for the first."""
