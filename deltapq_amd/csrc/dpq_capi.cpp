@@ -687,12 +687,10 @@ int run_batch(dpq_index* x, const float* d_queries, int nq, int top_k, int32_t* 
                                          (size_t)nq, stream));
                 // Which stream pass: the strand image (a lane per run of 64 nodes) has 64 x fewer, 64 x longer work items than
                 // the chunk-per-wavefront decode, so it wants a big shard.  Measured, us per call (strand / chunk), one query:
-                // 1 M codes 36 / 40 pipelined but 89 / 56 as a single synchronous call, 4 M 56 / 53, 12.5 M 73 / 98, 32 M
-                // 113 / 173, 125 M 353 / 613; four queries per pass (8 wavefronts per CU): 4 M 81 / 63, 12.5 M 116 / 121,
-                // 32 M 254 / 234, 125 M 708 / 832.
-                const int per_pass = dpq::stream_queries_per_pass(x->M, nq);
-                const bool strands = x->img.st_ckpt != nullptr &&
-                                     (x->tune.force_strands || x->img.n_local >= (per_pass <= 2 ? (int64_t)8 << 20 : (int64_t)64 << 20));
+                // 1 M codes 35 / 37 pipelined but 89 / 59 as a single synchronous call, 4 M 50 / 49, 12.5 M 72 / 97, 32 M
+                // 113 / 172, 125 M 343 / 619; four queries per pass: 1 M 55 / 47, 4 M 76 / 61, 12.5 M 103 / 121, 32 M
+                // 195 / 230, 125 M 609 / 841.  From 8 M codes.
+                const bool strands = x->img.st_ckpt != nullptr && (x->tune.force_strands || x->img.n_local >= ((int64_t)8 << 20));
                 if (strands) {
                     // the pass over the strand image: the level's share of the strips (every strip exactly once over
                     // the levels, like the segments; the bootstrap consumed none)

@@ -133,8 +133,8 @@ typedef struct dpq_open_opts {
                                      * them as candidates accumulate  [DPQ_TIGHTEN=0] */
 #define DPQ_OPT_NO_STRANDS 32u      /* no second, lane-per-run layout of the index for batches of up to four queries (they then
                                      * take the wavefront-per-chunk decode; saves ~1.2 x the payload in HBM)  [DPQ_STRANDS=0] */
-#define DPQ_OPT_FORCE_STRANDS 64u   /* that layout for every small batch, whatever the shard size (by default from 8 M codes for one
-                                     * or two queries per pass, 64 M for four): tests, experiments  [DPQ_STRANDS=2] */
+#define DPQ_OPT_FORCE_STRANDS 64u   /* that layout for every small batch, whatever the shard size (by default from 8 M codes per
+                                     * GPU): tests, experiments  [DPQ_STRANDS=2] */
 
 typedef struct dpq_info {
     int64_t n_codes_total;     /* N of the whole index (header field 0, h:1839-1840) */
