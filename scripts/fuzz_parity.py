@@ -18,7 +18,9 @@ while time.time() < t_end:
         n = int(rng.integers(60000, 400000))  # bootstrap shards
     cps = int(rng.choice([1, 2, 4, 4, 8, 16, 64]))
     k = int(min(n, rng.choice([1, 2, 10, 100, 100, 1000, 2048])))
-    nq = int(rng.choice([1, 2, 31, 32, 33, 70, 129, 200]))
+    nq = int(rng.choice([1, 2, 3, 4, 5, 8, 31, 32, 33, 70, 129, 200, 500, 700]))  # 1-4 (8 with stream_max 8): stream pass; >= 450: in-scan tightening
+    flags = int(rng.choice([0, 0, 16, 64, 64]))   # DPQ_OPT_NO_TIGHTEN, DPQ_OPT_FORCE_STRANDS
+    smax = int(rng.choice([0, 0, 8, -1]))
     bd = int(rng.choice([-1, 0, 0, 1, 1, 2, 5, 37, 300]))  # dpq_open_opts.batch_decode (>= 2: scratch tiles of that many segments)
     cap = int(rng.choice([0, 0, 0, 64, 300]))
     shards = int(rng.choice([1, 1, 1, 2, 5]))
@@ -31,19 +33,22 @@ while time.time() < t_end:
     tree["root"] = (tree["root"].astype(np.int64) % K).astype(np.uint8)
     payload, nb = synth.encode_dtc(tree)
     qs = synth.make_queries(nq, 128, seed + 2)
-    desc = "M=%d n=%d cps=%d k=%d nq=%d cap=%d shards=%d K=%d md=%.1f seed=%d batch_decode=%d" % (M, n, cps, k, nq, cap, shards, K, md, seed, bd)
+    desc = "M=%d n=%d cps=%d k=%d nq=%d cap=%d shards=%d K=%d md=%.1f seed=%d batch_decode=%d flags=%d stream_max=%d" % (
+        M, n, cps, k, nq, cap, shards, K, md, seed, bd, flags, smax)
     try:
         parts = []
         for r in range(shards):
             with api.DeltaPQIndex.open_memory(payload, n, M, K, chunks_per_segment=cps, cand_capacity=cap,
-                                              shard_rank=r, shard_count=shards, batch_decode=bd) as idx:
+                                              shard_rank=r, shard_count=shards, batch_decode=bd, flags=flags,
+                                              stream_max_queries=smax) as idx:
                 idx.set_codebook(cb)
                 parts.append(idx.query_batch(qs, k))
         if shards > 1:
             ids, dists = api.merge_topk_host(np.stack([p[0] for p in parts]), np.stack([p[1] for p in parts]))
         else:
             ids, dists = parts[0]
-        for i in range(nq):
+        check = range(nq) if nq <= 40 else sorted(set(range(12)) | set(int(v) for v in rng.integers(0, nq, 24)))
+        for i in check:
             lut = orc.build_lut(cb, qs[i])
             oi, od, alld, _ = orc.scan_lut(payload, n, lut, k, want_all=True)
             ok, msg = O.tie_aware_equal(ids[i], dists[i], oi, od, alld, n)
