@@ -4,7 +4,7 @@ set -o pipefail
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 OUT=gpurun_out/timeline
 rm -rf $OUT && mkdir -p $OUT
-timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/trace -- python bench.py --data stream --steps 12 --warmup 3 --reps 2 --no-cpu-baseline --check 0 $BENCH_ARGS > $OUT/bench.json 2> $OUT/err.txt || { tail -5 $OUT/err.txt; exit 1; }
+timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/trace -- python bench.py --steps 12 --warmup 3 --reps 2 --no-cpu-baseline --check 0 --sustain-seconds 0 --host-steps 0 $BENCH_ARGS > $OUT/bench.json 2> $OUT/err.txt || { tail -5 $OUT/err.txt; exit 1; }
 python - <<PY
 import csv, glob
 f = glob.glob("$OUT/trace/*/*_kernel_trace.csv")[0]

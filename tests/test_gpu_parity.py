@@ -1132,3 +1132,26 @@ def test_prefix_scan_minus_N_below_n_codes(gpu, oracle, codebook, n_scan):
     parts = [run(gpu, payload, n, codebook, qs, k, num_codes=n_scan, shard_rank=r, shard_count=2)[:2] for r in range(2)]
     mi, md = gpu.merge_topk_host(np.stack([p[0] for p in parts]), np.stack([p[1] for p in parts]))
     assert_parity(mi, md, ref, n_scan)
+
+
+@pytest.mark.parametrize("n_scan", [70_001, 123_458, 200_000])
+def test_stream_pass_on_a_prefix_and_on_a_part_of_a_larger_index(gpu, oracle, codebook, n_scan):
+    """The strand image (forced: flags = 64) built for a prefix scan (`-N` below n_codes: odd, even -> the trailing id rule)
+    and for a part of a larger index (global positions), on a whole shard and on shard 1 of 3: one-, two- and four-query
+    calls against the same queries inside a 70-query batch (filter path), and against the oracle."""
+    from deltapq_amd import synth
+    n, k = 200_000, 20
+    tree, payload, _ = make_case(n, seed=301)
+    qs = synth.make_queries(70, 128, seed=302)
+    for kw in (dict(num_codes=n_scan), dict(num_codes=n_scan, shard_rank=1, shard_count=3),
+               dict(global_offset=1_000_000_000 - n if n_scan == n else 12_345_678, global_n_codes=1_000_000_000)):
+        if "global_offset" in kw and n_scan != n and n_scan != 70_001:
+            continue
+        with gpu.DeltaPQIndex.open_memory(payload, n, 8, 256, flags=64, bootstrap=1, **kw) as idx:
+            idx.set_codebook(codebook)
+            ids_b, d_b = idx.query_batch(qs, k)
+            for lo, hi in ((0, 1), (3, 5), (10, 14)):
+                ids_s, d_s = idx.query_batch(qs[lo:hi], k)
+                assert np.array_equal(ids_s, ids_b[lo:hi]) and np.array_equal(d_s.view(np.uint32), d_b[lo:hi].view(np.uint32)), (kw, lo)
+        if kw == dict(num_codes=n_scan) and n_scan % 2 == 1:
+            assert_parity(ids_b[:4], d_b[:4], oracle_topk(oracle, payload, n_scan, codebook, qs[:4], k), n_scan)
