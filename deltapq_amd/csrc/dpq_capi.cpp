@@ -110,6 +110,8 @@ struct dpq_index {
     uint64_t *d_st_ckpt = nullptr, *d_st_hdr = nullptr;
     uint16_t* d_st_poff = nullptr;
     uint32_t *d_st_pbase = nullptr, *d_strip_order = nullptr;
+    uint32_t* d_strip_segs = nullptr;      // the segments of the strips, in strip visiting order (a level too small for the
+    std::vector<int64_t> strip_seg_off;    // strand pass runs the chunk-per-wavefront pass over ITS strips' segments)
     uint8_t* d_st_delta = nullptr;
     int64_t strand_bytes = 0;
     uint8_t *d_nib = nullptr, *d_par = nullptr, *d_carry = nullptr, *d_mask = nullptr, *d_delta = nullptr, *d_ckpt = nullptr,
@@ -698,10 +700,19 @@ int run_batch(dpq_index* x, const float* d_queries, int nq, int top_k, int32_t* 
                     const int64_t lo = (int64_t)x->level_off[l] * ns / nseg;
                     const int64_t hi = final_pass ? ns : ((int64_t)x->level_off[l] + x->level_cnt[l]) * ns / nseg;
                     dpq::ScanArgs st = sa;
-                    st.seg_list = x->d_strip_order + lo;
-                    st.n_seg_pass = (int32_t)(hi - lo);
                     Timer t(x, stream, 1);
-                    DPQ_HIP(dpq::launch_strand(st, nq, stream));
+                    // A level of few strips (one strip per wavefront: the launch takes a strip's 64 dependent steps
+                    // however few there are) goes through the chunk-per-wavefront pass over the same nodes: measured
+                    // break-even at about 1500 strips (6 M nodes).
+                    if (hi - lo < 1536 && x->d_strip_segs && !x->tune.force_strands) {
+                        st.seg_list = x->d_strip_segs + x->strip_seg_off[(size_t)lo];
+                        st.n_seg_pass = (int32_t)(x->strip_seg_off[(size_t)hi] - x->strip_seg_off[(size_t)lo]);
+                        DPQ_HIP(dpq::launch_stream(st, nq, stream));
+                    } else {
+                        st.seg_list = x->d_strip_order + lo;
+                        st.n_seg_pass = (int32_t)(hi - lo);
+                        DPQ_HIP(dpq::launch_strand(st, nq, stream));
+                    }
                 } else {
                     Timer t(x, stream, 1);
                     DPQ_HIP(dpq::launch_stream(sa, nq, stream));
@@ -967,6 +978,17 @@ int open_from_payload(const uint8_t* payload, int64_t n_bytes, int64_t n_codes, 
             while (gcd(P, ns) != 1) ++P;
             for (int64_t j = 0; j < ns; ++j) order[(size_t)j] = (uint32_t)((j * P) % ns);
             rc = up(&x->d_strip_order, order.data(), order.size() * 4);
+            const int64_t S = soa.nodes_per_segment();
+            if (!rc && dpq::kStripNodes % S == 0) {
+                std::vector<uint32_t> segs;
+                x->strip_seg_off.assign((size_t)ns + 1, 0);
+                for (int64_t j = 0; j < ns; ++j) {
+                    const int64_t s0 = (int64_t)order[(size_t)j] * (dpq::kStripNodes / S);
+                    for (int64_t t = s0; t < std::min(s0 + dpq::kStripNodes / S, soa.n_segments); ++t) segs.push_back((uint32_t)t);
+                    x->strip_seg_off[(size_t)j + 1] = (int64_t)segs.size();
+                }
+                rc = up(&x->d_strip_segs, segs.data(), segs.size() * 4);
+            }
         }
         if (!rc) {
             x->img.st_ckpt = x->d_st_ckpt;
@@ -1613,6 +1635,7 @@ int dpq_close(dpq_index* x) {
     hipFree(x->d_st_pbase);
     hipFree(x->d_st_delta);
     hipFree(x->d_strip_order);
+    hipFree(x->d_strip_segs);
     hipFree(x->d_nib);
     hipFree(x->d_par);
     hipFree(x->d_carry);

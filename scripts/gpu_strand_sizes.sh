@@ -2,7 +2,7 @@
 export DPQ_DEV=1
 # where the strand image starts to pay: one and four queries per call on shards of growing size, both stream passes
 mkdir -p gpurun_out
-for n in 1000000 4000000 12500000 32000000; do for q in 1 4; do for st in 2 0; do
+for n in 12500000 32000000 125000000; do for q in 1 4; do for st in 1 2; do
 DPQ_STRANDS=$st timeout -k 10 400 python bench.py --codes $n --data stream --queries $q --steps 20 --warmup 3 --reps 3 --check 1 --no-cpu-baseline --sustain-seconds 0 --host-steps 0 > gpurun_out/sz.json 2>gpurun_out/sz.err || { tail -3 gpurun_out/sz.err; continue; }
 python - <<PY
 import json

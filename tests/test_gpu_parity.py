@@ -437,6 +437,14 @@ def test_large_shard_config3_per_gpu_share(gpu, oracle, codebook):
     for r in range(nq):
         assert len(set(ids[r].tolist())) == k and ids[r].min() >= 0 and ids[r].max() <= n
     assert prof["scan_node_query_pairs"] == info["n_segments"] * S * nq
+    # calls of one, two and four queries on this shard size take the stream pass as the library routes it by default: the
+    # small first level through the chunk-per-wavefront pass over its strips' segments, the big one through the strand
+    # pass -- same lists as inside the 64-query batch, bit for bit
+    with gpu.DeltaPQIndex.open_memory(payload, n, 8, 256) as idx:
+        idx.set_codebook(codebook)
+        for lo_q, hi_q in ((0, 1), (20, 22), (40, 44)):
+            ids_s, d_s = idx.query_batch(qs[lo_q:hi_q], k)
+            assert np.array_equal(ids_s, ids[lo_q:hi_q]) and np.array_equal(d_s.view(np.uint32), dists[lo_q:hi_q].view(np.uint32)), lo_q
     # the same index as shard 5 of 8 (what one rank of the 8-GPU run holds)
     ids5, dists5, _, info5 = run(gpu, payload, n, codebook, qs[:8], k, shard_rank=5, shard_count=8)
     lut = oracle.build_lut(codebook, qs[3])
