@@ -966,7 +966,8 @@ int open_from_payload(const uint8_t* payload, int64_t n_bytes, int64_t n_codes, 
     if (!rc && x->boot && x->tune.strands && soa.n_strips > 0 && soa.n_strips < INT32_MAX) {
         rc = up(&x->d_st_ckpt, soa.st_ckpt.data(), soa.st_ckpt.size() * 8);
         if (!rc) rc = up(&x->d_st_hdr, soa.st_hdr.data(), soa.st_hdr.size() * 8);
-        if (!rc) rc = up(&x->d_st_poff, soa.st_poff.data(), soa.st_poff.size() * 2);
+        // (st_poff stays on the host: the kernel computes a lane's offset inside a phase as a wave prefix sum of the lanes'
+        // byte counts; the array exists for the CPU-side checks of the image)
         if (!rc) rc = up(&x->d_st_pbase, soa.st_pbase.data(), soa.st_pbase.size() * 4);
         if (!rc) rc = up(&x->d_st_delta, soa.st_delta.data(), soa.st_delta.size());
         if (!rc) {
@@ -993,7 +994,6 @@ int open_from_payload(const uint8_t* payload, int64_t n_bytes, int64_t n_codes, 
         if (!rc) {
             x->img.st_ckpt = x->d_st_ckpt;
             x->img.st_hdr = x->d_st_hdr;
-            x->img.st_poff = x->d_st_poff;
             x->img.st_pbase = x->d_st_pbase;
             x->img.st_delta = x->d_st_delta;
             x->img.n_strips = (int32_t)soa.n_strips;

@@ -1505,9 +1505,13 @@ __global__ __launch_bounds__(stream_threads<Q>(), M > 8 ? 4 : Q >= 4 ? DPQ_STREA
 // table) and merged into the parent code with two v_perm.
 // Same distances, keys and candidate handling as stream_kernel.  grid = (workgroups, ceil(slots / Q)), block = 256.
 // ---------------------------------------------------------------------------
+#ifndef DPQ_ADC_SPLIT
+#define DPQ_ADC_SPLIT 4  // sub-spaces summed before a lane looks at its bound (one query per pass)
+#endif
 constexpr int kStrandThreads = 256;
 constexpr int kStrandRows = kPhaseLen * 2 + 2;         // dword rows of a phase in LDS: a lane's <= 32 bytes + the overshoot of a 3-dword read
 constexpr int kStrandBuf = kStrandRows * 64 * 4;
+constexpr int kStrandLevels = 8;
 static_assert(kPhaseLen == 4 && kRunLen == 64, "headers come four to an 8-byte load; a phase is two 16-byte loads per lane at most");
 
 template <int Q>
@@ -1515,7 +1519,11 @@ struct StrandLds {
     static constexpr size_t kT = 0;                                        // [8][256][Q] f32
     static constexpr size_t kDtab = kT + (size_t)Q * 8 * 256 * 4;          // [256] x 8 B selectors
     static constexpr size_t kWave = kDtab + 256 * 8;                       // per wavefront: stack [8][64] x 8 B, then the phase buffer
-    static constexpr size_t kPerWave = 8 * 64 * 8 + kStrandBuf;
+    // 6.5 KB per wavefront: four blocks = 16 wavefronts per CU at Q = 1.  Squeezed to 5.5 KB (seven stack levels, eight rows
+    // with wrap-around reads: exactly 32 KB per block, five blocks per CU) the big level of a 125 M-code call took 337 us
+    // instead of 239 -- and 262 with the fifth block kept out by padding; three blocks (padding): 288, two: 352.  Sixteen
+    // wavefronts per CU is the optimum.
+    static constexpr size_t kPerWave = kStrandLevels * 64 * 8 + kStrandBuf;
     static constexpr size_t kBytes = kWave + (kStrandThreads / 64) * kPerWave;
 };
 
@@ -1527,10 +1535,10 @@ __global__ __launch_bounds__(kStrandThreads, Q >= 4 ? 2 : Q == 2 ? 3 : 4) void s
     uint2* dtab = reinterpret_cast<uint2*>(smem + StrandLds<Q>::kDtab);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     uint2* stk = reinterpret_cast<uint2*>(smem + StrandLds<Q>::kWave + (size_t)wave * StrandLds<Q>::kPerWave);  // [level][lane]
-    uint32_t* drow = reinterpret_cast<uint32_t*>(stk + LEVELS * 64);  // [kStrandRows][64] dwords of the current group
+    uint32_t* drow = reinterpret_cast<uint32_t*>(stk + kStrandLevels * 64);  // [kStrandRows][64] dwords of the current group
     const int slot0 = blockIdx.y * Q;
     uint64_t thr[Q];
-    float quick[Q];
+    float quick[Q], rest_min[Q][M];  // rest_min: minima of the sub-spaces' tables (wave-uniform)
     bool any = false;
 #pragma unroll
     for (int j = 0; j < Q; ++j) {
@@ -1539,6 +1547,8 @@ __global__ __launch_bounds__(kStrandThreads, Q >= 4 ? 2 : Q == 2 ? 3 : 4) void s
         any |= qq >= 0;
         thr[j] = qq >= 0 ? a.thr_key[slot] : 0ull;
         quick[j] = qq < 0 ? -INFINITY : thr[j] == ~0ull ? INFINITY : __uint_as_float((uint32_t)(thr[j] >> 32)) * (1.0f + 0x1p-19f);
+#pragma unroll
+        for (int m = 0; m < M; ++m) rest_min[j][m] = qq >= 0 ? lut_min_of(a.lut_min, (size_t)qq, M, m) : 0.0f;
         const float* src = a.lut32 + (size_t)(qq >= 0 ? qq : 0) * TE;
         for (int i = tid; i < TE; i += kStrandThreads) T[i * Q + j] = qq >= 0 ? src[i] : 0.0f;
     }
@@ -1551,26 +1561,32 @@ __global__ __launch_bounds__(kStrandThreads, Q >= 4 ? 2 : Q == 2 ? 3 : 4) void s
         const int64_t sid = __builtin_amdgcn_readfirstlane(a.seg_list ? (int)a.seg_list[entry] : entry);
         // the runs' ancestor stacks
 #pragma unroll
-        for (int lv = 0; lv < LEVELS; ++lv) {
+        for (int lv = 0; lv < kStrandLevels; ++lv) {
             const uint64_t c = a.img.st_ckpt[(sid * LEVELS + lv) * 64 + lane];
             stk[lv * 64 + lane] = make_uint2((uint32_t)c, (uint32_t)(c >> 32));
         }
         const uint32_t* pbase = a.img.st_pbase + sid * GROUPS;
-        // group g's header, offset and changed bytes, fetched while group g - 1 is decoded
-        struct Group {
-            uint64_t hdr;
+        // Two-deep prefetch: group g + 2's header word and group g + 1's changed bytes are fetched while group g is decoded.
+        // Where a lane's bytes start inside a group's bytes (which lie lane after lane) is the wave prefix sum of the
+        // lanes' byte counts, i.e. of the popcounts of the header's four masks: computed (bit planes + v_mbcnt), not
+        // loaded -- a loaded offset put two dependent HBM round trips into every group.
+        auto load_hdr = [&](int g) -> uint64_t { return g < GROUPS ? a.img.st_hdr[(sid * GROUPS + g) * 64 + lane] : 0ull; };
+        struct Bytes {
             uint4 b0, b1;
         };
-        auto fetch = [&](int g) {
-            Group r;
-            r.hdr = a.img.st_hdr[(sid * GROUPS + g) * 64 + lane];
-            const uint32_t off = a.img.st_poff[(sid * GROUPS + g) * 64 + lane];
+        auto load_bytes = [&](int g, uint64_t h) {
+            Bytes r;
+            const uint32_t mine = (uint32_t)__popcll(h & 0x00ff00ff00ff00ffull);  // <= 32
+            uint32_t off = 0;
+#pragma unroll
+            for (int bit = 5; bit >= 0; --bit) off = mbcnt64(__ballot((mine >> bit) & 1u), off << 1);
             const unsigned char* src = a.img.st_delta + (size_t)pbase[g] * 16 + off;  // byte address: unaligned 16-byte loads
             __builtin_memcpy(&r.b0, src, 16);
             __builtin_memcpy(&r.b1, src + 16, 16);
             return r;
         };
-        Group cur = fetch(0);
+        uint64_t hdr = load_hdr(0), hdr_next = load_hdr(1);
+        Bytes cur = load_bytes(0, hdr);
         for (int g = 0; g < GROUPS; ++g) {
             // stage the group's bytes (the previous group's reads of the buffer were issued before: LDS keeps a
             // wavefront's operations in order)
@@ -1581,13 +1597,14 @@ __global__ __launch_bounds__(kStrandThreads, Q >= 4 ? 2 : Q == 2 ? 3 : 4) void s
                 for (int k = 0; k < 8; ++k) drow[k * 64 + lane] = w[k];
             }
             __builtin_amdgcn_wave_barrier();
-            const uint64_t hdr = cur.hdr;
+            const uint64_t hdr_after = load_hdr(g + 2);
+            if (g + 1 < GROUPS) cur = load_bytes(g + 1, hdr_next);
             uint32_t ptr = 0;  // bytes of this lane's group consumed so far
-            if (g + 1 < GROUPS) cur = fetch(g + 1);
             // The group's four steps in two sweeps: decode + exact-table sums first, straight-line (a step's gathers run
             // under the next step's decode: a branch after every step kept them apart), then what may pass.
             uint32_t codes[kPhaseLen][2];
             float d32[kPhaseLen][Q];
+            constexpr int H = Q == 1 ? DPQ_ADC_SPLIT : M;  // several queries: a lane is rarely out of every race -- all at once
 #pragma unroll
             for (int st = 0; st < kPhaseLen; ++st) {
                 const uint32_t hw = (uint32_t)(hdr >> (16 * st)) & 0xffffu;
@@ -1605,20 +1622,45 @@ __global__ __launch_bounds__(kStrandThreads, Q >= 4 ? 2 : Q == 2 ? 3 : 4) void s
                 code[0] = __builtin_amdgcn_perm(parent.x, pv0, own_sel(mask & 15u));
                 code[1] = __builtin_amdgcn_perm(parent.y, pv1, own_sel(mask >> 4));
                 stk[depth * 64 + lane] = make_uint2(code[0], code[1]);
-                // ADC against the queries' exact tables
+                // ADC against the queries' exact tables, in two halves: after sub-spaces 0..3 a lane whose partial sum plus
+                // the minima of the other four tables already exceeds every query's bound is done (fp32 addition is
+                // monotone: the same chain with the real entries cannot come out lower) -- the second half's gathers run
+                // under the execution mask of the lanes still in the race, and a gather of a few lanes has no bank
+                // conflicts to replay (on random codes the 32-lane gathers of all lanes cost 3.5 x their two cycles: half
+                // of this kernel's LDS time).
+                float p[Q];
 #pragma unroll
-                for (int j = 0; j < Q; ++j) d32[st][j] = 0.0f;
-#pragma unroll
-                for (int m = 0; m < M; ++m) {
+                for (int j = 0; j < Q; ++j) p[j] = 0.0f;
+                auto gather = [&](int m) {
                     const float* row = T + (size_t)(m * 256 + ((code[m >> 2] >> (8 * (m & 3))) & 0xffu)) * Q;
                     if constexpr (Q == 1) {
-                        d32[st][0] += row[0];
+                        p[0] += row[0];
                     } else if constexpr (Q == 2) {
                         const float2 v = *reinterpret_cast<const float2*>(row);
-                        d32[st][0] += v.x, d32[st][1] += v.y;
+                        p[0] += v.x, p[1] += v.y;
                     } else {
                         const float4 v = *reinterpret_cast<const float4*>(row);
-                        d32[st][0] += v.x, d32[st][1] += v.y, d32[st][2] += v.z, d32[st][3] += v.w;
+                        p[0] += v.x, p[1] += v.y, p[2] += v.z, p[3] += v.w;
+                    }
+                };
+#pragma unroll
+                for (int m = 0; m < H; ++m) gather(m);
+                bool may = H == M;
+                if constexpr (H < M) {
+                    float b = p[0];
+#pragma unroll
+                    for (int m = H; m < M; ++m) b += rest_min[0][m];
+                    may = b <= quick[0];
+                }
+#pragma unroll
+                for (int j = 0; j < Q; ++j) d32[st][j] = H == M ? p[j] : INFINITY;
+                if constexpr (H < M) {
+                    // (one look per step: a single look per group of four, summing the rest for all four nodes of a lane
+                    // that has any in the race, was measured slower: 258 against 239 us on the big level)
+                    if (may) {
+#pragma unroll
+                        for (int m = H; m < M; ++m) gather(m);
+                        d32[st][0] = p[0];
                     }
                 }
             }
@@ -1653,6 +1695,8 @@ __global__ __launch_bounds__(kStrandThreads, Q >= 4 ? 2 : Q == 2 ? 3 : 4) void s
                     }
                 }
             }
+            hdr = hdr_next;
+            hdr_next = hdr_after;
         }
     }
 }
