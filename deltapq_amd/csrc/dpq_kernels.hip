@@ -30,10 +30,16 @@
 //                           checked exactly (the reference's distance, whole (distance, id)
 //                           keys) against the query's threshold key; what passes is a candidate
 //                           key in the workgroup's own region of the query's buffer (no global
-//                           atomics).
-//   stream_kernel           a5 + a6 for batches of one or two queries (the reference's own call shape): one query
-//                           per pass over the compressed image, every decoded node against the query's exact
-//                           table in LDS -- the mode bound by the decode and HBM instead of the LDS array.
+//                           atomics).  On one-level plans the LAST wavefront of a workgroup is a
+//                           helper that lowers the slots' thresholds from the candidates the query
+//                           group's workgroups have found so far (in-scan tightening).
+//   stream_kernel           a5 + a6 for batches of up to four queries (the reference's own call shape and its
+//                           neighbours): 1, 2 or 4 queries per pass over the compressed image, every decoded node
+//                           against the queries' exact tables in LDS (no filter tables); a wavefront per chunk.
+//   strand_kernel           the same pass over the STRAND image (M = 8, big shards): a LANE decodes a run of 64
+//                           consecutive nodes with the reference's own stack machine (h:2888-2905), 64 of them
+//                           side by side, ancestor stacks in LDS -- ~70 instructions per 64 nodes instead of ~300;
+//                           bound by the exact-table gathers in LDS, 24 % of the HBM peak in payload bytes.
 //   decode_segments_kernel  the same decode, writing plain codes (small shards: cascade level 0
 //                           is a query-independent spread sample).
 //   select_kernel           the rest of a6: candidate regions gathered; k-th smallest
