@@ -337,8 +337,10 @@ int auto_cap(int top_k) { return std::max(4096, 32 * top_k); }
 // are filter scans; expected survivors of level l = top_k * (bound[l]/bound[l-1] - 1).
 // Small batches (coarse == 1) are bound by the fixed cost per level (a launch + a select), not by survivor
 // handling, so they use steps of 16 and end up with three levels instead of five.
-int ensure_plan(dpq_index* x, int top_k, int cap, int coarse) {
-    if (x->plan_top_k == top_k && x->plan_cap == cap && x->plan_coarse == coarse) return DPQ_OK;
+int ensure_plan(dpq_index* x, int top_k, int cap, int shape) {
+    if (x->plan_top_k == top_k && x->plan_cap == cap && x->plan_coarse == shape) return DPQ_OK;
+    const int coarse = shape & 1;
+    const bool tight = (shape & 2) != 0;  // the scan tightens its thresholds as it goes (run_batch)
     const int64_t S = (int64_t)dpq::kChunk * x->img.chunks_per_segment;
     const int64_t nseg = x->img.n_segments;
     const int64_t s0 = std::min<int64_t>(nseg, std::max<int64_t>(1, dpq::kLevel0Nodes / S));
@@ -362,7 +364,9 @@ int ensure_plan(dpq_index* x, int top_k, int cap, int coarse) {
             // 8 K nodes): two short levels in front tighten it before the bulk of the index is filtered.  Measured
             // on 1 M codes (scripts/gpu_sweep_plans.sh): top-1000 1.40 M q/s with 3,3 against 0.95 M with one level
             // (M = 16: 0.79 M against 0.40 M); top-300 and below are fastest with one level.
-            if (top_k > 512 && ratios.size() < 2) ratios = {3, 3};
+            // With in-scan tightening the scan does that itself and one level wins again: top-1000 2.27 M q/s
+            // against 1.89 M with 3,3 (M = 16: 1.27 M against 1.21 M), top-2048 1.19 M against 0.97 M.
+            if (top_k > 512 && ratios.size() < 2 && !(tight && ratios.empty())) ratios = {3, 3};
         }
         int64_t b = nseg;
         for (int r : ratios) {
@@ -430,7 +434,7 @@ int ensure_plan(dpq_index* x, int top_k, int cap, int coarse) {
     }
     x->plan_top_k = top_k;
     x->plan_cap = cap;
-    x->plan_coarse = coarse;
+    x->plan_coarse = shape;
     return DPQ_OK;
 }
 
@@ -525,7 +529,11 @@ int run_batch(dpq_index* x, const float* d_queries, int nq, int top_k, int32_t* 
     const int ngroups = nqp / QG;
     const int cap = x->cap_auto ? auto_cap(top_k) : std::max(x->cap, top_k);
     int rc;
-    if ((rc = ensure_plan(x, top_k, cap, nq <= x->tune.coarse_below ? 1 : 0))) return rc;
+    // In-scan tightening is live when the scan runs its plain-code instantiation with at most kTightSplits
+    // workgroups per query group (8 groups or more): the plan then keeps one filter level also for a large top_k.
+    const bool tight_plan = x->tune.tighten && nq > x->tune.stream_max &&
+                            ngroups * dpq::kTightSplits >= dpq::kMaxSplits && (x->plain || use_batch_decode(x, ngroups));
+    if ((rc = ensure_plan(x, top_k, cap, (nq <= x->tune.coarse_below ? 1 : 0) | (tight_plan ? 2 : 0)))) return rc;
     int64_t stride = top_k;
     for (size_t l = 1; l < x->level_cnt.size(); ++l)
         stride = std::max(stride, regions_for(x, x->level_cnt[l], ngroups, top_k, cap).stride);
@@ -590,8 +598,8 @@ int run_batch(dpq_index* x, const float* d_queries, int nq, int top_k, int32_t* 
     // Measured (1 M codes x 1000 queries): top-100 +2 % queries/s (exact checks 3002 -> 1813 and candidates 802 -> 404 per
     // query, select 21 -> 16 us); top-1000 -2 % at M = 8 and -7 % at M = 16: there the plan's two short levels in front
     // already do the tightening, and the helper wavefront and the counting only cost.  So: plans of one level after a
-    // bootstrap, i.e. top_k <= 256 (ensure_plan).
-    sa.tight_hist = x->tune.tighten && top_k <= 256 ? x->d_overflow + x->ws_slots : nullptr;
+    // bootstrap, i.e. top_k <= 512 (ensure_plan; top-300: 3.69 -> see DESIGN.md 5.2c).
+    sa.tight_hist = x->tune.tighten && (top_k <= 512 || x->level_cnt.size() <= 2) ? x->d_overflow + x->ws_slots : nullptr;
     sa.tight_k = top_k;
 
     dpq::SelectArgs se{};
