@@ -650,8 +650,10 @@ int run_batch(dpq_index* x, const float* d_queries, int nq, int top_k, int32_t* 
             // M = 16 (a class sees 2 of 16 sub-spaces: weaker cells; a check costs 16 gathers): 3072 / 6144 / 8192 ->
             // 3003 / 1373 / 1021 candidates, 1.77 / 1.99 / 2.00 M q/s (scripts/gpu_m16_boot.sh).  top_k > 256
             // (scripts/gpu_boot_cap1000.sh, top-1000): 8192 / 12288 / 16384 -> M = 8 1.81 / 1.83 / 1.81, M = 16
-            // 1.05 / 1.10 / 1.00 M q/s.
-            const int cap_auto = top_k <= 256 ? (x->M <= 8 ? 3072 : 6144) : 12288;
+            // 1.05 / 1.10 / 1.00 M q/s.  Round 3, one level + in-scan tightening (scripts/gpu_boot_cap_large_k.sh),
+            // 4096 / 6144 / 8192 / 12288: top-512 3.11 / 3.27 / 3.25 / 3.16, top-1000 1.76 / 1.96 / 2.10 / 2.28,
+            // top-2048 0.74 / 0.97 / 1.06 / 1.20, M = 16 top-1000 1.04 / 1.17 / 1.22 / 1.27 M q/s.
+            const int cap_auto = top_k <= 256 ? (x->M <= 8 ? 3072 : 6144) : (top_k <= 640 && x->M <= 8) ? 6144 : 12288;
             ba.cap = std::max(std::min(cap_env > 0 ? cap_env : cap_auto, 16384), std::max(top_k, 2048));
             ba.cap = (ba.cap + 63) / 64 * 64;
             const int target_env = x->tune.boot_target;

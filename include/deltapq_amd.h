@@ -117,8 +117,8 @@ typedef struct dpq_open_opts {
                                  * threshold bootstrap; 0 = 128  [DPQ_COARSE_BELOW] */
     int32_t plan_ratios[3];     /* force the size ratios between consecutive filter levels (each >= 2); 0 = automatic
                                  *   [DPQ_PLAN_RATIOS=a,b,c] */
-    int32_t boot_cap;           /* nodes a bootstrap block may hold (2048..16384); 0 = 3072 / 6144 (M = 16) / 12288
-                                 * (top_k > 256)  [DPQ_BOOT_CAP] */
+    int32_t boot_cap;           /* nodes a bootstrap block may hold (2048..16384); 0 = 3072 / 6144 (M = 16) up to
+                                 * top-256, then 12288 (M = 8 up to top-640: 6144)  [DPQ_BOOT_CAP] */
     int32_t boot_target;        /* nodes after which the bootstrap stops walking cells; 0 = boot_cap  [DPQ_BOOT_TARGET] */
     int32_t flags;              /* DPQ_OPT_* bits below */
     int64_t batch_tile_nodes;   /* nodes per tile of the per-batch plain-code scratch; 0 = 16 M  [DPQ_BATCH_TILE_NODES] */
