@@ -40,6 +40,7 @@ with api.DeltaPQIndex.open_memory(payload, n, M, 256) as idx:
         idx.query_batch_torch(qd, k)
     torch.cuda.synchronize()
     p = idx.profile_read()
+    if os.environ.get("DPQ_PROGRESS"): print("product batches done", p, flush=True)
     idx.profile_enable(0)
     idx.query_batch_torch(qd, k)   # the launch the timings below repeat: as the product runs it, without statistics
     torch.cuda.synchronize()
@@ -52,6 +53,7 @@ with api.DeltaPQIndex.open_memory(payload, n, M, 256) as idx:
         rc = lib.dpq_debug_scan_time(idx._h, nq, mode, 20, 0, ms)
         assert rc == 0, lib.dpq_last_error()
         res[name] = ms.value
+        if os.environ.get("DPQ_PROGRESS"): print("mode", name, ms.value, flush=True)
     outs = [(torch.empty((nq, k), dtype=torch.int32, device="cuda"), torch.empty((nq, k), dtype=torch.float32, device="cuda")) for _ in range(2)]
     best = 1e9
     for rep in range(4):
