@@ -1850,6 +1850,11 @@ __device__ __forceinline__ int32_t report_id(uint32_t pos, int64_t n_total) {
     return (int32_t)pos;
 }
 
+#ifndef DPQ_RANK_BY_COUNT_MAX
+// winners up to which the final order comes from counting smaller winners instead of a sort (kk broadcast reads per winner:
+// it was the rule up to 2 x THREADS winners; top-300 3.91 -> 4.33 M q/s, top-512 3.20 -> 3.40 M with the sort from 257 on)
+#define DPQ_RANK_BY_COUNT_MAX 256
+#endif
 // THREADS: 512 for level 0 (3840 nodes to evaluate), 256 for the later levels (about a thousand keys: fewer
 // wavefronts per barrier, 16-19 us instead of 19-21)
 template <int M, int THREADS>
@@ -2019,7 +2024,7 @@ __global__ __launch_bounds__(THREADS) void select_kernel(const SelectArgs a) {
         return;
     }
 
-    if (kk <= 2 * THREADS) {
+    if (kk <= DPQ_RANK_BY_COUNT_MAX) {
         // few winners: a winner's output rank = the number of smaller winners (keys are unique); kk LDS
         // broadcast reads per thread and no barrier, against the 28+ barriers of a bitonic network
         for (int i = tid; i < kk; i += THREADS) {
@@ -2628,8 +2633,16 @@ static hipError_t launch_select_m(const SelectArgs& a, int n_slots, hipStream_t 
 hipError_t launch_select(const SelectArgs& a, int M, int n_slots, hipStream_t stream) {
     if (n_slots <= 0) return hipSuccess;
     const bool level0 = a.shared_id != nullptr;
-    if (M == 8) return level0 ? launch_select_m<8, 512>(a, n_slots, stream) : launch_select_m<8, 256>(a, n_slots, stream);
-    if (M == 16) return level0 ? launch_select_m<16, 512>(a, n_slots, stream) : launch_select_m<16, 256>(a, n_slots, stream);
+    // block size: 256 threads for the thousand keys of a top-100 level; beyond top-512 a slot brings thousands of keys
+    // and a 1024- or 2048-key final sort: 512 threads (the blocks per CU are set by the keys' LDS either way).  Measured
+    // (scripts/gpu_select_threads.sh; M q/s at 256 / 512 / 1024 threads): top-300 4.33 / 4.07 / 3.64, top-512 3.40 / 3.24 /
+    // 3.07, top-1000 2.28 / 2.32 / 2.10, M = 16 top-1000 1.27 / 1.32 / 1.23, top-2048 1.20 / 1.30 / 1.20.
+    static const int dev_threads = getenv("DPQ_DEV") && getenv("DPQ_SELECT_THREADS") ? atoi(getenv("DPQ_SELECT_THREADS")) : 0;
+    const int threads = dev_threads > 0 ? dev_threads : level0 ? 512 : a.top_k > 512 ? 512 : 256;
+    if (M == 8) return threads >= 1024 ? launch_select_m<8, 1024>(a, n_slots, stream)
+                     : threads >= 512 ? launch_select_m<8, 512>(a, n_slots, stream) : launch_select_m<8, 256>(a, n_slots, stream);
+    if (M == 16) return threads >= 1024 ? launch_select_m<16, 1024>(a, n_slots, stream)
+                      : threads >= 512 ? launch_select_m<16, 512>(a, n_slots, stream) : launch_select_m<16, 256>(a, n_slots, stream);
     return hipErrorInvalidValue;
 }
 
