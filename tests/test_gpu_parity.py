@@ -687,6 +687,34 @@ def test_in_scan_tightening_changes_nothing_but_the_work(gpu, oracle, n, M, k, d
     assert_parity(res[0][0][sample], res[0][1][sample], oracle_topk(oracle, payload, n, cb, qs[sample], k), n)
 
 
+@pytest.mark.parametrize("M,k", [(8, 1000), (16, 1000), (8, 300)])
+def test_large_topk_takes_one_level_when_the_scan_tightens(gpu, oracle, M, k):
+    """top_k > 512: with the in-scan tightening the plan keeps ONE filter level (ensure_plan); without it
+    (DPQ_OPT_NO_TIGHTEN) two short levels go in front.  Both answer bit for bit the same, and as the oracle.  The final
+    order of more than 256 winners comes from the bitonic network (select_kernel: 512-thread blocks beyond top-512)."""
+    from deltapq_amd import synth
+    n = 200_000
+    cb = synth.make_codebook(M, 256, 128 // M, seed=15)
+    tree = synth.synth_tree(n, M, seed=k + M, mean_diffs=3.0 if M == 8 else 5.0)
+    payload, _ = synth.encode_dtc(tree)
+    qs = synth.make_queries(640, 128, seed=k + 1)
+    res = {}
+    for flags in (0, 16):
+        with gpu.DeltaPQIndex.open_memory(payload, n, M, 256, flags=flags) as idx:
+            idx.set_codebook(cb)
+            idx.profile_enable(1)
+            idx.profile_reset()
+            ids, d = idx.query_batch(qs, k)
+            res[flags] = (ids, d, idx.profile_read())
+    assert np.array_equal(res[0][0], res[16][0]) and np.array_equal(res[0][1].view(np.uint32), res[16][1].view(np.uint32))
+    on, off = res[0][2], res[16][2]
+    assert on["overflow_reruns"] == 0 and off["overflow_reruns"] == 0
+    assert on["scan_launches"] == 1 and off["scan_launches"] == (3 if k > 512 else 1)
+    assert on["scan_node_query_pairs"] == off["scan_node_query_pairs"]          # every pair is visited either way
+    sample = [0, 63, 64, 639]
+    assert_parity(res[0][0][sample], res[0][1][sample], oracle_topk(oracle, payload, n, cb, qs[sample], k), n)
+
+
 def test_codebook_can_be_set_again_between_scratch_batches(gpu, oracle, codebook):
     """dpq_set_codebook after batches that used the plain-code scratch and the relabelled tables (it once freed them):
     the same index answers for a second codebook and again for the first."""
