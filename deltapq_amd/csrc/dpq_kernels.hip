@@ -808,8 +808,12 @@ __global__ __launch_bounds__(kScanThreads, (PLAIN && !STAMPS && M <= 8) ? 5 : 4)
     const size_t region0 = (size_t)a.region_off + (size_t)split * a.region_cap;  // this workgroup's region in a slot's buffer
     auto bit_slot = [](int p) { return (p >> 5) * (C::J * F) + ((p & 31) / EB) * C::J + (p % EB); };  // bit -> local slot
     // survivor bits a lane checks per round (their table gathers, M each from L2, are in flight together); 3, 4 and 6
-    // per round measured the same step time as 2
-    constexpr int RB = 2;
+    // per round measured the same step time as 2 at top-100, and 3 / 4 the same or worse at top-1000 (M = 16: 0.755 /
+    // 0.816 / 0.795 ms per step; scripts/gpu_refine_bits.sh): the checks are bound by cache lines per gather, not by latency
+#ifndef DPQ_REFINE_BITS
+#define DPQ_REFINE_BITS 2
+#endif
+    constexpr int RB = DPQ_REFINE_BITS;
     auto refine = [&](int n) {
         __builtin_amdgcn_wave_barrier();  // ring entries were written by other lanes of this wavefront
         int i = rq_head + lane;
