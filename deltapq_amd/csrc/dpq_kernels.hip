@@ -233,7 +233,10 @@ struct Cfg {
     // In-scan tightening: a slot's cut can be lowered by e * XU filter units, e = 1 .. XMAX, while a scan launch runs
     // (the additive term of its accumulator field grows by as much): the field sums need that much headroom.
     static constexpr int XMAX = kTightBuckets - 1;
-    static constexpr int XU = M <= 8 ? 2 : 8;  // about a quarter of QT at XMAX steps: the k-th distance of a bootstrap
+#ifndef DPQ_XU16
+#define DPQ_XU16 6  // swept on the GPU at top-1000 (scripts/gpu_xu16.sh; exact checks per query, ms per step): 4: 10823, 0.754; 6: 10295, 0.742; 8: 10806, 0.757; 12: 11957, 0.798; 16: 13133, 0.849; 24: 15919, 0.959 (top-100: 0.366 - 0.376)
+#endif
+    static constexpr int XU = M <= 8 ? 2 : DPQ_XU16;  // about a quarter of QT at XMAX steps: the k-th distance of a bootstrap
                                                // threshold of rank 8 k lies 17 % of (tau - minima) above the final one
     // field sum >= 2^(AB-1) (its top bit) <=> sum of entries > QT + 1.  R = 1: added to every m = 0 entry;
     // R = 2: the accumulator fields start from it.
