@@ -224,19 +224,26 @@ struct Cfg {
     // M = 8 with the in-scan tightening's headroom (8 SAT + BIAS + XMAX XU <= 255), scripts/sim_filter_nibbles.py, survivors
     // per query at a threshold of rank 800 / 400 / 200: 80/26 (no headroom) 2241 / 1139 / 550, 64/24 (none) 2156 / 1066 /
     // 501, 64/22 2414 / 1211 / 574, 72/23 2515 / 1284 / 620, 80/23 3113 / 1639 / 818
+    // Round 3, last step: tightening steps of ONE unit (seven steps = 11 % of the span; finer steps locate the cut better
+    // than a longer range reaches, as at M = 16) free a unit of saturation: 64/23 with XU 1 against 64/22 with XU 2 on the
+    // GPU (scripts/gpu_xu8.sh): exact checks per query 1676 against 1810 at top-100 (candidates 400 / 401), 12 514 against
+    // 13 344 at top-1000; scan launch 0.1148 / 0.1178 ms and 0.284 / 0.298 ms.
 #ifndef DPQ_QT8
 #define DPQ_QT8 64
-#define DPQ_SAT8 22
+#define DPQ_SAT8 23
 #endif
     static constexpr int QT = M <= 8 ? DPQ_QT8 : DPQ_QT16;   // filter units that span (tau - sum of minima)
     static constexpr int SAT = M <= 8 ? DPQ_SAT8 : DPQ_SAT16; // entry saturation
     // In-scan tightening: a slot's cut can be lowered by e * XU filter units, e = 1 .. XMAX, while a scan launch runs
     // (the additive term of its accumulator field grows by as much): the field sums need that much headroom.
     static constexpr int XMAX = kTightBuckets - 1;
+#ifndef DPQ_XU8
+#define DPQ_XU8 1
+#endif
 #ifndef DPQ_XU16
 #define DPQ_XU16 6  // swept on the GPU at top-1000 (scripts/gpu_xu16.sh; exact checks per query, ms per step): 4: 10823, 0.754; 6: 10295, 0.742; 8: 10806, 0.757; 12: 11957, 0.798; 16: 13133, 0.849; 24: 15919, 0.959 (top-100: 0.366 - 0.376)
 #endif
-    static constexpr int XU = M <= 8 ? 2 : DPQ_XU16;  // about a quarter of QT at XMAX steps: the k-th distance of a bootstrap
+    static constexpr int XU = M <= 8 ? DPQ_XU8 : DPQ_XU16;  // about a quarter of QT at XMAX steps: the k-th distance of a bootstrap
                                                // threshold of rank 8 k lies 17 % of (tau - minima) above the final one
     // field sum >= 2^(AB-1) (its top bit) <=> sum of entries > QT + 1.  R = 1: added to every m = 0 entry;
     // R = 2: the accumulator fields start from it.
