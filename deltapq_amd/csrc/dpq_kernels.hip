@@ -663,7 +663,7 @@ __global__ __launch_bounds__(256) void quantise_kernel(const ScanArgs a) {
 // Read window of the scan's ADC gathers at M = 8 (ds_read_b128 in flight before the first pair is summed; 0 = leave
 // the order to the compiler).  See scan_kernel.
 #ifndef DPQ_TIGHT_SLEEP
-#define DPQ_TIGHT_SLEEP 32  // s_sleep units of 64 cycles between two looks of the helper wavefront
+#define DPQ_TIGHT_SLEEP 32  // s_sleep units of 64 cycles between two looks of the helper wavefront (16 / 32 / 64: the same scan, scripts/gpu_tight_sleep.sh)
 #endif
 #ifndef DPQ_GATHER_PIPE
 #define DPQ_GATHER_PIPE 0
