@@ -594,11 +594,12 @@ int run_batch(dpq_index* x, const float* d_queries, int nq, int top_k, int32_t* 
     sa.region_off = top_k;
     sa.counters = x->prof && !x->prof_scan_only ? x->d_counters : nullptr;
     sa.qtab = x->d_qtab;
-    // in-scan threshold tightening (plain-code scans of this batch; scan_kernel): histograms behind the overflow flags
+    // in-scan threshold tightening (plain-code scans of this batch; scan_kernel): histograms behind the overflow flags.
     // Measured (1 M codes x 1000 queries): top-100 +2 % queries/s (exact checks 3002 -> 1813 and candidates 802 -> 404 per
-    // query, select 21 -> 16 us); top-1000 -2 % at M = 8 and -7 % at M = 16: there the plan's two short levels in front
-    // already do the tightening, and the helper wavefront and the counting only cost.  So: plans of one level after a
-    // bootstrap, i.e. top_k <= 512 (ensure_plan; top-300: 3.69 -> see DESIGN.md 5.2c).
+    // query, select 21 -> 16 us); top-300 +7 %, top-512 +22 %.  On top of the two short levels a large top_k used to get
+    // it cost 2 % (M = 8) to 7 % (M = 16) -- but ONE level with the tightening beats those plans (top-1000 1.89 -> 2.27 M
+    // q/s, M = 16 1.21 -> 1.27 M, top-2048 0.97 -> 1.19 M): ensure_plan gives top_k > 512 one level when the launch
+    // tightens, and the tightening stays off only where such a top_k meets a plan of several levels (shards > 2 M codes).
     sa.tight_hist = x->tune.tighten && (top_k <= 512 || x->level_cnt.size() <= 2) ? x->d_overflow + x->ws_slots : nullptr;
     sa.tight_k = top_k;
 
