@@ -9,7 +9,7 @@ export DPQ_ASYNC_OVERLAP=${DPQ_ASYNC_OVERLAP:-0}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 OUT=gpurun_out/kstats_$TAG
 rm -rf $OUT && mkdir -p $OUT
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python bench.py --steps 20 --warmup 3 --no-cpu-baseline --check 0 $BENCH_ARGS > $OUT/bench_under_rocprof.json 2> $OUT/stats.err || echo "rocprof failed"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-hbm-leg --check 0 $BENCH_ARGS > $OUT/bench_under_rocprof.json 2> $OUT/stats.err || echo "rocprof failed"
 cp $OUT/stats/*/*_kernel_stats.csv $OUT/kernel_stats.csv 2>/dev/null; rm -rf $OUT/stats
 echo "== $TAG $*"
 python - <<PY
