@@ -92,6 +92,7 @@ struct Tuning {
     int coarse_below = 128;
     int plan_ratios[3] = {0, 0, 0};
     int boot_cap = 0, boot_target = 0;
+    int select_threads = 0;  // select_kernel block size, 0 = by top_k  [DPQ_SELECT_THREADS]
     int64_t batch_tile_nodes = (int64_t)16 << 20;
     bool relabel = true, fuse_quantise = true, async_overlap = true, boot_fullsort = false, tighten = true, strands = true,
          force_strands = false;
@@ -245,6 +246,7 @@ Tuning resolve_tuning(const dpq_open_opts& o) {
         v = 1; geti("DPQ_ASYNC_OVERLAP", &v); t.async_overlap = t.async_overlap && v != 0;
         v = 0; geti("DPQ_BOOT_FULLSORT", &v); t.boot_fullsort = t.boot_fullsort || v != 0;
         v = 1; geti("DPQ_TIGHTEN", &v); t.tighten = t.tighten && v != 0;
+        geti("DPQ_SELECT_THREADS", &t.select_threads);
         v = 1; geti("DPQ_STRANDS", &v); t.strands = t.strands && v != 0;
         t.force_strands = t.force_strands || v == 2;
     }
@@ -604,6 +606,7 @@ int run_batch(dpq_index* x, const float* d_queries, int nq, int top_k, int32_t* 
     sa.tight_k = top_k;
 
     dpq::SelectArgs se{};
+    se.threads = x->tune.select_threads;
     se.cand_count = x->d_cand_count;
     se.cand_key = x->d_cand_key;
     se.cand_stride = stride;

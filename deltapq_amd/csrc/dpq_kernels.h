@@ -107,6 +107,7 @@ struct SelectArgs {
     int32_t fp32_accum;            // 1: plain-scan rule, distance accumulated in fp32 (h:2658-2662)
     int32_t keep_thr;              // 1: thr_key = min(thr_key, this level's k-th key) (levels after a bootstrap)
     unsigned long long* stamps;    // developer diagnostics (NULL in product calls): [slots][8] s_memtime marks
+    int32_t threads;               // block size (256 / 512 / 1024); 0 = by top_k (launch_select)
 };
 
 // Threshold bootstrap from the inverted multi-index (see bootstrap_kernel).
