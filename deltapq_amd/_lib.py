@@ -27,7 +27,7 @@ class Info(ctypes.Structure):
                 ("algorithmic_bytes", c_i64), ("device_bytes", c_i64), ("n_diffs", c_i64), ("M", c_i32),
                 ("K", c_i32), ("Ds", c_i32), ("n_segments", c_i32), ("chunks_per_segment", c_i32),
                 ("max_depth", c_i32), ("device", c_i32), ("cand_capacity", c_i32), ("bootstrap_bytes", c_i64),
-                ("bootstrap_stride", c_i32), ("batch_decode_mb", c_i32)]
+                ("bootstrap_stride", c_i32), ("batch_decode_mb", c_i32), ("strand_bytes", c_i64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -39,7 +39,8 @@ class Profile(ctypes.Structure):
                 ("scan_node_query_pairs", c_i64), ("scan_stream_bytes", c_i64), ("query_batches", c_i64),
                 ("queries", c_i64), ("overflow_reruns", c_i64), ("exact_checks", c_i64), ("candidates", c_i64),
                 ("quantise_ms", ctypes.c_double), ("decode_ms", ctypes.c_double), ("bootstrap_ms", ctypes.c_double),
-                ("bootstrap_launches", c_i64)]
+                ("bootstrap_launches", c_i64), ("stream_launches", c_i64), ("strand_launches", c_i64),
+                ("strand1_launches", c_i64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

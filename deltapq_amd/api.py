@@ -89,8 +89,9 @@ class HostSoA:
         check(lib.dpq_soa_info(h, info), "dpq_soa_info")
         self.info = info.as_dict()
         names = ["nib", "mask", "delta", "seg_delta_off", "seg_ckpt", "mi_cell_start", "mi_code", "mi_id", "par", "carry",
-                 "st_ckpt", "st_hdr", "st_poff", "st_pbase", "st_delta"]
-        views = {"seg_delta_off": np.uint64, "st_ckpt": np.uint64, "st_hdr": np.uint64, "st_poff": np.uint16, "st_pbase": np.uint32}
+                 "st_ckpt", "st_mask", "st_poff", "st_pbase", "st_delta", "st_depth"]
+        views = {"seg_delta_off": np.uint64, "st_ckpt": np.uint64, "st_mask": np.uint32, "st_poff": np.uint16, "st_pbase": np.uint32,
+                 "st_depth": np.uint16}
         for which, name in enumerate(names):
             ptr, nb = ctypes.c_void_p(), _lib.c_i64()
             check(lib.dpq_soa_array(h, which, ptr, nb), "dpq_soa_array")
@@ -219,13 +220,21 @@ def _apply_tuning(opts, tune):
             for i in range(3):
                 opts.plan_ratios[i] = int(vals[i])
         elif name in ("stream_max_queries", "coarse_below", "boot_cap", "boot_target", "flags", "batch_tile_nodes"):
-            setattr(opts, name, int(value))
+            v = int(value)
+            if name == "stream_max_queries" and v > MAX_STREAM_QUERIES:
+                raise ValueError("stream_max_queries above %d: the stream pass answers at most four queries per pass" % MAX_STREAM_QUERIES)
+            if name == "boot_cap" and v != 0 and not 2048 <= v <= 16384:
+                raise ValueError("boot_cap outside 2048..16384")
+            setattr(opts, name, v)
         else:
             raise TypeError("unknown dpq_open_opts field %r" % name)
     return opts
 
 
-OPT_NO_RELABEL, OPT_NO_FUSE_QUANTISE, OPT_NO_ASYNC_OVERLAP, OPT_BOOT_FULLSORT = 1, 2, 4, 8   # dpq_open_opts.flags
+# dpq_open_opts.flags (include/deltapq_amd.h DPQ_OPT_*)
+OPT_NO_RELABEL, OPT_NO_FUSE_QUANTISE, OPT_NO_ASYNC_OVERLAP, OPT_BOOT_FULLSORT = 1, 2, 4, 8
+OPT_NO_TIGHTEN, OPT_NO_STRANDS, OPT_FORCE_STRANDS, OPT_NO_STRAND1 = 16, 32, 64, 128
+MAX_STREAM_QUERIES = 16   # a larger stream_max_queries would send a big batch through ceil(nq / 4) full passes over the index
 
 
 class DeltaPQIndex:

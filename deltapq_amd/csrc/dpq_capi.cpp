@@ -95,7 +95,7 @@ struct Tuning {
     int select_threads = 0;  // select_kernel block size, 0 = by top_k  [DPQ_SELECT_THREADS]
     int64_t batch_tile_nodes = (int64_t)16 << 20;
     bool relabel = true, fuse_quantise = true, async_overlap = true, boot_fullsort = false, tighten = true, strands = true,
-         force_strands = false;
+         force_strands = false, strand1 = true;  // strand1: one query per pass takes strand1_kernel  [DPQ_STRAND1=0: strand_kernel<1>]
 };
 
 struct dpq_index {
@@ -108,8 +108,9 @@ struct dpq_index {
     dpq::DeviceImage img;
     // owned device memory of the image
     // strand image (dpq_format.h): the stream pass's own layout of the same nodes (M = 8, shards with a bootstrap)
-    uint64_t *d_st_ckpt = nullptr, *d_st_hdr = nullptr;
-    uint16_t* d_st_poff = nullptr;
+    uint64_t* d_st_ckpt = nullptr;
+    uint32_t* d_st_mask = nullptr;
+    uint16_t* d_st_depth = nullptr;
     uint32_t *d_st_pbase = nullptr, *d_strip_order = nullptr;
     uint32_t* d_strip_segs = nullptr;      // the segments of the strips, in strip visiting order (a level too small for the
     std::vector<int64_t> strip_seg_off;    // strand pass runs the chunk-per-wavefront pass over ITS strips' segments)
@@ -218,7 +219,7 @@ namespace {
 // here, once per dpq_open_*: a product process' plan never depends on its environment.
 Tuning resolve_tuning(const dpq_open_opts& o) {
     Tuning t;
-    if (o.stream_max_queries != 0) t.stream_max = std::max(0, o.stream_max_queries);
+    if (o.stream_max_queries != 0) t.stream_max = std::min(16, std::max(0, o.stream_max_queries));  // (four queries per pass at most)
     if (o.coarse_below > 0) t.coarse_below = o.coarse_below;
     for (int i = 0; i < 3; ++i) t.plan_ratios[i] = o.plan_ratios[i];
     t.boot_cap = std::max(0, o.boot_cap);
@@ -231,6 +232,7 @@ Tuning resolve_tuning(const dpq_open_opts& o) {
     t.tighten = !(o.flags & DPQ_OPT_NO_TIGHTEN);
     t.strands = !(o.flags & DPQ_OPT_NO_STRANDS);
     t.force_strands = (o.flags & DPQ_OPT_FORCE_STRANDS) != 0;
+    t.strand1 = !(o.flags & DPQ_OPT_NO_STRAND1);
     const char* dev = getenv("DPQ_DEV");
     if (dev && atoi(dev) != 0) {
         auto geti = [](const char* name, int* v) { if (const char* e = getenv(name)) *v = atoi(e); };
@@ -249,6 +251,7 @@ Tuning resolve_tuning(const dpq_open_opts& o) {
         geti("DPQ_SELECT_THREADS", &t.select_threads);
         v = 1; geti("DPQ_STRANDS", &v); t.strands = t.strands && v != 0;
         t.force_strands = t.force_strands || v == 2;
+        v = 1; geti("DPQ_STRAND1", &v); t.strand1 = t.strand1 && v != 0;
     }
     return t;
 }
@@ -343,6 +346,7 @@ int ensure_plan(dpq_index* x, int top_k, int cap, int shape) {
     if (x->plan_top_k == top_k && x->plan_cap == cap && x->plan_coarse == shape) return DPQ_OK;
     const int coarse = shape & 1;
     const bool tight = (shape & 2) != 0;  // the scan tightens its thresholds as it goes (run_batch)
+    const bool one_level = (shape & 4) != 0;  // one query per pass on the strand image: strand1_kernel tightens in the kernel
     const int64_t S = (int64_t)dpq::kChunk * x->img.chunks_per_segment;
     const int64_t nseg = x->img.n_segments;
     const int64_t s0 = std::min<int64_t>(nseg, std::max<int64_t>(1, dpq::kLevel0Nodes / S));
@@ -358,8 +362,8 @@ int ensure_plan(dpq_index* x, int top_k, int cap, int shape) {
         if (forced[0] >= 2) {
             for (int i = 0; i < 3; ++i)
                 if (forced[i] >= 2) ratios.push_back(forced[i]);
-        } else if (forced[0] == 1) {
-            // one level whatever the shard size (experiments)
+        } else if (forced[0] == 1 || one_level) {
+            // one level whatever the shard size (experiments; the one-query strand pass)
         } else {
             for (int64_t b = nseg; b * S > ((int64_t)2 << 20); b /= 8) ratios.push_back(8);
             // A large top_k takes its first threshold from a worse quantile of the bootstrap sample (the 1000th of
@@ -535,7 +539,14 @@ int run_batch(dpq_index* x, const float* d_queries, int nq, int top_k, int32_t* 
     // workgroups per query group (8 groups or more): the plan then keeps one filter level also for a large top_k.
     const bool tight_plan = x->tune.tighten && nq > x->tune.stream_max &&
                             ngroups * dpq::kTightSplits >= dpq::kMaxSplits && (x->plain || use_batch_decode(x, ngroups));
-    if ((rc = ensure_plan(x, top_k, cap, (nq <= x->tune.coarse_below ? 1 : 0) | (tight_plan ? 2 : 0)))) return rc;
+    // Which stream pass a batch of up to stream_max queries takes: the strand image (a lane per run of 64 nodes) has 64 x
+    // fewer, 64 x longer work items than the chunk-per-wavefront decode, so it wants a big shard (dpq::kStrandMinNodes).
+    // ONE query per pass runs strand1_kernel, which tightens its threshold while it runs: one level over the whole shard.
+    const bool direct = !x->plain && nq <= x->tune.stream_max;
+    const bool strands = direct && x->img.st_ckpt != nullptr && (x->tune.force_strands || x->img.n_local >= dpq::kStrandMinNodes);
+    const bool strand1 = strands && x->tune.strand1 && dpq::stream_queries_per_pass(x->M, nq) == 1;
+    const bool strand1_tight = strand1 && x->tune.tighten && x->tune.plan_ratios[0] == 0;
+    if ((rc = ensure_plan(x, top_k, cap, (nq <= x->tune.coarse_below ? 1 : 0) | (tight_plan ? 2 : 0) | (strand1_tight ? 4 : 0)))) return rc;
     int64_t stride = top_k;
     for (size_t l = 1; l < x->level_cnt.size(); ++l)
         stride = std::max(stride, regions_for(x, x->level_cnt[l], ngroups, top_k, cap).stride);
@@ -554,7 +565,6 @@ int run_batch(dpq_index* x, const float* d_queries, int nq, int top_k, int32_t* 
     // One or two queries (the reference's own call shape): one query per pass over the compressed image, every node
     // evaluated against the exact table (stream_kernel) -- no filter tables, no 64-query group machinery.
     // dpq_open_opts.stream_max_queries: the batch size up to which this mode is used (-1 = never).
-    const bool direct = !x->plain && nq <= x->tune.stream_max;
     const bool scratch = !direct && use_batch_decode(x, ngroups);
     if (scratch && (rc = ensure_batch_raw(x))) return rc;
     const int64_t tile_segs = scratch ? batch_tile_segments(x) : 0;
@@ -706,7 +716,6 @@ int run_batch(dpq_index* x, const float* d_queries, int nq, int top_k, int32_t* 
                 // 1 M codes 35 / 37 pipelined but 89 / 59 as a single synchronous call, 4 M 50 / 49, 12.5 M 72 / 97, 32 M
                 // 113 / 172, 125 M 343 / 619; four queries per pass: 1 M 55 / 47, 4 M 76 / 61, 12.5 M 103 / 121, 32 M
                 // 195 / 230, 125 M 609 / 841.  From 8 M codes.
-                const bool strands = x->img.st_ckpt != nullptr && (x->tune.force_strands || x->img.n_local >= ((int64_t)8 << 20));
                 if (strands) {
                     // the pass over the strand image: the level's share of the strips (every strip exactly once over
                     // the levels, like the segments; the bootstrap consumed none)
@@ -714,22 +723,30 @@ int run_batch(dpq_index* x, const float* d_queries, int nq, int top_k, int32_t* 
                     const int64_t lo = (int64_t)x->level_off[l] * ns / nseg;
                     const int64_t hi = final_pass ? ns : ((int64_t)x->level_off[l] + x->level_cnt[l]) * ns / nseg;
                     dpq::ScanArgs st = sa;
+                    // strand1_kernel's candidate histogram: the first 256 words of the tightening counters (cleared by the
+                    // table build); one launch per batch reads it (a later level would count in other units)
+                    st.tight_hist = strand1_tight && x->level_cnt.size() == 2 ? x->d_overflow + x->ws_slots : nullptr;
+                    st.debug_pass = strand1 ? 0 : 3;
                     Timer t(x, stream, 1);
                     // A level of few strips (one strip per wavefront: the launch takes a strip's 64 dependent steps
                     // however few there are) goes through the chunk-per-wavefront pass over the same nodes: measured
                     // break-even at about 1500 strips (6 M nodes).
-                    if (hi - lo < 1536 && x->d_strip_segs && !x->tune.force_strands) {
+                    if (hi - lo < 1536 && x->d_strip_segs && !x->tune.force_strands && !strand1) {
                         st.seg_list = x->d_strip_segs + x->strip_seg_off[(size_t)lo];
                         st.n_seg_pass = (int32_t)(x->strip_seg_off[(size_t)hi] - x->strip_seg_off[(size_t)lo]);
                         DPQ_HIP(dpq::launch_stream(st, nq, stream));
+                        if (x->prof) x->prof_acc.stream_launches++;
                     } else {
                         st.seg_list = x->d_strip_order + lo;
                         st.n_seg_pass = (int32_t)(hi - lo);
                         DPQ_HIP(dpq::launch_strand(st, nq, stream));
+                        if (x->prof) (strand1 ? x->prof_acc.strand1_launches : x->prof_acc.strand_launches)++;
                     }
                 } else {
                     Timer t(x, stream, 1);
+                    sa.tight_hist = nullptr;
                     DPQ_HIP(dpq::launch_stream(sa, nq, stream));
+                    if (x->prof) x->prof_acc.stream_launches++;
                 }
                 if (x->prof) {
                     x->prof_acc.scan_launches++;
@@ -935,8 +952,12 @@ int open_from_payload(const uint8_t* payload, int64_t n_bytes, int64_t n_codes, 
     const int64_t per_shard = n_scan / std::max(1, o.shard_count);
     int mi_stride = o.bootstrap < 0 ? 0 : dpq::bootstrap_stride_for(per_shard);
     if (o.bootstrap > 0 && mi_stride == 0 && per_shard >= 16384) mi_stride = 1;  // forced on (tests, experiments)
+    // the strand image (the stream pass's own layout, ~1.2 x the payload in host RAM and HBM) only where run_batch
+    // will read it: big shards (cut by bytes: a margin on the estimate), or forced (tests, experiments)
+    const Tuning tune0 = resolve_tuning(o);
+    const bool want_strands = tune0.strands && (tune0.force_strands || per_shard >= dpq::kStrandMinNodes / 4 * 3);
     int rc = dpq::transcode(payload, n_bytes, n_codes, M, o.shard_rank, o.shard_count, o.chunks_per_segment, &soa,
-                            &err, o.num_codes, mi_stride);
+                            &err, o.num_codes, mi_stride, 0, want_strands ? 1 : 0);
     if (rc) return fail(rc, err);
 
     DPQ_HIP(hipSetDevice(o.device));
@@ -947,7 +968,7 @@ int open_from_payload(const uint8_t* payload, int64_t n_bytes, int64_t n_codes, 
     x->cap_auto = o.cand_capacity <= 0;
     x->cap = o.cand_capacity;
     x->batch_decode = o.batch_decode;
-    x->tune = resolve_tuning(o);
+    x->tune = tune0;
     auto up = [&](auto** dptr, const void* src, size_t bytes) -> int {
         using T = std::remove_pointer_t<std::remove_pointer_t<decltype(dptr)>>;
         int r = dev_alloc(dptr, (bytes + sizeof(T) - 1) / sizeof(T) + 64 / sizeof(T));
@@ -979,7 +1000,8 @@ int open_from_payload(const uint8_t* payload, int64_t n_bytes, int64_t n_codes, 
     }
     if (!rc && x->boot && x->tune.strands && soa.n_strips > 0 && soa.n_strips < INT32_MAX) {
         rc = up(&x->d_st_ckpt, soa.st_ckpt.data(), soa.st_ckpt.size() * 8);
-        if (!rc) rc = up(&x->d_st_hdr, soa.st_hdr.data(), soa.st_hdr.size() * 8);
+        if (!rc) rc = up(&x->d_st_mask, soa.st_mask.data(), soa.st_mask.size() * 4);
+        if (!rc) rc = up(&x->d_st_depth, soa.st_depth.data(), soa.st_depth.size() * 2);
         // (st_poff stays on the host: the kernel computes a lane's offset inside a phase as a wave prefix sum of the lanes'
         // byte counts; the array exists for the CPU-side checks of the image)
         if (!rc) rc = up(&x->d_st_pbase, soa.st_pbase.data(), soa.st_pbase.size() * 4);
@@ -1007,7 +1029,8 @@ int open_from_payload(const uint8_t* payload, int64_t n_bytes, int64_t n_codes, 
         }
         if (!rc) {
             x->img.st_ckpt = x->d_st_ckpt;
-            x->img.st_hdr = x->d_st_hdr;
+            x->img.st_mask = x->d_st_mask;
+            x->img.st_depth = x->d_st_depth;
             x->img.st_pbase = x->d_st_pbase;
             x->img.st_delta = x->d_st_delta;
             x->img.n_strips = (int32_t)soa.n_strips;
@@ -1043,6 +1066,7 @@ int open_from_payload(const uint8_t* payload, int64_t n_bytes, int64_t n_codes, 
     inf.bootstrap_bytes = x->boot ? soa.bootstrap_bytes() : 0;
     inf.bootstrap_stride = x->boot ? soa.mi_stride : 0;
     inf.batch_decode_mb = batch_decode_possible(x) ? (int32_t)((batch_raw_bytes(x) + (1 << 20) - 1) >> 20) : 0;
+    inf.strand_bytes = x->strand_bytes;
     inf.n_diffs = soa.n_diffs;
     inf.M = M;
     inf.K = K;
@@ -1166,6 +1190,7 @@ void fill_info_from_soa(const dpq::SoA& s, dpq_info* inf) {
     inf->device_bytes = s.device_bytes();
     inf->bootstrap_bytes = s.bootstrap_bytes();
     inf->bootstrap_stride = s.mi_stride;
+    inf->strand_bytes = s.n_strips > 0 ? s.strand_bytes() : 0;
     inf->n_diffs = s.n_diffs;
     inf->M = s.M;
     inf->n_segments = (int32_t)s.n_segments;
@@ -1304,11 +1329,12 @@ int dpq_soa_array(const dpq_soa* soa, int which, const void** ptr, int64_t* n_by
         case 8: *ptr = s.par.data(); *n_bytes = (int64_t)s.par.size(); break;
         case 9: *ptr = s.carry.data(); *n_bytes = (int64_t)s.carry.size(); break;
         case 10: *ptr = s.st_ckpt.data(); *n_bytes = (int64_t)s.st_ckpt.size() * 8; break;
-        case 11: *ptr = s.st_hdr.data(); *n_bytes = (int64_t)s.st_hdr.size() * 8; break;
+        case 11: *ptr = s.st_mask.data(); *n_bytes = (int64_t)s.st_mask.size() * 4; break;
         case 12: *ptr = s.st_poff.data(); *n_bytes = (int64_t)s.st_poff.size() * 2; break;
         case 13: *ptr = s.st_pbase.data(); *n_bytes = (int64_t)s.st_pbase.size() * 4; break;
         case 14: *ptr = s.st_delta.data(); *n_bytes = (int64_t)s.st_delta.size(); break;
-        default: return fail(DPQ_ERR_ARG, "which must be 0..14");
+        case 15: *ptr = s.st_depth.data(); *n_bytes = (int64_t)s.st_depth.size() * 2; break;
+        default: return fail(DPQ_ERR_ARG, "which must be 0..15");
     }
     return DPQ_OK;
     });
@@ -1644,8 +1670,8 @@ int dpq_close(dpq_index* x) {
         if (x->lane_ready[l]) hipEventDestroy(x->lane_ready[l]);
     }
     hipFree(x->d_st_ckpt);
-    hipFree(x->d_st_hdr);
-    hipFree(x->d_st_poff);
+    hipFree(x->d_st_mask);
+    hipFree(x->d_st_depth);
     hipFree(x->d_st_pbase);
     hipFree(x->d_st_delta);
     hipFree(x->d_strip_order);

@@ -148,7 +148,7 @@ int validate(const uint8_t* payload, int64_t n_bytes, int64_t n_codes, int M, dp
 
 int transcode(const uint8_t* payload, int64_t n_bytes, int64_t n_codes, int M, int shard_rank, int shard_count,
               int chunks_per_segment, SoA* out, std::string* err, int64_t scan_codes, int multi_index_stride,
-              int multi_index_classes) {
+              int multi_index_classes, int strands) {
     int rc = check_args(payload, n_bytes, n_codes, M, err);
     if (rc) return rc;
     if (scan_codes < 0 || scan_codes > n_codes) {
@@ -242,7 +242,7 @@ int transcode(const uint8_t* payload, int64_t n_bytes, int64_t n_codes, int M, i
         mi_codes.reserve((size_t)((o.node_hi - o.node_lo) / multi_index_stride + 1) * M);
     }
     // strand image (see dpq_format.h): filled strip by strip
-    const bool want_strands = multi_index_stride > 0 && M == 8;
+    const bool want_strands = multi_index_stride > 0 && M == 8 && strands != 0;
     constexpr int kPhases = kRunLen / kPhaseLen;
     std::vector<uint8_t> strip_bytes;                      // changed bytes of the current strip, [lane][step][<= 8]
     std::vector<uint8_t> strip_cnt;                        // their counts
@@ -250,7 +250,8 @@ int transcode(const uint8_t* payload, int64_t n_bytes, int64_t n_codes, int M, i
         o.n_strips = (o.node_hi - o.node_lo + kStripNodes - 1) / kStripNodes;
         o.st_ckpt.assign((size_t)o.n_strips * levels * 64, 0);
         // padding nodes: depth 1, mask 0 (a copy of stack[0]); the kernel never reports them
-        o.st_hdr.assign((size_t)o.n_strips * (kRunLen / 4) * 64, 0x0100010001000100ull);
+        o.st_mask.assign((size_t)o.n_strips * (kRunLen / 4) * 64, 0u);
+        o.st_depth.assign((size_t)o.n_strips * (kRunLen / 4) * 64, 0x1111u);
         o.st_poff.assign((size_t)o.n_strips * kPhases * 64, 0);
         o.st_pbase.assign((size_t)o.n_strips * kPhases + 1, 0);
         strip_bytes.assign((size_t)kStripNodes * 8, 0);
@@ -323,8 +324,9 @@ int transcode(const uint8_t* payload, int64_t n_bytes, int64_t n_codes, int M, i
                 const int64_t strip = l / kStripNodes, in_strip = l % kStripNodes;
                 const int s_lane = (int)(in_strip / kRunLen), step = (int)(in_strip % kRunLen);
                 // (the root, depth 0, arrives with mask 0xFF and its 8 bytes: every position "changes")
-                uint16_t* h = reinterpret_cast<uint16_t*>(&o.st_hdr[(size_t)((strip * (kRunLen / 4) + step / 4) * 64 + s_lane)]);
-                h[step % 4] = (uint16_t)((r.mask & 0xFFu) | ((unsigned)r.depth << 8));
+                const size_t hw = (size_t)((strip * (kRunLen / 4) + step / 4) * 64 + s_lane);
+                o.st_mask[hw] |= (uint32_t)(r.mask & 0xFFu) << (8 * (step % 4));
+                o.st_depth[hw] = (uint16_t)((o.st_depth[hw] & ~(0xFu << (4 * (step % 4)))) | ((unsigned)r.depth << (4 * (step % 4))));
                 memcpy(&strip_bytes[(size_t)in_strip * 8], r.deltas, (size_t)r.n_diff);
                 strip_cnt[(size_t)in_strip] = (uint8_t)r.n_diff;
                 if (in_strip + 1 == kStripNodes || i + 1 == o.node_hi) flush_strip(strip);

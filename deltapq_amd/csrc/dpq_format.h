@@ -102,12 +102,15 @@ struct SoA {
     // steps: the bytes all 64 lanes need for those steps lie together (lane after lane) and are staged in LDS.
     int64_t n_strips = 0;
     std::vector<uint64_t> st_ckpt;   // [n_strips][levels][64]: the ancestor stack (one code per level) at a run's first node
-    std::vector<uint64_t> st_hdr;    // [n_strips][kRunLen / 4][64]: four 16-bit (mask | depth << 8) of the lane's next four nodes
-    std::vector<uint16_t> st_poff;   // [n_strips][kRunLen / kPhaseLen][64]: offset of the lane's bytes inside the phase
+    std::vector<uint32_t> st_mask;   // [n_strips][kRunLen / 4][64]: the diff masks of the lane's next four nodes, one byte each
+    std::vector<uint16_t> st_depth;  // [n_strips][kRunLen / 4][64]: their depths, four bits each (1.5 B per node of headers: what the
+                                     // DTC payload spends on a node's mask byte and depth nibble)
+    std::vector<uint16_t> st_poff;   // [n_strips][kRunLen / kPhaseLen][64]: offset of the lane's bytes inside the phase (host only:
+                                     // the kernels compute it as a wave prefix sum of the masks' popcounts)
     std::vector<uint32_t> st_pbase;  // [n_strips * phases + 1]: start of a phase in st_delta, in units of 16 bytes
     std::vector<uint8_t> st_delta;   // the phases, each padded to 16 bytes; 16 bytes of tail padding
     int64_t strand_bytes() const {
-        return (int64_t)(st_ckpt.size() * 8 + st_hdr.size() * 8 + st_poff.size() * 2 + st_pbase.size() * 4 + st_delta.size());
+        return (int64_t)(st_ckpt.size() * 8 + st_mask.size() * 4 + st_depth.size() * 2 + st_pbase.size() * 4 + st_delta.size());
     }
     int64_t nodes_per_segment() const { return (int64_t)kChunk * chunks_per_segment; }
     int64_t device_bytes() const {
@@ -122,9 +125,14 @@ int validate(const uint8_t* payload, int64_t n_bytes, int64_t n_codes, int M, dp
 // h:2825-2829); the stream is parsed with the header's n_codes (it decides which node owns a whole depth byte).
 // multi_index_stride > 0: also build the bootstrap multi-index over every multi_index_stride-th local node, dealt to
 // multi_index_classes classes (0 = chosen by bootstrap_classes_for).
+// strands: build the strand image too (M = 8, with a multi-index): -1 = whenever the multi-index is built, 0 = never,
+// 1 = yes.  dpq_open_* asks for it only where the stream pass will read it (shards from kStrandMinNodes, or forced).
 int transcode(const uint8_t* payload, int64_t n_bytes, int64_t n_codes, int M, int shard_rank, int shard_count,
               int chunks_per_segment, SoA* out, std::string* err, int64_t scan_codes = 0, int multi_index_stride = 0,
-              int multi_index_classes = 0);
+              int multi_index_classes = 0, int strands = -1);
+// The strand pass has 64 x fewer, 64 x longer work items than the chunk-per-wavefront decode: it is taken from this many
+// codes per shard (dpq_capi.cpp: measured break-even), and the image is only built and uploaded for such shards.
+constexpr int64_t kStrandMinNodes = (int64_t)8 << 20;
 // The bootstrap multi-index of a list of (global position, code) pairs: counting sort by class and cell.
 void build_multi_index(const std::vector<uint32_t>& ids, const std::vector<uint8_t>& codes, int M, int stride, int classes,
                        SoA* out);

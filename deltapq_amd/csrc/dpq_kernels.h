@@ -36,8 +36,8 @@ struct DeviceImage {
     const uint8_t* raw = nullptr;             // non-NULL: plain (uncompressed) index, codes[n][M], padded to whole segments
     // strand image (dpq_format.h; NULL = not built): the same nodes, a lane per run of 64
     const uint64_t* st_ckpt = nullptr;        // [n_strips][8][64]
-    const uint64_t* st_hdr = nullptr;         // [n_strips][16][64]
-    const uint16_t* st_poff = nullptr;        // [n_strips][16][64]
+    const uint32_t* st_mask = nullptr;        // [n_strips][16][64]: four mask bytes
+    const uint16_t* st_depth = nullptr;       // [n_strips][16][64]: four depth nibbles
     const uint32_t* st_pbase = nullptr;       // [n_strips * 16 + 1], units of 16 bytes
     const uint8_t* st_delta = nullptr;
     int32_t n_strips = 0;

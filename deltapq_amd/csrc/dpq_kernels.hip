@@ -1516,7 +1516,7 @@ __global__ __launch_bounds__(stream_threads<Q>(), M > 8 ? 4 : Q >= 4 ? DPQ_STREA
 // prefix scan over the masks, no pointer jumping over the LDS crossbar, no carry between chunks): the pass is bound by
 // the exact-table gathers in LDS instead of by instruction issue.
 // A wavefront takes a strip (4096 nodes) at a time: loads the 64 runs' checkpoints into its stack rows, then per group
-// of four steps one coalesced 8-byte header load (four 16-bit mask | depth << 8), one 2-byte offset, and the lane's
+// of four steps one coalesced header load (four mask bytes + four depth nibbles: 6 bytes), and the lane's
 // changed bytes of the group (<= 32: two 16-byte loads at ITS byte offset inside the group's bytes, which lie lane after
 // lane: the wavefront's loads touch a few hundred contiguous bytes), a group ahead.  They are parked in LDS as dword
 // ROWS [k][lane] -- lane l's k-th dword in bank l mod 32 whatever k, so the three dwords a node reads around its byte
@@ -1590,13 +1590,19 @@ __global__ __launch_bounds__(kStrandThreads, Q >= 4 ? 2 : Q == 2 ? 3 : 4) void s
         // Where a lane's bytes start inside a group's bytes (which lie lane after lane) is the wave prefix sum of the
         // lanes' byte counts, i.e. of the popcounts of the header's four masks: computed (bit planes + v_mbcnt), not
         // loaded -- a loaded offset put two dependent HBM round trips into every group.
-        auto load_hdr = [&](int g) -> uint64_t { return g < GROUPS ? a.img.st_hdr[(sid * GROUPS + g) * 64 + lane] : 0ull; };
+        struct Hdr {
+            uint32_t masks, depths;  // the lane's next four nodes: a mask byte and a depth nibble each
+        };
+        auto load_hdr = [&](int g) -> Hdr {
+            if (g >= GROUPS) return Hdr{0u, 0u};
+            return Hdr{a.img.st_mask[(sid * GROUPS + g) * 64 + lane], (uint32_t)a.img.st_depth[(sid * GROUPS + g) * 64 + lane]};
+        };
         struct Bytes {
             uint4 b0, b1;
         };
-        auto load_bytes = [&](int g, uint64_t h) {
+        auto load_bytes = [&](int g, const Hdr& h) {
             Bytes r;
-            const uint32_t mine = (uint32_t)__popcll(h & 0x00ff00ff00ff00ffull);  // <= 32
+            const uint32_t mine = (uint32_t)__popc(h.masks);  // <= 32
             uint32_t off = 0;
 #pragma unroll
             for (int bit = 5; bit >= 0; --bit) off = mbcnt64(__ballot((mine >> bit) & 1u), off << 1);
@@ -1605,7 +1611,7 @@ __global__ __launch_bounds__(kStrandThreads, Q >= 4 ? 2 : Q == 2 ? 3 : 4) void s
             __builtin_memcpy(&r.b1, src + 16, 16);
             return r;
         };
-        uint64_t hdr = load_hdr(0), hdr_next = load_hdr(1);
+        Hdr hdr = load_hdr(0), hdr_next = load_hdr(1);
         Bytes cur = load_bytes(0, hdr);
         for (int g = 0; g < GROUPS; ++g) {
             // stage the group's bytes (the previous group's reads of the buffer were issued before: LDS keeps a
@@ -1617,7 +1623,7 @@ __global__ __launch_bounds__(kStrandThreads, Q >= 4 ? 2 : Q == 2 ? 3 : 4) void s
                 for (int k = 0; k < 8; ++k) drow[k * 64 + lane] = w[k];
             }
             __builtin_amdgcn_wave_barrier();
-            const uint64_t hdr_after = load_hdr(g + 2);
+            const Hdr hdr_after = load_hdr(g + 2);
             if (g + 1 < GROUPS) cur = load_bytes(g + 1, hdr_next);
             uint32_t ptr = 0;  // bytes of this lane's group consumed so far
             // The group's four steps in two sweeps: decode + exact-table sums first, straight-line (a step's gathers run
@@ -1627,8 +1633,7 @@ __global__ __launch_bounds__(kStrandThreads, Q >= 4 ? 2 : Q == 2 ? 3 : 4) void s
             constexpr int H = Q == 1 ? DPQ_ADC_SPLIT : M;  // several queries: a lane is rarely out of every race -- all at once
 #pragma unroll
             for (int st = 0; st < kPhaseLen; ++st) {
-                const uint32_t hw = (uint32_t)(hdr >> (16 * st)) & 0xffffu;
-                const uint32_t mask = hw & 0xffu, depth = hw >> 8;
+                const uint32_t mask = (hdr.masks >> (8 * st)) & 0xffu, depth = (hdr.depths >> (4 * st)) & 0xfu;
                 const uint2 parent = stk[(depth > 0 ? depth - 1 : 0) * 64 + lane];
                 const uint32_t* at = drow + (ptr >> 2) * 64 + lane;
                 const uint32_t w0 = at[0], w1 = at[64], w2 = at[128];
@@ -1718,6 +1723,319 @@ __global__ __launch_bounds__(kStrandThreads, Q >= 4 ? 2 : Q == 2 ? 3 : 4) void s
             hdr = hdr_next;
             hdr_next = hdr_after;
         }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// strand1: ONE query per pass over the strand image -- the reference's own call shape (main:328-339: one query per
+// call) on a big shard, the regime in which the path has to be bound by HBM.  strand_kernel<1> is bound by the LDS
+// array instead: the eight exact-table gathers of a node (ds_read_b32 at random rows of an 8 KB table) replay 3.5-fold
+// bank conflicts on random codes (38 % of its LDS cycles), and a node's changed bytes make a round trip through
+// dword rows in LDS.  This kernel removes both:
+//  * ADC (h:2896-2905) in fixed point first: the scan's conservative 8-bit lower bound,
+//    entry[m][c] = min(floor((T[m][c] - min_m) s), 255), s = QT / (tau' - sum of minima) -- floor and min only lower an
+//    entry, so a node within the threshold has sum <= QT; what the bound lets through (a few per million nodes) is
+//    summed exactly (fp64 sum of the fp32 entries, the reference's distance) and compared as a whole (distance, id) key.
+//    The table is ONE 8-byte row per code value c -- byte m = entry of sub-space m -- stored once per LDS bank pair:
+//    Tq[c][lane mod 32], 64 KB.  A lane's ds_read_b64 at (c << 8 | (lane mod 32) << 3) then hits its own two banks
+//    whatever c is: eight conflict-free gathers = 16 LDS cycles per 64 nodes instead of ~56, and the address is one
+//    v_perm_b32 (the code byte lands on bits 8..15).  A lane owns its accumulator (32 bits: no saturation tricks, QT = 250
+//    units instead of the batched scan's 64).
+//  * the changed bytes never touch LDS: a lane loads the <= 8 bytes of each of its next four nodes with FOUR unaligned
+//    8-byte global loads at exactly the node's byte offset (the wave prefix sum of the masks' popcounts gives a lane's
+//    offset in the phase, the popcounts of its own earlier masks the rest), a phase ahead.  No row parking, no
+//    funnel shifts, no 6.5 KB of rows per wavefront.
+//  * the byte-permute selectors (the decoder[256] of main:312-325) come from a 16-entry NIBBLE table, also stored once
+//    per bank (2 KB): low half = perm(parent.x, raw.x, sel[mask & 15]), high half = perm(parent.y, raw >> 8 popc(low), ...).
+// What stays in LDS is the reference's stack machine itself (h:2888-2905): the ancestor stacks [level][lane] x 8 B, one
+// conflict-free read (the parent) and one write per node.  Per 64 nodes: 13 LDS instructions, ~28 LDS issue cycles
+// (2 + 4 + 6 + 16) against ~84.
+// One workgroup of 16 wavefronts per CU (138 KB of LDS: the bound rows, the selectors, 4 KB of stack per wavefront, the
+// exact table for the rare exact sums).
+// In-kernel threshold tightening: one pass over the whole shard at the bootstrap's threshold would admit every node
+// below it (rank ~30 K on 125 M codes).  Candidates are counted in a global histogram by the bound-table unit their
+// distance falls under; a wavefront looks at it when it starts a strip (and a few times inside its first): once top_k
+// candidates lie under a cut of e units the final k-th key cannot lie above it -- the wavefront lowers ITS cut (an SGPR)
+// and its threshold key.  Thresholds only tighten and every one is an upper bound of the final k-th key, so the result
+// does not depend on when a wavefront looks or how fresh the counts are.
+// grid = (workgroups <= 256, slots), block = 1024; a.seg_list / a.n_seg_pass name strips.
+// ---------------------------------------------------------------------------
+#ifndef DPQ_S1_QT
+#define DPQ_S1_QT 250  // units of the bound table that span (tau' - sum of minima); entries saturate at 255
+#endif
+#ifndef DPQ_S1_DEPTH
+#define DPQ_S1_DEPTH 1  // phases the changed bytes are fetched ahead of their decode (headers: two more)
+#endif
+constexpr int kS1Threads = 1024, kS1Waves = kS1Threads / 64;
+constexpr int kS1Buckets = 256;  // histogram words per slot (a.tight_hist)
+static_assert(DPQ_S1_QT + 2 <= kS1Buckets && DPQ_S1_QT <= 253, "cuts are bucket indices; 8 entries of 255 must reject");
+
+struct S1Lds {
+    static constexpr size_t kTq = 0;                                          // [256][32] x 8 B bound rows
+    static constexpr size_t kSel = kTq + 256 * 32 * 8;                        // [16][32] x 4 B nibble selectors
+    static constexpr size_t kStack = kSel + 16 * 32 * 4;                      // [waves][8][64] x 8 B ancestor stacks
+    static constexpr size_t kT32 = kStack + (size_t)kS1Waves * 8 * 64 * 8;    // [8][256] f32 exact table
+    static constexpr size_t kBytes = kT32 + 8 * 256 * 4;
+};
+static_assert(S1Lds::kBytes <= 160 * 1024 && S1Lds::kTq == 0, "one workgroup per CU; the bound rows sit at LDS offset 0");
+
+// LDS accesses by BYTE OFFSET (this kernel has no static LDS: its dynamic LDS starts at offset 0, checked in the
+// prologue): the bound rows' addresses are built with v_perm_b32 and must reach ds_read_b64 as they are
+#define DPQ_LDS __attribute__((address_space(3)))
+__device__ __forceinline__ uint2 lds_ld64(uint32_t off) {
+    const uint64_t v = *(const DPQ_LDS uint64_t*)(uintptr_t)off;
+    return make_uint2((uint32_t)v, (uint32_t)(v >> 32));
+}
+__device__ __forceinline__ uint32_t lds_ld32(uint32_t off) { return *(const DPQ_LDS uint32_t*)(uintptr_t)off; }
+__device__ __forceinline__ void lds_st64(uint32_t off, uint2 v) { *(DPQ_LDS uint64_t*)(uintptr_t)off = ((uint64_t)v.y << 32) | v.x; }
+// a whole 8-byte row although one half is used: a ds_read_b64 of 32 lanes covers all 64 banks with (lane mod 32) * 8;
+// narrowed to ds_read_b32 the same addresses would meet two to a bank
+__device__ __forceinline__ uint2 lds_ld64_whole(uint32_t off) {
+    const uint64_t v = *(const volatile DPQ_LDS uint64_t*)(uintptr_t)off;
+    return make_uint2((uint32_t)v, (uint32_t)(v >> 32));
+}
+
+// v_perm_b32 selector of a mask nibble: byte i = rank of bit i among the set bits (take the i-th changed byte) where the
+// bit is set, 4 + i (keep the parent's byte) elsewhere.  perm(parent, raw, sel).
+__device__ __forceinline__ uint32_t s1_nibble_sel(uint32_t nib) {
+    uint32_t sel = 0, rank = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const bool set = (nib >> i) & 1u;
+        sel |= (set ? rank : 4u + i) << (8 * i);
+        rank += set ? 1u : 0u;
+    }
+    return sel;
+}
+
+__global__ __launch_bounds__(kS1Threads) void strand1_kernel(const ScanArgs a) {
+    constexpr int M = 8, TE = M * 256, GROUPS = kRunLen / kPhaseLen, D = DPQ_S1_DEPTH, QT = DPQ_S1_QT;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int slot = blockIdx.y;
+    const int qq = a.slot_query ? (slot < a.n_queries ? a.slot_query[slot] : -1) : (slot < a.n_queries ? slot : -1);
+    if (qq < 0) return;  // block-uniform: a slot nobody asks for
+    if ((uint32_t)(uintptr_t)(DPQ_LDS unsigned char*)smem != 0u) __builtin_trap();  // (see lds_ld64: offsets are addresses)
+    uint64_t thr = a.thr_key[slot];  // wave-uniform; only ever lowered
+    // scale of the bound table (filter_scale with this kernel's QT): s32 = QT / (tau' - B) (1 - 2^-20), tau' = tau (1 + 2^-20)
+    FilterScale fs{0.0f, 0u, 0.0};
+    float min_m[M];
+    {
+        double B = 0.0;
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+            min_m[m] = lut_min_of(a.lut_min, (size_t)qq, M, m);
+            B += (double)min_m[m];
+        }
+        const double taup = (double)__uint_as_float((uint32_t)(thr >> 32)) * (1.0 + 0x1p-20);
+        const double R = taup - B;
+        fs.B = B;
+        if (thr != ~0ull && R > 0.0 && R < 1e300) fs.s32 = (float)((double)QT / R * (1.0 - 0x1p-20));  // else: everything passes the bound
+    }
+    const float sc = fs.s32, bdn = __double2float_rd(fs.B);
+    uint32_t* hist = a.tight_hist && sc != 0.0f ? a.tight_hist + (size_t)slot * kS1Buckets : nullptr;
+    int cut = QT;  // wave-uniform: a node passes the bound iff its sum <= cut + 1
+
+    // ---- prologue: exact table, selectors, bound rows ----
+    float* T32 = reinterpret_cast<float*>(smem + S1Lds::kT32);
+    {
+        const float* src = a.lut32 + (size_t)qq * TE;
+        T32[tid] = src[tid];
+        T32[tid + kS1Threads] = src[tid + kS1Threads];
+        if (tid < 16 * 32) reinterpret_cast<uint32_t*>(smem + S1Lds::kSel)[tid] = s1_nibble_sel((uint32_t)tid >> 5);
+        __syncthreads();
+        uint2* qtmp = reinterpret_cast<uint2*>(smem + S1Lds::kStack);  // the stacks' space, until the loop starts
+        if (tid < 256) {
+            uint32_t lo = 0, hi = 0;
+#pragma unroll
+            for (int m = 0; m < M; ++m) {
+                // as the scan's filter_field: half a unit off first, so whichever way v_cvt_pk_u8_f32 rounds the byte is
+                // <= floor((T - min) s): the entry stays a lower bound; it clamps to [0, 255] (inf of centroids beyond K: 255)
+                const float of = filter_offset<M>(fs, min_m[m], 1);
+                const float fv = fminf(__fmaf_rn(T32[m * 256 + tid], sc, of), 255.0f);
+                if (m < 4)
+                    lo = __builtin_amdgcn_cvt_pk_u8_f32(fv, (uint32_t)m, lo);
+                else
+                    hi = __builtin_amdgcn_cvt_pk_u8_f32(fv, (uint32_t)(m - 4), hi);
+            }
+            qtmp[tid] = make_uint2(lo, hi);
+        }
+        __syncthreads();
+        uint2* Tq = reinterpret_cast<uint2*>(smem + S1Lds::kTq);
+#pragma unroll
+        for (int i = 0; i < 256 * 32 / kS1Threads; ++i) Tq[tid + i * kS1Threads] = qtmp[(tid + i * kS1Threads) >> 5];
+        __syncthreads();
+    }
+
+    // LDS byte offsets a lane uses all along
+    const uint32_t lane8 = (uint32_t)(lane & 31) * 8u;                                             // its copy of a bound row
+    const uint32_t lane_sel = (uint32_t)S1Lds::kSel + (uint32_t)(lane & 31) * 4u;                  // ... of a selector
+    // row -1 of its stack column: depth 0 (the root, mask 0xFF: every byte replaced) reads a parent that does not matter
+    // from the 512 bytes in front of the stack -- the previous wavefront's row 7 or the end of the selectors: valid LDS
+    const uint32_t lane_stk = (uint32_t)S1Lds::kStack + (uint32_t)wave * (8 * 64 * 8) + (uint32_t)lane * 8u - 512u;
+
+    // ---- looks at the candidate histogram (in-kernel tightening) ----
+    // bucket e counts candidates whose distance lies under a cut of e units (see the exact check below); the smallest e
+    // whose running count reaches top_k is a valid cut: the k-th best key seen is <= the key of that cut
+    auto look = [&]() {
+        const uint32_t* h = hist + lane * 4;
+        uint32_t v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = __hip_atomic_load(h + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t s = v[0] + v[1] + v[2] + v[3];
+        uint32_t incl = s;  // inclusive prefix over the lanes
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t up = (uint32_t)__shfl_up((int)incl, o);
+            if (lane >= o) incl += up;
+        }
+        const uint64_t ge = __ballot(incl >= (uint32_t)a.tight_k);
+        if (ge == 0) return;
+        const int L = __ffsll((unsigned long long)ge) - 1;
+        uint32_t run = (uint32_t)__builtin_amdgcn_readlane((int)(incl - s), L);
+        int e = 4 * L;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            run += (uint32_t)__builtin_amdgcn_readlane((int)v[j], L);
+            if (run >= (uint32_t)a.tight_k) break;
+            ++e;
+        }
+        if (e < cut) {
+            cut = e;
+            // the cut in distance terms: a candidate counted under <= e units has d <= t2 (exact check below)
+            const double t2 = ((double)bdn + (double)e / (double)sc) / (1.0 + 0x1p-20);
+            const uint64_t key = ((uint64_t)__float_as_uint(__double2float_ru(t2)) << 32) | 0xffffffffull;
+            if (key < thr) thr = key;
+        }
+    };
+
+    const int n_waves = (int)gridDim.x * kS1Waves;
+    bool first_strip = true;
+    // strips are dealt to the workgroups first (a short list still reaches every CU), then to their wavefronts
+    for (int entry = (int)blockIdx.x + (int)gridDim.x * wave; entry < a.n_seg_pass; entry += n_waves) {
+        const int64_t sid = __builtin_amdgcn_readfirstlane(a.seg_list ? (int)a.seg_list[entry] : entry);
+        if (hist) look();  // the pipeline is empty here: the look costs its own latency only
+        // the runs' ancestor stacks (h:2858-2862), and where the strip's phases start (16-byte units)
+        const uint32_t pb = a.img.st_pbase[sid * GROUPS + min(lane, GROUPS)];
+#pragma unroll
+        for (int lv = 0; lv < 8; ++lv) {
+            const uint64_t c = a.img.st_ckpt[(sid * 8 + lv) * 64 + lane];
+            lds_st64(lane_stk + 512u * (lv + 1), make_uint2((uint32_t)c, (uint32_t)(c >> 32)));
+        }
+        struct Hdr {
+            uint32_t masks, depths;  // the lane's next four nodes: a mask byte and a depth nibble each
+        };
+        struct Bytes {
+            uint2 w[kPhaseLen];  // the (up to) eight changed bytes of each of them, from the node's first byte on
+        };
+        auto load_hdr = [&](int g) -> Hdr {
+            const int gc = min(g, GROUPS - 1);  // (past the strip: the last phase again, never used)
+            return Hdr{a.img.st_mask[(sid * GROUPS + gc) * 64 + lane], (uint32_t)a.img.st_depth[(sid * GROUPS + gc) * 64 + lane]};
+        };
+        auto load_bytes = [&](int g, const Hdr& h) -> Bytes {
+            const int gc = min(g, GROUPS - 1);
+            // where the lane's bytes start in the phase (lane after lane): wave prefix sum of the lanes' byte counts
+            const uint32_t mine = (uint32_t)__popc(h.masks);  // <= 32
+            uint32_t off = 0;
+#pragma unroll
+            for (int bit = 5; bit >= 0; --bit) off = mbcnt64(__ballot((mine >> bit) & 1u), off << 1);
+            const unsigned char* base = a.img.st_delta + (size_t)(uint32_t)__builtin_amdgcn_readlane((int)pb, gc) * 16;
+            const uint32_t o1 = off + (uint32_t)__popc(h.masks & 0xffu), o2 = off + (uint32_t)__popc(h.masks & 0xffffu),
+                           o3 = off + (uint32_t)__popc(h.masks & 0xffffffu);
+            Bytes r;
+            __builtin_memcpy(&r.w[0], base + off, 8);  // byte addresses: unaligned 8-byte loads
+            __builtin_memcpy(&r.w[1], base + o1, 8);
+            __builtin_memcpy(&r.w[2], base + o2, 8);
+            __builtin_memcpy(&r.w[3], base + o3, 8);
+            return r;
+        };
+        Hdr hq[D + 2];
+        Bytes bq[D + 1];
+#pragma unroll
+        for (int i = 0; i < D + 2; ++i) hq[i] = load_hdr(i);
+#pragma unroll
+        for (int i = 0; i < D; ++i) bq[i] = load_bytes(i, hq[i]);
+#pragma unroll 1
+        for (int g = 0; g < GROUPS; ++g) {
+            if (hist && first_strip && (g == 1 || g == 2 || g == 4 || g == 8)) look();  // (drains the prefetches: first strip only)
+            const Hdr h_new = load_hdr(g + D + 2);
+            bq[D] = load_bytes(g + D, hq[D]);
+            const Hdr hdr = hq[0];
+            uint32_t codes[kPhaseLen][2], sum[kPhaseLen];
+#pragma unroll
+            for (int st = 0; st < kPhaseLen; ++st) {
+                // the reference's stack machine (h:2888-2905): code = stack[depth - 1] with the masked positions replaced
+                const uint32_t depth = (hdr.depths >> (4 * st)) & 0xfu;
+                const uint32_t lo = (hdr.masks >> (8 * st)) & 0xfu, hi = (hdr.masks >> (8 * st + 4)) & 0xfu;
+                const uint32_t paddr = (depth << 9) + lane_stk;
+                const uint2 parent = lds_ld64(paddr);
+                const uint32_t sel_lo = lds_ld32((lo << 7) + lane_sel), sel_hi = lds_ld32((hi << 7) + lane_sel);
+                const uint2 raw = bq[0].w[st];
+                const uint32_t raw_hi = (uint32_t)((((uint64_t)raw.y << 32) | raw.x) >> (8 * __popc(lo)));
+                uint32_t* code = codes[st];
+                code[0] = __builtin_amdgcn_perm(parent.x, raw.x, sel_lo);
+                code[1] = __builtin_amdgcn_perm(parent.y, raw_hi, sel_hi);
+                lds_st64(paddr + 512u, make_uint2(code[0], code[1]));  // stack[depth] = code
+                // ADC, lower bound: sum of the eight entries; row of code byte c at c << 8, the lane's copy at lane8
+                uint32_t acc = 0;
+#pragma unroll
+                for (int m = 0; m < M; ++m) {
+                    const uint32_t row = __builtin_amdgcn_perm(code[m >> 2], lane8, 0x0c0c0400u + ((uint32_t)(m & 3) << 8));
+                    const uint2 e = lds_ld64_whole(row);
+                    acc = __builtin_amdgcn_udot4(m < 4 ? e.x : e.y, 1u << (8 * (m & 3)), acc, false);
+                }
+                sum[st] = acc;
+            }
+            // what the bound lets through: the reference's distance and the whole (distance, id) key
+            const uint32_t cutp = (uint32_t)cut + 1u;
+            if (__ballot(min(min(sum[0], sum[1]), min(sum[2], sum[3])) <= cutp)) {
+#pragma unroll
+                for (int st = 0; st < kPhaseLen; ++st) {
+                    const uint32_t c0 = codes[st][0], c1 = codes[st][1], sm = sum[st];
+                    const int64_t node = sid * kStripNodes + lane * kRunLen + g * kPhaseLen + st;
+                    bool pass = sm <= cutp && node < a.img.n_local;
+                    const uint64_t checked = __ballot(pass);
+                    if (checked == 0) continue;  // wave-uniform
+                    uint64_t key = 0;
+                    float d = 0.0f;
+                    if (pass) {
+                        const uint32_t c[2] = {c0, c1};
+                        double dsum = 0.0;
+#pragma unroll
+                        for (int m = 0; m < M; ++m) dsum = __dadd_rn(dsum, (double)T32[m * 256 + ((c[m >> 2] >> (8 * (m & 3))) & 0xffu)]);
+                        d = (float)dsum;
+                        key = make_key(d, a.img.id_base + (uint32_t)node);
+                        pass = key <= thr;
+                    }
+                    const uint64_t found = __ballot(pass);
+                    if (a.counters && lane == 0) {
+                        atomicAdd(a.counters, (unsigned long long)__popcll(checked));
+                        atomicAdd(a.counters + 1, (unsigned long long)__popcll(found));
+                    }
+                    if (found == 0) continue;
+                    uint32_t* count = a.cand_count + (size_t)slot * kRegionStride + 1;  // the slot's single region
+                    uint64_t* region = a.cand_key + (size_t)slot * a.cand_stride + a.region_off;
+                    uint32_t base = 0;
+                    if (lane == 0) base = atomicAdd(count, (uint32_t)__popcll(found));
+                    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                    const uint32_t li = base + mbcnt64(found, 0);
+                    if (pass && li < (uint32_t)a.region_cap) region[li] = key;
+                    if (hist && pass) {
+                        // the candidate's distance in units of the bound table, rounded against it (as scan_kernel's
+                        // tightening: the roundings are below 1e-4 units, the margin 2e-3): it lies under a cut of e units
+                        const float u = __fmaf_rn(d * sc, 0x1.000002p-20f, (d - bdn) * sc);
+                        const int e = max((int)(u + 2e-3f) + 1, 0);
+                        if (e < cut) atomicAdd(hist + e, 1u);
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < D + 1; ++i) hq[i] = hq[i + 1];
+            hq[D + 1] = h_new;
+#pragma unroll
+            for (int i = 0; i < D; ++i) bq[i] = bq[i + 1];
+        }
+        first_strip = false;
     }
 }
 
@@ -2586,11 +2904,22 @@ static hipError_t launch_strand_q(const ScanArgs& a, int n_slots, hipStream_t st
     return hipGetLastError();
 }
 
+// One query per pass: the bound-table kernel.  One workgroup of 16 wavefronts per CU; strips go to the workgroups
+// first, so a short list still reaches every CU.
+static hipError_t launch_strand1(const ScanArgs& a, int n_slots, hipStream_t stream) {
+    static std::atomic<bool> done[64] = {};
+    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&strand1_kernel), S1Lds::kBytes, done);
+    if (e != hipSuccess) return e;
+    const int wgs = std::max(1, std::min(256, a.n_seg_pass));
+    hipLaunchKernelGGL(strand1_kernel, dim3((unsigned)wgs, (unsigned)n_slots), dim3(kS1Threads), S1Lds::kBytes, stream, a);
+    return hipGetLastError();
+}
+
 hipError_t launch_strand(const ScanArgs& a, int n_slots, hipStream_t stream) {
     if (a.n_seg_pass <= 0 || n_slots <= 0) return hipSuccess;
     if (a.img.M != 8 || !a.img.st_ckpt) return hipErrorInvalidValue;
     switch (stream_queries_per_pass(8, n_slots)) {
-        case 1: return launch_strand_q<1>(a, n_slots, stream);
+        case 1: return a.debug_pass == 3 ? launch_strand_q<1>(a, n_slots, stream) : launch_strand1(a, n_slots, stream);
         case 2: return launch_strand_q<2>(a, n_slots, stream);
         default: return launch_strand_q<4>(a, n_slots, stream);
     }

@@ -135,6 +135,8 @@ typedef struct dpq_open_opts {
                                      * take the wavefront-per-chunk decode; saves ~1.2 x the payload in HBM)  [DPQ_STRANDS=0] */
 #define DPQ_OPT_FORCE_STRANDS 64u   /* that layout for every small batch, whatever the shard size (by default from 8 M codes per
                                      * GPU): tests, experiments  [DPQ_STRANDS=2] */
+#define DPQ_OPT_NO_STRAND1 128u      /* one query per pass over that layout takes the exact-table kernel (strand_kernel<1>) instead of
+                                     * the bound-table kernel with in-kernel tightening (strand1_kernel)  [DPQ_STRAND1=0] */
 
 typedef struct dpq_info {
     int64_t n_codes_total;     /* N of the whole index (header field 0, h:1839-1840) */
@@ -153,6 +155,8 @@ typedef struct dpq_info {
     int32_t bootstrap_stride;  /* every bootstrap_stride-th node is in it */
     int32_t batch_decode_mb;   /* MB of plain-code scratch (one tile, per pipeline lane) a batch decodes into; 0 = this
                                 * handle always decodes inside the scan */
+    int64_t strand_bytes;      /* HBM bytes of the strand image (the stream pass's own layout of the same nodes, resident
+                                * beside the SoA image on shards from 8 M codes); 0 = not built */
 } dpq_info;
 
 /* Per-kernel device time accumulated since the last dpq_profile_reset, measured
@@ -170,6 +174,10 @@ typedef struct dpq_profile {
     double decode_ms;                  /* per-batch decodes into the plain-code scratch (dpq_profile_enable(idx, 1) only) */
     double bootstrap_ms;               /* threshold bootstrap launches (NOT part of select_ms; dpq_profile_enable(idx, 1) only) */
     int64_t bootstrap_launches;
+    /* which kernel the stream pass (batches of up to stream_max_queries) ran, launch by launch (all three are also
+     * counted in scan_launches / scan_ms): wavefront per chunk, lane per run with exact tables, lane per run with the
+     * one-query bound table */
+    int64_t stream_launches, strand_launches, strand1_launches;
 } dpq_profile;
 
 typedef struct dpq_dtc_stats {
@@ -209,8 +217,9 @@ int dpq_soa_info(const dpq_soa* soa, dpq_info* info);
 /* Borrowed pointers into the image (valid until dpq_soa_free):
  * which = 0 depth nibbles, 1 masks, 2 deltas, 3 segment delta offsets (u64[n_seg+1]),
  * 4 segment ancestor checkpoints (u8[n_seg][levels][M]), 5-7 the bootstrap multi-index (cell starts, codes, ids),
- * 8 parent lanes, 9 carry lanes, 10-14 the strand image of the stream pass (checkpoints u64[strips][8][64], headers
- * u64[strips][16][64], phase offsets u16[strips][16][64], phase starts u32[strips*16+1] in 16-byte units, changed bytes). */
+ * 8 parent lanes, 9 carry lanes, 10-14 the strand image of the stream pass (checkpoints u64[strips][8][64],
+ * mask bytes u32[strips][16][64] (four nodes each), phase offsets u16[strips][16][64], phase starts u32[strips*16+1] in
+ * 16-byte units, changed bytes), 15 the strand image's depth nibbles u16[strips][16][64] (four nodes each). */
 int dpq_soa_array(const dpq_soa* soa, int which, const void** ptr, int64_t* n_bytes);
 void dpq_soa_free(dpq_soa* soa);
 /* Serialise a tree given as per-node arrays into the reference DTC payload

@@ -31,8 +31,8 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
 def test_struct_layouts_match_header(lib):
     from deltapq_amd import _lib
     assert ctypes.sizeof(_lib.OpenOpts) == 48 + 8 * 4 + 8
-    assert ctypes.sizeof(_lib.Info) == 7 * 8 + 8 * 4 + 8 + 2 * 4
-    assert ctypes.sizeof(_lib.Profile) == 3 * 8 + 10 * 8 + 2 * 8 + 2 * 8
+    assert ctypes.sizeof(_lib.Info) == 7 * 8 + 8 * 4 + 8 + 2 * 4 + 8
+    assert ctypes.sizeof(_lib.Profile) == 3 * 8 + 10 * 8 + 2 * 8 + 2 * 8 + 3 * 8
     assert ctypes.sizeof(_lib.DtcStats) == 3 * 8 + 16 * 8 + 2 * 4
 
 

@@ -230,11 +230,12 @@ def test_bootstrap_multi_index_layout(lib, stride, shards, n):
 
 def decode_strands(soa, n_local):
     """The strand image as strand_kernel reads it: per strip 64 lanes, each running the reference's stack machine
-    (h:2876-2905) over its 64 nodes -- header (mask | depth << 8) four to an 8-byte word, the changed bytes of a
+    (h:2876-2905) over its 64 nodes -- four mask bytes to a dword and four depth nibbles to a halfword, the changed bytes of a
     four-step phase at st_pbase (16-byte units) + st_poff, ancestor stacks from st_ckpt [strip][level][lane]."""
     n_strips = len(soa.st_ckpt) // (8 * 64)
     out = np.zeros((n_strips * 4096, 8), dtype=np.uint8)
-    hdr = soa.st_hdr.view(np.uint16).reshape(n_strips, 16, 64, 4)
+    masks = soa.st_mask.reshape(n_strips, 16, 64)
+    depths = soa.st_depth.reshape(n_strips, 16, 64)
     ck = soa.st_ckpt.view(np.uint8).reshape(n_strips, 8, 64, 8)
     poff = soa.st_poff.reshape(n_strips, 16, 64)
     for s in range(n_strips):
@@ -243,8 +244,7 @@ def decode_strands(soa, n_local):
             for g in range(16):
                 ptr = int(soa.st_pbase[s * 16 + g]) * 16 + int(poff[s, g, lane])
                 for st in range(4):
-                    hw = int(hdr[s, g, lane, st])
-                    mask, depth = hw & 0xFF, hw >> 8
+                    mask, depth = int(masks[s, g, lane]) >> (8 * st) & 0xFF, int(depths[s, g, lane]) >> (4 * st) & 0xF
                     code = stack[max(depth, 1) - 1].copy()
                     for m in range(8):
                         if mask >> m & 1:
@@ -268,7 +268,8 @@ def test_strand_image_is_lossless(lib, n, shards):
         soa = api.HostSoA(payload, n, 8, shard_rank=r, shard_count=shards, multi_index_stride=1)
         lo, hi = soa.info["node_lo"], soa.info["node_hi"]
         n_strips = -(-(hi - lo) // 4096)
-        assert len(soa.st_ckpt) == n_strips * 8 * 64 and len(soa.st_hdr) == n_strips * 16 * 64 and len(soa.st_pbase) == n_strips * 16 + 1
+        assert len(soa.st_ckpt) == n_strips * 8 * 64 and len(soa.st_mask) == n_strips * 16 * 64 and len(soa.st_pbase) == n_strips * 16 + 1
+        assert len(soa.st_depth) == n_strips * 16 * 64
         assert np.all(np.diff(soa.st_pbase.astype(np.int64)) * 16 <= 2048) and len(soa.st_delta) == int(soa.st_pbase[-1]) * 16 + 48
         assert np.array_equal(decode_strands(soa, hi - lo), codes[lo:hi])
     # without the multi-index (small shards, bootstrap off) there is no strand image
@@ -327,3 +328,64 @@ def test_codes_plain_other_record_layouts(lib, tmp_path):
     assert i is None and c.dtype == np.uint16 and np.array_equal(c, wide)
     with pytest.raises(api.DpqError):
         api.read_codes_plain_ex(p2, M, 1024, with_id=True)
+
+
+def _perm(src0, src1, sel):
+    """v_perm_b32: byte i of the result = byte sel_i of {src0 (4..7), src1 (0..3)}; 0x0c = zero."""
+    pool = [(src1 >> (8 * j)) & 0xFF for j in range(4)] + [(src0 >> (8 * j)) & 0xFF for j in range(4)]
+    out = 0
+    for i in range(4):
+        s = (sel >> (8 * i)) & 0xFF
+        out |= (0 if s == 0x0C else pool[s]) << (8 * i)
+    return out
+
+
+def _nibble_sel(nib):
+    sel, rank = 0, 0
+    for i in range(4):
+        sel |= (rank if nib >> i & 1 else 4 + i) << (8 * i)
+        rank += nib >> i & 1
+    return sel
+
+
+def decode_strands_like_strand1(soa, n_local):
+    """strand1_kernel's decode, instruction for instruction: a lane's byte offset in a phase = sum of the earlier lanes'
+    popcounts, each node's (up to) eight bytes read from ITS first byte on, low half = perm(parent.x, raw.x, sel[mask & 15]),
+    high half = perm(parent.y, raw >> 8 popc(mask & 15), sel[mask >> 4]), stack[depth] = code."""
+    n_strips = len(soa.st_ckpt) // (8 * 64)
+    out = np.zeros((n_strips * 4096, 8), dtype=np.uint8)
+    masks = soa.st_mask.reshape(n_strips, 16, 64)
+    depths = soa.st_depth.reshape(n_strips, 16, 64)
+    ck = soa.st_ckpt.reshape(n_strips, 8, 64)
+    delta = np.concatenate([soa.st_delta, np.zeros(16, np.uint8)])
+    for s in range(n_strips):
+        stack = [[int(ck[s, lv, lane]) for lane in range(64)] for lv in range(8)]
+        stack.insert(0, [0xDEADBEEFCAFEF00D] * 64)            # row -1: whatever the LDS holds in front of the stack
+        for g in range(16):
+            base = int(soa.st_pbase[s * 16 + g]) * 16
+            mine = [bin(int(masks[s, g, lane])).count("1") for lane in range(64)]
+            off = np.concatenate([[0], np.cumsum(mine)[:-1]])
+            for lane in range(64):
+                mk, dp = int(masks[s, g, lane]), int(depths[s, g, lane])
+                for st in range(4):
+                    o = base + int(off[lane]) + bin(mk & ((1 << (8 * st)) - 1)).count("1")
+                    raw = int.from_bytes(delta[o:o + 8].tobytes(), "little")
+                    lo, hi, depth = mk >> (8 * st) & 15, mk >> (8 * st + 4) & 15, dp >> (4 * st) & 15
+                    parent = stack[depth][lane]               # row depth - 1 of the real stack
+                    raw_hi = (raw >> (8 * bin(lo).count("1"))) & 0xFFFFFFFF
+                    c0 = _perm(parent & 0xFFFFFFFF, raw & 0xFFFFFFFF, _nibble_sel(lo))
+                    c1 = _perm(parent >> 32, raw_hi, _nibble_sel(hi))
+                    stack[depth + 1][lane] = c0 | c1 << 32
+                    out[s * 4096 + lane * 64 + g * 4 + st] = np.frombuffer((c0 | c1 << 32).to_bytes(8, "little"), np.uint8)
+    return out[:n_local]
+
+
+@pytest.mark.parametrize("n", [1, 4097, 20000])
+def test_strand1_decode_rules(lib, n):
+    """The one-query strand pass reads a node's bytes with one unaligned 8-byte load at the node's own offset and
+    scatters them with nibble selectors: the same codes as the reference's stack machine."""
+    from deltapq_amd import api, synth
+    tree, payload, nb = make_case(n, seed=n + 5)
+    codes = synth.decode_tree_codes(tree)
+    soa = api.HostSoA(payload, n, 8, multi_index_stride=1)
+    assert np.array_equal(decode_strands_like_strand1(soa, n), codes)

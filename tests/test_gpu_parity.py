@@ -631,7 +631,7 @@ def test_one_query_per_pass_matches_the_batched_path(gpu, oracle, n, M, k):
     for kw in ({}, {"shard_rank": 1, "shard_count": 2}):
         # flags = 64: DPQ_OPT_FORCE_STRANDS, the lane-per-run stream pass (strand_kernel) on shards far below the size from
         # which it is the default (M = 8 shards with a bootstrap have the image; the others run stream_kernel)
-        with gpu.DeltaPQIndex.open_memory(payload, n, M, 256, stream_max_queries=8, flags=64, **kw) as idx:
+        with gpu.DeltaPQIndex.open_memory(payload, n, M, 256, stream_max_queries=8, flags=gpu.OPT_FORCE_STRANDS, **kw) as idx:
             idx.set_codebook(cb)
             ids_b, d_b = idx.query_batch(qs, k)                # 70 queries: filter path
             got = [idx.query_batch(qs[lo:hi], k) for lo, hi in cuts]
@@ -657,6 +657,77 @@ def test_one_query_per_pass_matches_the_batched_path(gpu, oracle, n, M, k):
             assert_parity(ids_p, d_p, oracle_topk(oracle, payload, n, cb, qs[pick], k), n)
 
 
+@pytest.mark.parametrize("n,k,diffs,kw", [
+    (20_000, 10, 3.0, dict(bootstrap=1)),                                   # the smallest shard that can carry the strand image
+    (200_000, 50, 3.0, {}),
+    (200_000, 100, 0.4, {}),                                                # duplicate-heavy: thousands of equal keys at the cut
+    (2_300_000, 100, 3.0, {}),
+    (200_001, 20, 3.0, dict(num_codes=123_458)),                            # a prefix scan (even: the trailing id rule)
+    (200_000, 20, 3.0, dict(shard_rank=1, shard_count=3)),
+    (200_000, 20, 3.0, dict(global_offset=12_345_678, global_n_codes=1_000_000_000)),   # a part of a larger index
+])
+def test_one_query_strand_pass_with_the_bound_table(gpu, oracle, codebook, n, k, diffs, kw):
+    """strand1_kernel (one query per pass over the strand image): per-bank 8-bit bound rows, exact check of
+    what they let through, one level with in-kernel threshold tightening.  Every single-query call must return the list
+    the same query gets inside a 70-query batch (the filter path), bit for bit; also with the tightening off (the
+    multi-level plan) and through the exact-table kernel it replaces (DPQ_OPT_NO_STRAND1); and the oracle's list."""
+    from deltapq_amd import synth
+    tree = synth.synth_tree(n, 8, seed=n + k, mean_diffs=diffs)
+    payload, _ = synth.encode_dtc(tree)
+    qs = synth.make_queries(70, 128, seed=n + k + 1)
+    F = gpu.OPT_FORCE_STRANDS
+    with gpu.DeltaPQIndex.open_memory(payload, n, 8, 256, flags=F, **kw) as idx:
+        idx.set_codebook(codebook)
+        ids_b, d_b = idx.query_batch(qs, k)
+        idx.profile_enable(1)
+        idx.profile_reset()
+        singles = [idx.query_batch(qs[i:i + 1], k) for i in range(12)]
+        prof = idx.profile_read()
+    assert prof["strand1_launches"] == 12 and prof["strand_launches"] == 0 and prof["stream_launches"] == 0   # one level each
+    assert prof["overflow_reruns"] == 0
+    for i, (ids_s, d_s) in enumerate(singles):
+        assert np.array_equal(ids_s[0], ids_b[i]) and np.array_equal(d_s[0].view(np.uint32), d_b[i].view(np.uint32)), i
+    for flags in (F | gpu.OPT_NO_TIGHTEN, F | gpu.OPT_NO_STRAND1):
+        with gpu.DeltaPQIndex.open_memory(payload, n, 8, 256, flags=flags, **kw) as idx:
+            idx.set_codebook(codebook)
+            for i in (0, 5, 11):
+                ids_s, d_s = idx.query_batch(qs[i:i + 1], k)
+                assert np.array_equal(ids_s[0], ids_b[i]) and np.array_equal(d_s[0].view(np.uint32), d_b[i].view(np.uint32)), (flags, i)
+    if not kw or "bootstrap" in kw:
+        pick = [0, 3, 7, 11]
+        assert_parity(ids_b[pick], d_b[pick], oracle_topk(oracle, payload, n, codebook, qs[pick], k), n)
+    elif "num_codes" in kw:
+        n_scan = kw["num_codes"]
+        assert_parity(ids_b[:2], d_b[:2], oracle_topk(oracle, payload, n_scan, codebook, qs[:2], k), n_scan)
+
+
+def test_one_query_strand_pass_tightens_in_the_kernel(gpu, oracle, codebook):
+    """One level over the whole shard at the bootstrap's threshold would admit every node below it; the kernel lowers its
+    cut from the candidates all wavefronts have found: far fewer candidates than nodes under the first threshold, none
+    lost (the list equals the filter path's), no overflow rerun."""
+    from deltapq_amd import synth
+    n, k = 3_000_000, 100
+    tree = synth.synth_tree_large(n, 8, seed=77, mean_diffs=3.0)
+    payload, _ = synth.encode_dtc(tree)
+    qs = synth.make_queries(70, 128, seed=78)
+    res = {}
+    for flags in (gpu.OPT_FORCE_STRANDS, gpu.OPT_FORCE_STRANDS | gpu.OPT_NO_TIGHTEN):
+        with gpu.DeltaPQIndex.open_memory(payload, n, 8, 256, flags=flags, plan_ratios=[1, 0, 0] if flags & gpu.OPT_NO_TIGHTEN else [0, 0, 0]) as idx:
+            idx.set_codebook(codebook)
+            ids_b, d_b = idx.query_batch(qs, k)
+            idx.profile_enable(1)
+            idx.profile_reset()
+            got = [idx.query_batch(qs[i:i + 1], k) for i in range(8)]
+            res[flags] = (got, idx.profile_read())
+            for i, (ids_s, d_s) in enumerate(got):
+                assert np.array_equal(ids_s[0], ids_b[i]) and np.array_equal(d_s[0].view(np.uint32), d_b[i].view(np.uint32)), (flags, i)
+    on, off = res[gpu.OPT_FORCE_STRANDS][1], res[gpu.OPT_FORCE_STRANDS | gpu.OPT_NO_TIGHTEN][1]
+    assert on["strand1_launches"] == 8 and off["strand1_launches"] == 8          # one level either way (forced for `off`)
+    assert on["overflow_reruns"] == 0
+    assert on["candidates"] < 0.5 * off["candidates"], (on["candidates"], off["candidates"])
+    assert_parity(ids_b[:3], d_b[:3], oracle_topk(oracle, payload, n, codebook, qs[:3], k), n)
+
+
 @pytest.mark.parametrize("n,M,k,dup", [(300_000, 8, 100, False), (300_000, 8, 10, True), (150_000, 16, 50, False)])
 def test_in_scan_tightening_changes_nothing_but_the_work(gpu, oracle, n, M, k, dup):
     """dpq_open_opts.flags & DPQ_OPT_NO_TIGHTEN (16): a one-level filter scan that keeps the bootstrap's thresholds and
@@ -670,7 +741,7 @@ def test_in_scan_tightening_changes_nothing_but_the_work(gpu, oracle, n, M, k, d
     payload, _ = synth.encode_dtc(tree)
     qs = synth.make_queries(640, 128, seed=n + 1)
     res = {}
-    for flags in (0, 16):
+    for flags in (0, gpu.OPT_NO_TIGHTEN):
         with gpu.DeltaPQIndex.open_memory(payload, n, M, 256, flags=flags) as idx:
             idx.set_codebook(cb)
             idx.profile_enable(1)
@@ -699,7 +770,7 @@ def test_large_topk_takes_one_level_when_the_scan_tightens(gpu, oracle, M, k):
     payload, _ = synth.encode_dtc(tree)
     qs = synth.make_queries(640, 128, seed=k + 1)
     res = {}
-    for flags in (0, 16):
+    for flags in (0, gpu.OPT_NO_TIGHTEN):
         with gpu.DeltaPQIndex.open_memory(payload, n, M, 256, flags=flags) as idx:
             idx.set_codebook(cb)
             idx.profile_enable(1)
@@ -1183,7 +1254,7 @@ def test_stream_pass_on_a_prefix_and_on_a_part_of_a_larger_index(gpu, oracle, co
                dict(global_offset=1_000_000_000 - n if n_scan == n else 12_345_678, global_n_codes=1_000_000_000)):
         if "global_offset" in kw and n_scan != n and n_scan != 70_001:
             continue
-        with gpu.DeltaPQIndex.open_memory(payload, n, 8, 256, flags=64, bootstrap=1, **kw) as idx:
+        with gpu.DeltaPQIndex.open_memory(payload, n, 8, 256, flags=gpu.OPT_FORCE_STRANDS, bootstrap=1, **kw) as idx:
             idx.set_codebook(codebook)
             ids_b, d_b = idx.query_batch(qs, k)
             for lo, hi in ((0, 1), (3, 5), (10, 14)):
