@@ -68,21 +68,23 @@ def hbm_leg():
     (its own 125 M-code index; this process keeps its workload), its bench line condensed."""
     import subprocess
     cmd = [sys.executable, os.path.abspath(__file__), "--codes", "125000000", "--data", "stream", "--queries", "1", "--steps", "10",
-           "--warmup", "2", "--reps", "3", "--check", "2", "--no-cpu-baseline", "--sustain-seconds", "0", "--host-steps", "0", "--no-hbm-leg"]
+           "--warmup", "2", "--reps", "3", "--check", "4", "--min-check", "4", "--no-cpu-baseline", "--sustain-seconds", "0", "--host-steps", "0",
+           "--no-hbm-leg"]
     try:
-        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=HERE)
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=HERE)
         d = json.loads(r.stdout.strip().splitlines()[-1])
     except Exception as e:   # noqa: BLE001 -- the headline must not depend on this leg
         return {"error": repr(e)[:300]}
     ro = d["roofline"]
     return {"workload": d["config"]["workload"], "n_codes": d["config"]["n_codes"], "payload_bytes": d["config"]["n_bytes"],
             "queries_per_call": 1, "ms_per_call": d["ms_per_step"], "queries_per_s": d["value"],
-            "kernel": ro["kernel"], "bound": ro["bound"],
+            "kernel": ro["kernel"], "kernels_per_call": ro.get("stream_pass_launches_per_step"), "bound": ro["bound"],
             "achieved_GBps": ro["achieved"], "peak_GBps": ro["peak"], "frac": ro["frac"],
             "whole_call_GBps": d["config"]["n_bytes"] / (d["ms_per_step"] * 1e-3) / 1e9,
             "definition": "achieved = DTC payload bytes of the index / kernel time of the call's stream-pass launches (HIP events); "
                           "whole_call_GBps = the same bytes / the whole call (table build, bootstrap, three levels, selects)",
-            "traffic": ro.get("traffic"), "parity_checked_queries": d["parity_checked_queries"]}
+            "traffic": ro.get("traffic"), "parity_checked_queries": d["parity_checked_queries"],
+            "device_bytes": d["index"]["device_bytes_rank0"], "strand_image_bytes": d["index"].get("strand_bytes_rank0")}
 
 
 def make_queries(args, seed):
@@ -363,9 +365,21 @@ def main():
     # correctness gate before timing (rank 0, against the oracle)
     out_ids, out_dists = step(0)
     sync()
+    if nq == 1 and args.check > 1:
+        # one query per call: the gate wants several queries through that very path -- one call each
+        gate_q = np.concatenate([b[:1] for b in batches_np] + [make_queries(args, 900 + i)[:1] for i in range(max(0, args.check - N_BATCHES))])[:args.check]
+        g_ids, g_d = [], []
+        for i in range(len(gate_q)):
+            gi, gd = idx.query_batch(gate_q[i:i + 1], k)
+            g_ids.append(gi[0]), g_d.append(gd[0])
+        gate = (gate_q, np.stack(g_ids), np.stack(g_d))
+    else:
+        gate = None
     parity = 0
     if rank == 0 and args.check > 0:
-        if wl["whole"]:
+        if wl["whole"] and gate is not None:
+            parity = parity_gate(args, wl, gate[0], gate[1], gate[2])
+        elif wl["whole"]:
             parity = parity_gate(args, wl, batches_np[0], out_ids.cpu().numpy(), out_dists.cpu().numpy())
         else:   # own part of a larger index: the rank's partial lists (still in ids / dists) against the oracle on the part
             parity = parity_gate(args, wl, batches_np[0], ids.cpu().numpy(), dists.cpu().numpy())
@@ -491,7 +505,8 @@ def main():
     stats = torch.tensor([prof["scan_ms"], float(prof["scan_launches"]), float(info["algorithmic_bytes"]),
                           float(info["device_bytes"] + info["bootstrap_bytes"]), prof_aux["select_ms"], prof_aux["lut_ms"],
                           prof_aux["quantise_ms"], lds_bytes_step, float(prof_aux["exact_checks"]), float(prof_aux["candidates"]),
-                          float(info["node_hi"] - info["node_lo"]), prof_aux["decode_ms"]],
+                          float(info["node_hi"] - info["node_lo"]), prof_aux["decode_ms"], float(info["strand_bytes"]),
+                          float(prof_aux["stream_launches"]), float(prof_aux["strand_launches"]), float(prof_aux["strand1_launches"])],
                          dtype=torch.float64, device=torch.device("cpu") if cpu_coll else dev)
     if world > 1:
         all_stats = [torch.zeros_like(stats) for _ in range(world)]
@@ -601,7 +616,8 @@ def main():
                       "raw_pq_equivalent_GBps": global_q * args.steps / med * float(all_stats[:, 10].sum()) / (1 if sharded or world == 1 else world) * args.m / 1e9,
                       "note": "queries/s x codes each query is compared with (every code, exactly once); x M bytes = the bandwidth "
                               "a plain PQ scan would need at one query per pass"},
-            "index": {"device_bytes_rank0": int(all_stats[0, 3]), "segments_rank0": info["n_segments"],
+            "index": {"device_bytes_rank0": int(all_stats[0, 3] + all_stats[0, 12]), "strand_bytes_rank0": int(all_stats[0, 12]),
+                      "segments_rank0": info["n_segments"],
                       "codes_rank0": int(all_stats[0, 10]), "gen_seconds": wl["gen_s"]},
         }
         dev = os.environ.get("DPQ_DEV", "0") not in ("", "0")
@@ -613,9 +629,15 @@ def main():
             r = result["roofline"]
             per_pass = 1 if nq <= 1 else 2 if nq <= 2 else 4
             passes = -(-nq // per_pass)
-            strands = args.m == 8 and info["bootstrap_bytes"] > 0 and not (dev and os.environ.get("DPQ_STRANDS", "1") == "0")
+            # which kernels the stream pass's launches were (dpq_profile counts them): named as they ran, all of them
+            # when a call's levels mix
+            ran = {"stream_kernel": float(all_stats[0, 13]) / aux_steps, "strand_kernel": float(all_stats[0, 14]) / aux_steps,
+                   "strand1_kernel": float(all_stats[0, 15]) / aux_steps}
+            names = [n for n, c in ran.items() if c > 0]
+            strands = any(n.startswith("strand") for n in names)
             alg = (passes * alg_bytes_total) / (scan_ms_step * 1e-3) / 1e9 if scan_ms_step > 0 else 0.0
-            r.update({"bound": "hbm", "kernel": "strand_kernel" if strands else "stream_kernel", "achieved": alg, "peak": HBM_PEAK_GBPS * world,
+            r.update({"bound": "hbm", "kernel": " + ".join(names) if names else "stream_kernel", "stream_pass_launches_per_step": ran,
+                      "achieved": alg, "peak": HBM_PEAK_GBPS * world,
                       "frac": alg / (HBM_PEAK_GBPS * world),
                       "definition": "stream pass, %d quer%s per pass, %d pass(es): achieved = passes x DTC payload bytes (SURVEY.md 8(d): every "
                                     "pass streams the compressed index once) / kernel time of the pass's launches (HIP events on the launch "
@@ -625,7 +647,7 @@ def main():
             r.pop("lds_gather_bytes_per_step", None)
             r["algorithmic_hbm"]["note"] = ("queries x DTC payload bytes / kernel time: with %d quer%s per pass this is %d x the bytes the "
                                             "passes stream" % (per_pass, "y" if per_pass == 1 else "ies", per_pass))
-            result["config"]["decode"] = ("lane per run of 64 nodes over the strand image (strand_kernel)" if strands else
+            result["config"]["decode"] = ("lane per run of 64 nodes over the strand image (%s)" % " + ".join(names) if strands else
                                           "wavefront per 64-node chunk (stream_kernel)") + ", once per pass of %d quer%s" % (per_pass, "y" if per_pass == 1 else "ies")
             result["config"]["queries_per_decode_pass"] = per_pass
         if replicas:

@@ -95,7 +95,10 @@ struct Tuning {
     int select_threads = 0;  // select_kernel block size, 0 = by top_k  [DPQ_SELECT_THREADS]
     int64_t batch_tile_nodes = (int64_t)16 << 20;
     bool relabel = true, fuse_quantise = true, async_overlap = true, boot_fullsort = false, tighten = true, strands = true,
-         force_strands = false, strand1 = true;  // strand1: one query per pass takes strand1_kernel  [DPQ_STRAND1=0: strand_kernel<1>]
+         force_strands = false, strand1 = true;
+    int s1_debug = 0;  // developer experiments of strand1_kernel  [DPQ_S1_DEBUG]
+    int s1_scatter = 0;  // ... its one level in the low-discrepancy strip order instead of storage order  [DPQ_S1_SCATTER=1]
+    bool dummy_ = false;  // strand1: one query per pass takes strand1_kernel  [DPQ_STRAND1=0: strand_kernel<1>]
 };
 
 struct dpq_index {
@@ -125,6 +128,7 @@ struct dpq_index {
     bool boot = false;
     int boot_classes = 0;
     unsigned long long* d_boot_stamps = nullptr;  // developer diagnostics (dpq_debug_boot_stamps)
+    unsigned long long* d_s1_stamps = nullptr;    // developer diagnostics (dpq_debug_strand1_stamps)
     uint8_t* d_batch_raw = nullptr;  // active lane: the shard's plain codes, decoded once per batch (batch_decode)
     int batch_decode = 0;            // dpq_open_opts.batch_decode
     uint8_t* d_relabel = nullptr;    // [M][256] code value -> label in the plain-code scratch (bank-aware; NULL = code values)
@@ -252,6 +256,8 @@ Tuning resolve_tuning(const dpq_open_opts& o) {
         v = 1; geti("DPQ_STRANDS", &v); t.strands = t.strands && v != 0;
         t.force_strands = t.force_strands || v == 2;
         v = 1; geti("DPQ_STRAND1", &v); t.strand1 = t.strand1 && v != 0;
+        geti("DPQ_S1_DEBUG", &t.s1_debug);
+        geti("DPQ_S1_SCATTER", &t.s1_scatter);
     }
     return t;
 }
@@ -550,6 +556,9 @@ int run_batch(dpq_index* x, const float* d_queries, int nq, int top_k, int32_t* 
     int64_t stride = top_k;
     for (size_t l = 1; l < x->level_cnt.size(); ++l)
         stride = std::max(stride, regions_for(x, x->level_cnt[l], ngroups, top_k, cap).stride);
+    // strand1_kernel: a region per workgroup (no global atomics on the candidates' way): room for top_k keys each, 64..256
+    const int s1_region_cap = std::min(std::max(64, top_k), 256);
+    if (strand1) stride = std::max<int64_t>(stride, (int64_t)top_k + (int64_t)dpq::kStrand1Regions * s1_region_cap);
     if (stride > INT32_MAX) return fail(DPQ_ERR_NOMEM, "candidate buffer too large");
     if ((rc = ensure_workspace(x, nqp, (int)stride))) return rc;
     stride = x->ws_cap;
@@ -726,7 +735,8 @@ int run_batch(dpq_index* x, const float* d_queries, int nq, int top_k, int32_t* 
                     // strand1_kernel's candidate histogram: the first 256 words of the tightening counters (cleared by the
                     // table build); one launch per batch reads it (a later level would count in other units)
                     st.tight_hist = strand1_tight && x->level_cnt.size() == 2 ? x->d_overflow + x->ws_slots : nullptr;
-                    st.debug_pass = strand1 ? 0 : 3;
+                    st.debug_pass = strand1 ? (x->tune.s1_debug ? 16 + x->tune.s1_debug : 0) : 3;
+                    st.stamps = strand1 ? x->d_s1_stamps : nullptr;
                     Timer t(x, stream, 1);
                     // A level of few strips (one strip per wavefront: the launch takes a strip's 64 dependent steps
                     // however few there are) goes through the chunk-per-wavefront pass over the same nodes: measured
@@ -739,6 +749,12 @@ int run_batch(dpq_index* x, const float* d_queries, int nq, int top_k, int32_t* 
                     } else {
                         st.seg_list = x->d_strip_order + lo;
                         st.n_seg_pass = (int32_t)(hi - lo);
+                        if (strand1) {  // a region per workgroup, counts written by the kernel
+                            // one level: the strips in storage order (a workgroup sweeps a contiguous share)
+                            if (x->level_cnt.size() == 2 && !x->tune.s1_scatter) st.seg_list = nullptr;
+                            st.region_cap = se.region_cap = (int32_t)((stride - top_k) / dpq::kStrand1Regions);
+                            se.n_regions = 1 + dpq::strand1_workgroups(st.n_seg_pass);
+                        }
                         DPQ_HIP(dpq::launch_strand(st, nq, stream));
                         if (x->prof) (strand1 ? x->prof_acc.strand1_launches : x->prof_acc.strand_launches)++;
                     }
@@ -1674,6 +1690,7 @@ int dpq_close(dpq_index* x) {
     hipFree(x->d_st_depth);
     hipFree(x->d_st_pbase);
     hipFree(x->d_st_delta);
+    hipFree(x->d_s1_stamps);
     hipFree(x->d_strip_order);
     hipFree(x->d_strip_segs);
     hipFree(x->d_nib);
@@ -2147,6 +2164,25 @@ int dpq_debug_scan_stamps(dpq_index* x, int nq, int splits, unsigned long long* 
     hipFree(d_st);
     return DPQ_OK;
     });
+}
+
+// Developer hook: per-wavefront marks of strand1_kernel (100 MHz clock): [256 workgroups][16 wavefronts][16 marks] =
+// start, end of the prologue, end of each of the wavefront's first strips.  First call arms it; later calls copy out
+// the marks of the last one-query call on a strand image.
+int dpq_debug_strand1_stamps(dpq_index* x, unsigned long long* out, int n_words) {
+    if (!x || !out) return fail(DPQ_ERR_ARG, "NULL argument");
+    DPQ_HIP(hipSetDevice(x->device));
+    const size_t total = (size_t)256 * 16 * 16;
+    if (!x->d_s1_stamps) {
+        int rc = dev_alloc(&x->d_s1_stamps, total);
+        if (rc) return rc;
+        DPQ_HIP(hipMemset(x->d_s1_stamps, 0, total * 8));
+        return DPQ_OK;
+    }
+    DPQ_HIP(hipDeviceSynchronize());
+    DPQ_HIP(hipMemcpy(out, x->d_s1_stamps, std::min((size_t)std::max(n_words, 0), total) * 8, hipMemcpyDeviceToHost));
+    DPQ_HIP(hipMemset(x->d_s1_stamps, 0, total * 8));
+    return DPQ_OK;
 }
 
 // Developer hook (not in the public header): phase marks of the bootstrap kernel.  First call arms it

@@ -150,6 +150,10 @@ hipError_t launch_stream(const ScanArgs& a, int n_slots, hipStream_t stream);
 // The same pass over the strand image (M = 8, img.st_* set): a.seg_list / a.n_seg_pass name STRIPS here.
 hipError_t launch_strand(const ScanArgs& a, int n_slots, hipStream_t stream);
 int stream_queries_per_pass(int M, int n_slots);  // 1, 2, 4 or 8 (M = 16: at most 4)
+// One query per pass over the strand image (strand1_kernel): its workgroups, each with its own candidate region
+// (region 1 + w of the slot, a.region_cap keys, count published by the kernel).
+int strand1_workgroups(int n_strips);
+constexpr int kStrand1Regions = 256;
 hipError_t launch_quantise(const ScanArgs& a, int n_slot_groups, hipStream_t stream);
 hipError_t launch_scan(const ScanArgs& a, int n_slot_groups, int splits, hipStream_t stream);
 size_t qtab_bytes_per_group(int M);

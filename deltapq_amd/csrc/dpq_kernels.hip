@@ -1763,19 +1763,30 @@ __global__ __launch_bounds__(kStrandThreads, Q >= 4 ? 2 : Q == 2 ? 3 : 4) void s
 #ifndef DPQ_S1_QT
 #define DPQ_S1_QT 250  // units of the bound table that span (tau' - sum of minima); entries saturate at 255
 #endif
+#ifndef DPQ_S1_SKIP
+#define DPQ_S1_SKIP 0  // (timing experiments only, wrong results: 1 no ADC, 2 no stack / selector traffic, 4 no changed-byte loads)
+#endif
 #ifndef DPQ_S1_DEPTH
 #define DPQ_S1_DEPTH 1  // phases the changed bytes are fetched ahead of their decode (headers: two more)
 #endif
 constexpr int kS1Threads = 1024, kS1Waves = kS1Threads / 64;
-constexpr int kS1Buckets = 256;  // histogram words per slot (a.tight_hist)
-static_assert(DPQ_S1_QT + 2 <= kS1Buckets && DPQ_S1_QT <= 253, "cuts are bucket indices; 8 entries of 255 must reject");
+constexpr int kS1Buckets = 64;  // histogram words: bucket b = candidates under a cut of 4 b + 3 units
+// The global histogram (a.tight_hist, zero at launch) is kept in kS1Replicas copies 2 KB apart, a workgroup adds to copy
+// blockIdx % 8 and a look sums the copies: the few thousand adds of a launch's first microseconds otherwise queue up in
+// ONE memory channel, and every wavefront's in-order loads wait for the one that goes there.
+constexpr int kS1Replicas = 8, kS1ReplicaWords = 512;
+static_assert((DPQ_S1_QT >> 2) < kS1Buckets && DPQ_S1_QT <= 253, "a lane per bucket; 8 entries of 255 must reject");
 
 struct S1Lds {
     static constexpr size_t kTq = 0;                                          // [256][32] x 8 B bound rows
     static constexpr size_t kSel = kTq + 256 * 32 * 8;                        // [16][32] x 4 B nibble selectors
     static constexpr size_t kStack = kSel + 16 * 32 * 4;                      // [waves][8][64] x 8 B ancestor stacks
     static constexpr size_t kT32 = kStack + (size_t)kS1Waves * 8 * 64 * 8;    // [8][256] f32 exact table
-    static constexpr size_t kBytes = kT32 + 8 * 256 * 4;
+    // the workgroup's shared words: u32 cut, (pad), u64 threshold key, u32 candidates appended, u32 wavefronts done, u32 next strip, (pad),
+    // then [64] u32 candidate counts not yet moved to the global histogram
+    static constexpr size_t kShare = kT32 + 8 * 256 * 4;
+    static constexpr size_t kHist = kShare + 48;
+    static constexpr size_t kBytes = kHist + 64 * 4;
 };
 static_assert(S1Lds::kBytes <= 160 * 1024 && S1Lds::kTq == 0, "one workgroup per CU; the bound rows sit at LDS offset 0");
 
@@ -1808,6 +1819,18 @@ __device__ __forceinline__ uint32_t s1_nibble_sel(uint32_t nib) {
     return sel;
 }
 
+// inclusive prefix sum over the 64 lanes with DPP row shifts and row broadcasts (gfx9: the sequence LLVM's own wave
+// scan uses): 12 VALU operations, no LDS, no ballots
+__device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);  // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);  // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);  // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);  // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1 and 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);  // row_bcast:31 into rows 2 and 3
+    return v;
+}
+
 __global__ __launch_bounds__(kS1Threads) void strand1_kernel(const ScanArgs a) {
     constexpr int M = 8, TE = M * 256, GROUPS = kRunLen / kPhaseLen, D = DPQ_S1_DEPTH, QT = DPQ_S1_QT;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1817,6 +1840,20 @@ __global__ __launch_bounds__(kS1Threads) void strand1_kernel(const ScanArgs a) {
     if (qq < 0) return;  // block-uniform: a slot nobody asks for
     if ((uint32_t)(uintptr_t)(DPQ_LDS unsigned char*)smem != 0u) __builtin_trap();  // (see lds_ld64: offsets are addresses)
     uint64_t thr = a.thr_key[slot];  // wave-uniform; only ever lowered
+    // developer diagnostics (a.stamps NULL in every query call): per wavefront 16 marks on the 100 MHz clock -- start,
+    // end of the prologue, end of each of its first strips
+    unsigned long long* const stp = a.stamps ? a.stamps + ((size_t)blockIdx.x * kS1Waves + wave) * 16 : nullptr;
+    int n_stamp = 0;
+    unsigned long long slow_ticks = 0, slow_entries = 0;  // (diagnostics: time in and entries into the exact-check path)
+    auto stamp = [&]() {
+        if (stp && n_stamp < 14) {
+            // low 40 bits: the 100 MHz clock; high 24 bits: the shader clock / 1024 (clock rate between two marks)
+            const unsigned long long t = (__builtin_amdgcn_s_memrealtime() & 0xffffffffffull) | ((__builtin_amdgcn_s_memtime() >> 10) << 40);
+            if (lane == 0) stp[n_stamp] = t;
+            ++n_stamp;
+        }
+    };
+    stamp();
     // scale of the bound table (filter_scale with this kernel's QT): s32 = QT / (tau' - B) (1 - 2^-20), tau' = tau (1 + 2^-20)
     FilterScale fs{0.0f, 0u, 0.0};
     float min_m[M];
@@ -1833,7 +1870,10 @@ __global__ __launch_bounds__(kS1Threads) void strand1_kernel(const ScanArgs a) {
         if (thr != ~0ull && R > 0.0 && R < 1e300) fs.s32 = (float)((double)QT / R * (1.0 - 0x1p-20));  // else: everything passes the bound
     }
     const float sc = fs.s32, bdn = __double2float_rd(fs.B);
-    uint32_t* hist = a.tight_hist && sc != 0.0f ? a.tight_hist + (size_t)slot * kS1Buckets : nullptr;
+    // developer experiments (a.debug_pass >= 16, never in a query call): bit 0 nothing is checked exactly, bit 1 no looks
+    // inside the first strip, bit 2 no tightening
+    const int dbg = a.debug_pass >= 16 ? a.debug_pass - 16 : 0;
+    uint32_t* hist = a.tight_hist && sc != 0.0f && !(dbg & 4) ? a.tight_hist + (size_t)slot * (kS1Replicas * kS1ReplicaWords) : nullptr;
     int cut = QT;  // wave-uniform: a node passes the bound iff its sum <= cut + 1
 
     // ---- prologue: exact table, selectors, bound rows ----
@@ -1864,9 +1904,17 @@ __global__ __launch_bounds__(kS1Threads) void strand1_kernel(const ScanArgs a) {
         uint2* Tq = reinterpret_cast<uint2*>(smem + S1Lds::kTq);
 #pragma unroll
         for (int i = 0; i < 256 * 32 / kS1Threads; ++i) Tq[tid + i * kS1Threads] = qtmp[(tid + i * kS1Threads) >> 5];
+        if (tid == 0) {
+            *reinterpret_cast<uint32_t*>(smem + S1Lds::kShare) = (uint32_t)QT;
+            *reinterpret_cast<unsigned long long*>(smem + S1Lds::kShare + 8) = thr;
+            *reinterpret_cast<uint4*>(smem + S1Lds::kShare + 16) = make_uint4(0u, 0u, 0u, 0u);  // candidates, wavefronts done, next strip
+            *reinterpret_cast<uint4*>(smem + S1Lds::kShare + 32) = make_uint4(0u, 0u, 0u, 0u);  // statistics
+        }
+        if (tid < 64) reinterpret_cast<uint32_t*>(smem + S1Lds::kHist)[tid] = 0u;
         __syncthreads();
     }
 
+    stamp();
     // LDS byte offsets a lane uses all along
     const uint32_t lane8 = (uint32_t)(lane & 31) * 8u;                                             // its copy of a bound row
     const uint32_t lane_sel = (uint32_t)S1Lds::kSel + (uint32_t)(lane & 31) * 4u;                  // ... of a selector
@@ -1874,16 +1922,30 @@ __global__ __launch_bounds__(kS1Threads) void strand1_kernel(const ScanArgs a) {
     // from the 512 bytes in front of the stack -- the previous wavefront's row 7 or the end of the selectors: valid LDS
     const uint32_t lane_stk = (uint32_t)S1Lds::kStack + (uint32_t)wave * (8 * 64 * 8) + (uint32_t)lane * 8u - 512u;
 
-    // ---- looks at the candidate histogram (in-kernel tightening) ----
-    // bucket e counts candidates whose distance lies under a cut of e units (see the exact check below); the smallest e
-    // whose running count reaches top_k is a valid cut: the k-th best key seen is <= the key of that cut
+    // ---- in-kernel tightening: looks at the candidate histogram, the workgroup's cut in LDS ----
+    // bucket b counts candidates whose distance lies under a cut of 4 b + 3 units (see the exact check below); the first b
+    // whose running count reaches top_k gives a valid cut: the k-th best key seen so far is <= the key of that cut.
+    // A wavefront looks when it starts a strip (its pipeline is empty there) and once inside its first strip, the
+    // workgroup's wavefronts one phase after the other; what it finds goes to the workgroup's shared (cut, threshold key)
+    // in LDS with atomic minima, and every wavefront reads those once per phase.
+    DPQ_LDS uint32_t* const sh_cut = (DPQ_LDS uint32_t*)(uintptr_t)S1Lds::kShare;
+    DPQ_LDS unsigned long long* const sh_thr = (DPQ_LDS unsigned long long*)(uintptr_t)(S1Lds::kShare + 8);
+    DPQ_LDS uint32_t* const sh_count = (DPQ_LDS uint32_t*)(uintptr_t)(S1Lds::kShare + 16);
+    DPQ_LDS uint32_t* const sh_done = (DPQ_LDS uint32_t*)(uintptr_t)(S1Lds::kShare + 20);
+    DPQ_LDS uint32_t* const sh_next = (DPQ_LDS uint32_t*)(uintptr_t)(S1Lds::kShare + 24);
+    DPQ_LDS uint32_t* const sh_stat = (DPQ_LDS uint32_t*)(uintptr_t)(S1Lds::kShare + 32);  // [2] statistics
+    DPQ_LDS uint32_t* const sh_hist = (DPQ_LDS uint32_t*)(uintptr_t)S1Lds::kHist;
     auto look = [&]() {
-        const uint32_t* h = hist + lane * 4;
-        uint32_t v[4];
+        // the workgroup's counts since its last look go to the global histogram first: ONE add per bucket that has any.
+        // (Candidates never touch global counters themselves: a few thousand atomics on a handful of words were measured
+        // to cost every wavefront of the chip 70 us -- the words' memory channel queues up, and each wavefront's in-order
+        // loads wait for the one that goes there.)
+        const uint32_t mine = __hip_atomic_exchange(sh_hist + lane, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (mine) atomicAdd(hist + (blockIdx.x % kS1Replicas) * kS1ReplicaWords + lane, mine);
+        uint32_t v = 0;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = __hip_atomic_load(h + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const uint32_t s = v[0] + v[1] + v[2] + v[3];
-        uint32_t incl = s;  // inclusive prefix over the lanes
+        for (int r = 0; r < kS1Replicas; ++r) v += __hip_atomic_load(hist + r * kS1ReplicaWords + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        uint32_t incl = v;  // inclusive prefix over the lanes (= buckets)
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
             const uint32_t up = (uint32_t)__shfl_up((int)incl, o);
@@ -1891,30 +1953,50 @@ __global__ __launch_bounds__(kS1Threads) void strand1_kernel(const ScanArgs a) {
         }
         const uint64_t ge = __ballot(incl >= (uint32_t)a.tight_k);
         if (ge == 0) return;
-        const int L = __ffsll((unsigned long long)ge) - 1;
-        uint32_t run = (uint32_t)__builtin_amdgcn_readlane((int)(incl - s), L);
-        int e = 4 * L;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            run += (uint32_t)__builtin_amdgcn_readlane((int)v[j], L);
-            if (run >= (uint32_t)a.tight_k) break;
-            ++e;
-        }
+        const int e = 4 * (__ffsll((unsigned long long)ge) - 1) + 3;
         if (e < cut) {
-            cut = e;
             // the cut in distance terms: a candidate counted under <= e units has d <= t2 (exact check below)
             const double t2 = ((double)bdn + (double)e / (double)sc) / (1.0 + 0x1p-20);
             const uint64_t key = ((uint64_t)__float_as_uint(__double2float_ru(t2)) << 32) | 0xffffffffull;
-            if (key < thr) thr = key;
+            if (lane == 0) {
+                __hip_atomic_fetch_min(sh_cut, (uint32_t)e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_min(sh_thr, (unsigned long long)key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
         }
     };
+    auto refresh = [&]() {  // the workgroup's cut and threshold key: both only ever fall, each valid on its own
+        // (LDS loads by address space: through a generic pointer these were flat loads behind a full s_waitcnt vmcnt(0))
+        const uint32_t c = __hip_atomic_load(sh_cut, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const uint64_t t = __hip_atomic_load(sh_thr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        cut = min(cut, (int)__builtin_amdgcn_readfirstlane((int)c));
+        const uint64_t tu = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(t >> 32)) << 32) |
+                            (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)t);
+        thr = tu < thr ? tu : thr;
+    };
 
-    const int n_waves = (int)gridDim.x * kS1Waves;
-    bool first_strip = true;
-    // strips are dealt to the workgroups first (a short list still reaches every CU), then to their wavefronts
-    for (int entry = (int)blockIdx.x + (int)gridDim.x * wave; entry < a.n_seg_pass; entry += n_waves) {
+    uint32_t n_checked = 0, n_found = 0;  // statistics (a.counters)
+    int iter = 0;                         // strips this wavefront has done
+    bool first_strip = !(dbg & 2);
+    // A workgroup takes a CONTIGUOUS share of the launch's list and its sixteen wavefronts sweep it side by side: with
+    // the list in storage order (the one-level plan) a CU's sixty-four streams stay within a few hundred KB of each
+    // array at any time -- dealt out across the whole image instead (4096 x 4 streams over 1.5 GB), the first strips of
+    // a launch took twice the time of the last ones (address translation).  256 shares are still a spread sample of
+    // the shard at every moment, which is what the tightening wants.
+    // Its wavefronts DRAW their strips from an LDS counter: the four wavefronts of a SIMD do not advance at the same
+    // pace (instruction issue goes to the oldest first: the youngest took 1.6 x the time per strip), and with a fixed deal
+    // the fast ones sat idle for the last fifth of the launch.
+    const int per_wg = (a.n_seg_pass + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int wg_begin = (int)blockIdx.x * per_wg, wg_end = min(a.n_seg_pass, wg_begin + per_wg);
+    for (;;) {
+        uint32_t drawn = 0;
+        if (lane == 0) drawn = __hip_atomic_fetch_add(sh_next, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const int entry = wg_begin + __builtin_amdgcn_readfirstlane((int)drawn);
+        if (entry >= wg_end) break;
         const int64_t sid = __builtin_amdgcn_readfirstlane(a.seg_list ? (int)a.seg_list[entry] : entry);
-        if (hist) look();  // the pipeline is empty here: the look costs its own latency only
+        // looks at strip starts (the pipeline is empty there: a look costs its own latency only), a quarter of the
+        // workgroup's wavefronts each round: the others take what those find from LDS (refresh)
+        if (hist && !first_strip && ((iter + wave) & 3) == 0) look();
+        ++iter;
         // the runs' ancestor stacks (h:2858-2862), and where the strip's phases start (16-byte units)
         const uint32_t pb = a.img.st_pbase[sid * GROUPS + min(lane, GROUPS)];
 #pragma unroll
@@ -1936,13 +2018,15 @@ __global__ __launch_bounds__(kS1Threads) void strand1_kernel(const ScanArgs a) {
             const int gc = min(g, GROUPS - 1);
             // where the lane's bytes start in the phase (lane after lane): wave prefix sum of the lanes' byte counts
             const uint32_t mine = (uint32_t)__popc(h.masks);  // <= 32
-            uint32_t off = 0;
-#pragma unroll
-            for (int bit = 5; bit >= 0; --bit) off = mbcnt64(__ballot((mine >> bit) & 1u), off << 1);
+            const uint32_t off = wave_inclusive_sum(mine) - mine;
             const unsigned char* base = a.img.st_delta + (size_t)(uint32_t)__builtin_amdgcn_readlane((int)pb, gc) * 16;
             const uint32_t o1 = off + (uint32_t)__popc(h.masks & 0xffu), o2 = off + (uint32_t)__popc(h.masks & 0xffffu),
                            o3 = off + (uint32_t)__popc(h.masks & 0xffffffu);
             Bytes r;
+            if constexpr ((DPQ_S1_SKIP & 4) != 0) {
+                r.w[0] = make_uint2(off, o1), r.w[1] = make_uint2(o1, o2), r.w[2] = make_uint2(o2, o3), r.w[3] = make_uint2(o3, (uint32_t)(uintptr_t)base);
+                return r;
+            }
             __builtin_memcpy(&r.w[0], base + off, 8);  // byte addresses: unaligned 8-byte loads
             __builtin_memcpy(&r.w[1], base + o1, 8);
             __builtin_memcpy(&r.w[2], base + o2, 8);
@@ -1957,38 +2041,75 @@ __global__ __launch_bounds__(kS1Threads) void strand1_kernel(const ScanArgs a) {
         for (int i = 0; i < D; ++i) bq[i] = load_bytes(i, hq[i]);
 #pragma unroll 1
         for (int g = 0; g < GROUPS; ++g) {
-            if (hist && first_strip && (g == 1 || g == 2 || g == 4 || g == 8)) look();  // (drains the prefetches: first strip only)
+            if (hist) {
+                // inside the first strip: wavefronts 0..3 after 1, 2, 4, 8 phases (drains that wavefront's prefetches, once)
+                if (first_strip && wave < 4 && g == (1 << wave)) look();
+#ifndef DPQ_S1_REFRESH
+#define DPQ_S1_REFRESH 4  // phases between two reads of the workgroup's cut (every phase inside the first strip)
+#endif
+                if (first_strip || (g % DPQ_S1_REFRESH) == 0) refresh();
+            }
             const Hdr h_new = load_hdr(g + D + 2);
             bq[D] = load_bytes(g + D, hq[D]);
             const Hdr hdr = hq[0];
             uint32_t codes[kPhaseLen][2], sum[kPhaseLen];
+            // The four steps as a software pipeline over the LDS round trips: step s + 1's parent and selectors are read
+            // behind step s's eight bound-row gathers and before their sums -- one round trip per step instead of two.
+            struct Dec {
+                uint32_t paddr, lo;
+                uint2 parent;
+                uint32_t sel_lo, sel_hi;
+            };
+            auto dec_reads = [&](int st) -> Dec {
+                // the reference's stack machine (h:2888-2905): code = stack[depth - 1] with the masked positions replaced
+                Dec d;
+                const uint32_t depth = (hdr.depths >> (4 * st)) & 0xfu;
+                const uint32_t hi = (hdr.masks >> (8 * st + 4)) & 0xfu;
+                d.lo = (hdr.masks >> (8 * st)) & 0xfu;
+                d.paddr = (depth << 9) + lane_stk;
+                if constexpr ((DPQ_S1_SKIP & 2) != 0) {
+                    d.parent = make_uint2(d.paddr, hi), d.sel_lo = d.lo * 0x01010101u, d.sel_hi = hi * 0x01010101u;
+                    return d;
+                }
+                d.parent = lds_ld64(d.paddr);
+                d.sel_lo = lds_ld32((d.lo << 7) + lane_sel);
+                d.sel_hi = lds_ld32((hi << 7) + lane_sel);
+                return d;
+            };
+            Dec dc = dec_reads(0);
 #pragma unroll
             for (int st = 0; st < kPhaseLen; ++st) {
-                // the reference's stack machine (h:2888-2905): code = stack[depth - 1] with the masked positions replaced
-                const uint32_t depth = (hdr.depths >> (4 * st)) & 0xfu;
-                const uint32_t lo = (hdr.masks >> (8 * st)) & 0xfu, hi = (hdr.masks >> (8 * st + 4)) & 0xfu;
-                const uint32_t paddr = (depth << 9) + lane_stk;
-                const uint2 parent = lds_ld64(paddr);
-                const uint32_t sel_lo = lds_ld32((lo << 7) + lane_sel), sel_hi = lds_ld32((hi << 7) + lane_sel);
                 const uint2 raw = bq[0].w[st];
-                const uint32_t raw_hi = (uint32_t)((((uint64_t)raw.y << 32) | raw.x) >> (8 * __popc(lo)));
+                const uint32_t raw_hi = (uint32_t)((((uint64_t)raw.y << 32) | raw.x) >> (8 * __popc(dc.lo)));
                 uint32_t* code = codes[st];
-                code[0] = __builtin_amdgcn_perm(parent.x, raw.x, sel_lo);
-                code[1] = __builtin_amdgcn_perm(parent.y, raw_hi, sel_hi);
-                lds_st64(paddr + 512u, make_uint2(code[0], code[1]));  // stack[depth] = code
+                code[0] = __builtin_amdgcn_perm(dc.parent.x, raw.x, dc.sel_lo);
+                code[1] = __builtin_amdgcn_perm(dc.parent.y, raw_hi, dc.sel_hi);
+                if constexpr ((DPQ_S1_SKIP & 2) == 0) lds_st64(dc.paddr + 512u, make_uint2(code[0], code[1]));  // stack[depth] = code
                 // ADC, lower bound: sum of the eight entries; row of code byte c at c << 8, the lane's copy at lane8
-                uint32_t acc = 0;
-#pragma unroll
-                for (int m = 0; m < M; ++m) {
-                    const uint32_t row = __builtin_amdgcn_perm(code[m >> 2], lane8, 0x0c0c0400u + ((uint32_t)(m & 3) << 8));
-                    const uint2 e = lds_ld64_whole(row);
-                    acc = __builtin_amdgcn_udot4(m < 4 ? e.x : e.y, 1u << (8 * (m & 3)), acc, false);
+                if constexpr ((DPQ_S1_SKIP & 1) != 0) {
+                    if (st + 1 < kPhaseLen) dc = dec_reads(st + 1);
+                    sum[st] = 300u + (code[0] ^ code[1]);
+                    continue;
                 }
-                sum[st] = acc;
+                uint32_t row[M];
+#pragma unroll
+                for (int m = 0; m < M; ++m) row[m] = __builtin_amdgcn_perm(code[m >> 2], lane8, 0x0c0c0400u + ((uint32_t)(m & 3) << 8));
+                uint2 e[M];
+#pragma unroll
+                for (int m = 0; m < M; ++m) e[m] = lds_ld64_whole(row[m]);
+                if (st + 1 < kPhaseLen) dc = dec_reads(st + 1);
+                uint32_t acc0 = 0, acc1 = 0;  // two chains
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    acc0 = __builtin_amdgcn_udot4(e[m].x, 1u << (8 * m), acc0, false);
+                    acc1 = __builtin_amdgcn_udot4(e[m + 4].y, 1u << (8 * m), acc1, false);
+                }
+                sum[st] = acc0 + acc1;
             }
             // what the bound lets through: the reference's distance and the whole (distance, id) key
             const uint32_t cutp = (uint32_t)cut + 1u;
-            if (__ballot(min(min(sum[0], sum[1]), min(sum[2], sum[3])) <= cutp)) {
+            if (__ballot(min(min(sum[0], sum[1]), min(sum[2], sum[3])) <= cutp) && !(dbg & 1)) {
+                const unsigned long long t_in = stp ? __builtin_amdgcn_s_memrealtime() : 0ull;
 #pragma unroll
                 for (int st = 0; st < kPhaseLen; ++st) {
                     const uint32_t c0 = codes[st][0], c1 = codes[st][1], sm = sum[st];
@@ -2008,15 +2129,13 @@ __global__ __launch_bounds__(kS1Threads) void strand1_kernel(const ScanArgs a) {
                         pass = key <= thr;
                     }
                     const uint64_t found = __ballot(pass);
-                    if (a.counters && lane == 0) {
-                        atomicAdd(a.counters, (unsigned long long)__popcll(checked));
-                        atomicAdd(a.counters + 1, (unsigned long long)__popcll(found));
-                    }
+                    n_checked += (uint32_t)__popcll(checked);
+                    n_found += (uint32_t)__popcll(found);
                     if (found == 0) continue;
-                    uint32_t* count = a.cand_count + (size_t)slot * kRegionStride + 1;  // the slot's single region
-                    uint64_t* region = a.cand_key + (size_t)slot * a.cand_stride + a.region_off;
+                    // the workgroup's own region of the slot's buffer, filled through an LDS counter (no global atomics)
+                    uint64_t* region = a.cand_key + (size_t)slot * a.cand_stride + a.region_off + (size_t)blockIdx.x * a.region_cap;
                     uint32_t base = 0;
-                    if (lane == 0) base = atomicAdd(count, (uint32_t)__popcll(found));
+                    if (lane == 0) base = __hip_atomic_fetch_add(sh_count, (uint32_t)__popcll(found), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
                     const uint32_t li = base + mbcnt64(found, 0);
                     if (pass && li < (uint32_t)a.region_cap) region[li] = key;
@@ -2025,8 +2144,13 @@ __global__ __launch_bounds__(kS1Threads) void strand1_kernel(const ScanArgs a) {
                         // tightening: the roundings are below 1e-4 units, the margin 2e-3): it lies under a cut of e units
                         const float u = __fmaf_rn(d * sc, 0x1.000002p-20f, (d - bdn) * sc);
                         const int e = max((int)(u + 2e-3f) + 1, 0);
-                        if (e < cut) atomicAdd(hist + e, 1u);
+                        // bucket b: under a cut of 4 b + 3 units; counted in LDS, moved to the global histogram by the next look
+                        if (e < cut) __hip_atomic_fetch_add(sh_hist + (e >> 2), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     }
+                }
+                if (stp) {
+                    slow_ticks += __builtin_amdgcn_s_memrealtime() - t_in;
+                    ++slow_entries;
                 }
             }
 #pragma unroll
@@ -2036,6 +2160,27 @@ __global__ __launch_bounds__(kS1Threads) void strand1_kernel(const ScanArgs a) {
             for (int i = 0; i < D; ++i) bq[i] = bq[i + 1];
         }
         first_strip = false;
+        stamp();
+        if (stp && n_stamp == 3 && lane == 0) stp[14] = slow_ticks, stp[15] = slow_entries;  // ... of the first strip
+    }
+    // ---- epilogue: the last wavefront of the workgroup publishes its region's count (a count above region_cap tells
+    // the select kernel that keys were dropped) ----
+    uint32_t done = 0;
+    if (lane == 0) {
+        if (a.counters) {  // (statistics: summed over the workgroup in LDS, two global adds per workgroup)
+            __hip_atomic_fetch_add(sh_stat, n_checked, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(sh_stat + 1, n_found, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        done = __hip_atomic_fetch_add(sh_done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (done == kS1Waves - 1) {
+            a.cand_count[(size_t)slot * kRegionStride + 1 + blockIdx.x] = __hip_atomic_load(sh_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (a.counters) {
+                const uint32_t c0 = __hip_atomic_load(sh_stat, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                const uint32_t c1 = __hip_atomic_load(sh_stat + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (c0) atomicAdd(a.counters, (unsigned long long)c0);
+                if (c1) atomicAdd(a.counters + 1, (unsigned long long)c1);
+            }
+        }
     }
 }
 
@@ -2904,13 +3049,15 @@ static hipError_t launch_strand_q(const ScanArgs& a, int n_slots, hipStream_t st
     return hipGetLastError();
 }
 
+int strand1_workgroups(int n_strips) { return std::max(1, std::min(256, n_strips)); }
+
 // One query per pass: the bound-table kernel.  One workgroup of 16 wavefronts per CU; strips go to the workgroups
 // first, so a short list still reaches every CU.
 static hipError_t launch_strand1(const ScanArgs& a, int n_slots, hipStream_t stream) {
     static std::atomic<bool> done[64] = {};
     hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&strand1_kernel), S1Lds::kBytes, done);
     if (e != hipSuccess) return e;
-    const int wgs = std::max(1, std::min(256, a.n_seg_pass));
+    const int wgs = strand1_workgroups(a.n_seg_pass);
     hipLaunchKernelGGL(strand1_kernel, dim3((unsigned)wgs, (unsigned)n_slots), dim3(kS1Threads), S1Lds::kBytes, stream, a);
     return hipGetLastError();
 }
@@ -2919,7 +3066,7 @@ hipError_t launch_strand(const ScanArgs& a, int n_slots, hipStream_t stream) {
     if (a.n_seg_pass <= 0 || n_slots <= 0) return hipSuccess;
     if (a.img.M != 8 || !a.img.st_ckpt) return hipErrorInvalidValue;
     switch (stream_queries_per_pass(8, n_slots)) {
-        case 1: return a.debug_pass == 3 ? launch_strand_q<1>(a, n_slots, stream) : launch_strand1(a, n_slots, stream);
+        case 1: return a.debug_pass == 3 ? launch_strand_q<1>(a, n_slots, stream) : launch_strand1(a, n_slots, stream);  // (>= 16: strand1 experiments)
         case 2: return launch_strand_q<2>(a, n_slots, stream);
         default: return launch_strand_q<4>(a, n_slots, stream);
     }

@@ -15,11 +15,14 @@ while time.time() < t_end:
     M = int(rng.choice([8, 8, 8, 16]))
     n = int(rng.choice([1, 2, 3, 63, 64, 65, 255, 257, int(rng.integers(300, 3000)), int(rng.integers(3000, 60000))]))
     if os.environ.get("DPQ_FUZZ_BIG") == "1" and rng.random() < 0.3:
-        n = int(rng.integers(60000, 400000))  # bootstrap shards
+        n = int(rng.integers(17000, 400000))  # bootstrap shards
     cps = int(rng.choice([1, 2, 4, 4, 8, 16, 64]))
     k = int(min(n, rng.choice([1, 2, 10, 100, 100, 1000, 2048])))
     nq = int(rng.choice([1, 2, 3, 4, 5, 8, 31, 32, 33, 70, 129, 200, 500, 700]))  # 1-4 (8 with stream_max 8): stream pass; >= 450: in-scan tightening
-    flags = int(rng.choice([0, 0, 16, 64, 64]))   # DPQ_OPT_NO_TIGHTEN, DPQ_OPT_FORCE_STRANDS
+    # DPQ_OPT_NO_TIGHTEN 16, DPQ_OPT_FORCE_STRANDS 64 (one query per call on a bootstrap shard: strand1_kernel), 64 | 16 (its
+    # multi-level plan without in-kernel tightening), 64 | 128 (DPQ_OPT_NO_STRAND1: the exact-table kernel)
+    flags = int(rng.choice([0, 0, 16, 64, 64, 64, 80, 192]))
+    boot = int(rng.choice([0, 0, 1]))           # 1: the threshold bootstrap (and with it the strand image) from 16 K nodes
     smax = int(rng.choice([0, 0, 8, -1]))
     bd = int(rng.choice([-1, 0, 0, 1, 1, 2, 5, 37, 300]))  # dpq_open_opts.batch_decode (>= 2: scratch tiles of that many segments)
     cap = int(rng.choice([0, 0, 0, 64, 300]))
@@ -33,14 +36,14 @@ while time.time() < t_end:
     tree["root"] = (tree["root"].astype(np.int64) % K).astype(np.uint8)
     payload, nb = synth.encode_dtc(tree)
     qs = synth.make_queries(nq, 128, seed + 2)
-    desc = "M=%d n=%d cps=%d k=%d nq=%d cap=%d shards=%d K=%d md=%.1f seed=%d batch_decode=%d flags=%d stream_max=%d" % (
-        M, n, cps, k, nq, cap, shards, K, md, seed, bd, flags, smax)
+    desc = "M=%d n=%d cps=%d k=%d nq=%d cap=%d shards=%d K=%d md=%.1f seed=%d batch_decode=%d flags=%d stream_max=%d bootstrap=%d" % (
+        M, n, cps, k, nq, cap, shards, K, md, seed, bd, flags, smax, boot)
     try:
         parts = []
         for r in range(shards):
             with api.DeltaPQIndex.open_memory(payload, n, M, K, chunks_per_segment=cps, cand_capacity=cap,
                                               shard_rank=r, shard_count=shards, batch_decode=bd, flags=flags,
-                                              stream_max_queries=smax) as idx:
+                                              stream_max_queries=smax, bootstrap=boot) as idx:
                 idx.set_codebook(cb)
                 parts.append(idx.query_batch(qs, k))
         if shards > 1:

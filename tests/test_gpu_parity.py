@@ -662,7 +662,7 @@ def test_one_query_per_pass_matches_the_batched_path(gpu, oracle, n, M, k):
     (200_000, 50, 3.0, {}),
     (200_000, 100, 0.4, {}),                                                # duplicate-heavy: thousands of equal keys at the cut
     (2_300_000, 100, 3.0, {}),
-    (200_001, 20, 3.0, dict(num_codes=123_458)),                            # a prefix scan (even: the trailing id rule)
+    (200_001, 20, 3.0, dict(num_codes=123_457)),                            # a prefix scan (odd: exactly the reference's `-N`; even prefixes: test_stream_pass_on_a_prefix...)
     (200_000, 20, 3.0, dict(shard_rank=1, shard_count=3)),
     (200_000, 20, 3.0, dict(global_offset=12_345_678, global_n_codes=1_000_000_000)),   # a part of a larger index
 ])
