@@ -102,6 +102,12 @@ SYMBOLS = [
     ("dpq_profile_enable", ctypes.c_int, [_VP, ctypes.c_int]),
     ("dpq_profile_reset", ctypes.c_int, [_VP]),
     ("dpq_profile_read", ctypes.c_int, [_VP, P(Profile)]),
+    # developer diagnostics (DPQ_DEV=1 only; scripts/)
+    ("dpq_debug_scan_time", ctypes.c_int, [_VP, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, P(ctypes.c_float)]),
+    ("dpq_debug_scan_stamps", ctypes.c_int, [_VP, ctypes.c_int, ctypes.c_int, P(ctypes.c_ulonglong), ctypes.c_int, P(ctypes.c_float)]),
+    ("dpq_debug_boot_stamps", ctypes.c_int, [_VP, ctypes.c_int, P(ctypes.c_double)]),
+    ("dpq_debug_select_time", ctypes.c_int, [_VP, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, P(ctypes.c_float)]),
+    ("dpq_debug_strand1_stamps", ctypes.c_int, [_VP, _VP, ctypes.c_int]),
 ]
 
 _lib = None

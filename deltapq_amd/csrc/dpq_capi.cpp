@@ -219,6 +219,15 @@ struct dpq_index {
 
 namespace {
 
+// Developer diagnostics (the dpq_debug_* entry points, include/deltapq_amd.h) and developer environment variables are
+// live only in a process started with DPQ_DEV=1.
+bool dev_mode() {
+    const char* dev = getenv("DPQ_DEV");
+    return dev && atoi(dev) != 0;
+}
+#define DPQ_DEV_ONLY() \
+    if (!dev_mode()) return fail(DPQ_ERR_STATE, "developer diagnostics: start the process with DPQ_DEV=1")
+
 // dpq_open_opts -> Tuning.  The environment takes part only with DPQ_DEV=1 (developer sweeps: scripts/), and only
 // here, once per dpq_open_*: a product process' plan never depends on its environment.
 Tuning resolve_tuning(const dpq_open_opts& o) {
@@ -237,8 +246,7 @@ Tuning resolve_tuning(const dpq_open_opts& o) {
     t.strands = !(o.flags & DPQ_OPT_NO_STRANDS);
     t.force_strands = (o.flags & DPQ_OPT_FORCE_STRANDS) != 0;
     t.strand1 = !(o.flags & DPQ_OPT_NO_STRAND1);
-    const char* dev = getenv("DPQ_DEV");
-    if (dev && atoi(dev) != 0) {
+    if (dev_mode()) {
         auto geti = [](const char* name, int* v) { if (const char* e = getenv(name)) *v = atoi(e); };
         geti("DPQ_STREAM_MAX_QUERIES", &t.stream_max);
         geti("DPQ_COARSE_BELOW", &t.coarse_below);
@@ -264,6 +272,7 @@ Tuning resolve_tuning(const dpq_open_opts& o) {
 
 void switch_lane(dpq_index* x, int lane) {
     if (lane == x->active_lane) return;
+    x->dbg_groups = x->dbg_boot_slots = 0;  // (dpq_debug_scan_time mode 3 replays launches of the ACTIVE workspace)
     dpq_index::Lane cur;
     cur.d_lut32 = x->d_lut32; cur.d_lut_min = x->d_lut_min; cur.d_qtab = x->d_qtab; cur.d_lut32r = x->d_lut32r;
     cur.d_cand_count = x->d_cand_count; cur.d_overflow = x->d_overflow;
@@ -287,6 +296,7 @@ void free_parked_lane(dpq_index* x) {
 }
 
 void free_workspace(dpq_index* x) {
+    x->dbg_groups = x->dbg_boot_slots = 0;  // the recorded launch arguments point into what is freed here
     hipFree(x->d_lut32);
     hipFree(x->d_lut32r);
     x->d_lut32r = nullptr;
@@ -1399,7 +1409,7 @@ int dpq_tree_build_gpu(const uint8_t* codes, int64_t n_codes, int M, int K, int 
     if (rc) return fail(rc, err);
     dpq_tree* t = new dpq_tree();
     // DPQ_DEV=1 DPQ_BUILD_LAYOUT=host keeps the layout on the host (developer A/B; same tree either way)
-    static const bool host_layout = getenv("DPQ_DEV") && atoi(getenv("DPQ_DEV")) != 0 && getenv("DPQ_BUILD_LAYOUT") &&
+    static const bool host_layout = dev_mode() && getenv("DPQ_BUILD_LAYOUT") &&
                                     std::string(getenv("DPQ_BUILD_LAYOUT")) == "host";
     rc = host_layout ? dpq::layout_tree(codes, n_codes, M, K, max_height_folds, codewords, Ds, finalists, &edges, &t->tree, &err)
                      : dpq::layout_tree_gpu(codes, n_codes, M, K, max_height_folds, codewords, Ds, finalists, &edges, device,
@@ -2008,12 +2018,13 @@ int dpq_merge_topk_device_packed(const int32_t* d_packed, int n_lists, int nq, i
     });
 }
 
-// Developer hook (not in the public header): time `reps` full-index filter-scan
+// Developer hook: time `reps` full-index filter-scan
 // launches for nq query slots with the filter pinned (pass_all == 0: nothing
 // survives; 1: everything survives), to separate decode/ADC cost from
 // candidate handling.  Needs a prior dpq_query_batch* call with >= nq queries.
 int dpq_debug_scan_time(dpq_index* x, int nq, int pass_all, int reps, int splits, float* ms_out) {
     return guarded([&]() -> int {
+    DPQ_DEV_ONLY();
     if (!x || !ms_out || !x->d_lut32) return fail(DPQ_ERR_STATE, "run a query batch first");
     DPQ_HIP(hipSetDevice(x->device));
     if (pass_all == 3) {
@@ -2119,6 +2130,7 @@ int dpq_debug_scan_time(dpq_index* x, int nq, int pass_all, int reps, int splits
 // left behind; out[0..n) = per-section cycle sums over all wavefronts (order: enum in dpq_kernels.hip).
 int dpq_debug_scan_stamps(dpq_index* x, int nq, int splits, unsigned long long* out, int n_out, float* ms_out) {
     return guarded([&]() -> int {
+    DPQ_DEV_ONLY();
     if (!x || !out || !x->d_lut32) return fail(DPQ_ERR_STATE, "run a query batch first");
     if (x->M != 8) return fail(DPQ_ERR_ARG, "the STAMPS build exists for M = 8");
     DPQ_HIP(hipSetDevice(x->device));
@@ -2170,6 +2182,8 @@ int dpq_debug_scan_stamps(dpq_index* x, int nq, int splits, unsigned long long* 
 // start, end of the prologue, end of each of the wavefront's first strips.  First call arms it; later calls copy out
 // the marks of the last one-query call on a strand image.
 int dpq_debug_strand1_stamps(dpq_index* x, unsigned long long* out, int n_words) {
+    return guarded([&]() -> int {
+    DPQ_DEV_ONLY();
     if (!x || !out) return fail(DPQ_ERR_ARG, "NULL argument");
     DPQ_HIP(hipSetDevice(x->device));
     const size_t total = (size_t)256 * 16 * 16;
@@ -2183,12 +2197,15 @@ int dpq_debug_strand1_stamps(dpq_index* x, unsigned long long* out, int n_words)
     DPQ_HIP(hipMemcpy(out, x->d_s1_stamps, std::min((size_t)std::max(n_words, 0), total) * 8, hipMemcpyDeviceToHost));
     DPQ_HIP(hipMemset(x->d_s1_stamps, 0, total * 8));
     return DPQ_OK;
+    });
 }
 
-// Developer hook (not in the public header): phase marks of the bootstrap kernel.  First call arms it
+// Developer hook: phase marks of the bootstrap kernel.  First call arms it
 // (allocates [2048][8] marks); later calls return the mean cycles between consecutive marks over `nq` slots
 // of the last batch: out[0] rank, [1] cell counts + prefix, [2] node evaluation, [3] k-th key select.
 int dpq_debug_boot_stamps(dpq_index* x, int nq, double* out) {
+    return guarded([&]() -> int {
+    DPQ_DEV_ONLY();
     if (!x || !out) return fail(DPQ_ERR_ARG, "NULL argument");
     DPQ_HIP(hipSetDevice(x->device));
     if (!x->d_boot_stamps) {
@@ -2232,11 +2249,13 @@ int dpq_debug_boot_stamps(dpq_index* x, int nq, double* out) {
                 out[4 * half + i] += (double)(h[o + i + 1] - h[o + i]) / nq;
             }
     return DPQ_OK;
+    });
 }
 
 // Developer hook: time the level-0 select (shared, query-independent candidate list).
 int dpq_debug_select_time(dpq_index* x, int nq, int top_k, int flags, int reps, float* ms_out) {
     return guarded([&]() -> int {
+    DPQ_DEV_ONLY();
     if (!x || !ms_out || !x->d_lut32 || !x->d_l0_id) return fail(DPQ_ERR_STATE, "run a query batch first");
     DPQ_HIP(hipSetDevice(x->device));
     dpq::SelectArgs se{};

@@ -340,6 +340,22 @@ int dpq_profile_enable(dpq_index* idx, int on);  /* 0 off, 1 every kernel, 2 sca
 int dpq_profile_reset(dpq_index* idx);
 int dpq_profile_read(dpq_index* idx, dpq_profile* out);
 
+/* ---- developer diagnostics ----------------------------------------------
+ * Not part of the drop-in boundary: timing and instrumentation hooks used by scripts/ (limiter studies, kernel
+ * section marks).  They return DPQ_ERR_STATE unless the process was started with DPQ_DEV=1 in its environment, and
+ * only then read their own DPQ_DEBUG_* variables.  A query call never goes through them. */
+/* `reps` filter-scan launches over the whole shard for nq slots of the last batch with the filter pinned (pass_all 0:
+ * nothing survives, 1: everything, 2: the batch's thresholds, 3: the last batch's bootstrap + first level as they ran). */
+int dpq_debug_scan_time(dpq_index* idx, int nq, int pass_all, int reps, int splits, float* ms_out);
+/* One launch of the STAMPS build of the scan kernel (M = 8): per-section cycle sums over all wavefronts. */
+int dpq_debug_scan_stamps(dpq_index* idx, int nq, int splits, unsigned long long* out, int n_out, float* ms_out);
+/* Phase marks of the bootstrap and the last select launch (first call arms them). */
+int dpq_debug_boot_stamps(dpq_index* idx, int nq, double* out);
+/* The level-0 select alone (shards without a bootstrap). */
+int dpq_debug_select_time(dpq_index* idx, int nq, int top_k, int flags, int reps, float* ms_out);
+/* Per-wavefront marks of strand1_kernel on the 100 MHz clock, [256][16][16] words (first call arms them). */
+int dpq_debug_strand1_stamps(dpq_index* idx, unsigned long long* out, int n_words);
+
 #ifdef __cplusplus
 }
 #endif

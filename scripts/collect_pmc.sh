@@ -15,7 +15,7 @@ rm -rf "$OUT" && mkdir -p "$OUT"
 trap 'rm -rf $OUT/stats $OUT/pmc_fetch $OUT/pmc_write' EXIT
 COMMON="--no-cpu-baseline --reps 2 $*"
 echo "pass 1: kernel stats" >> $OUT/progress.txt
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python bench.py --steps 20 --warmup 3 $COMMON > $OUT/bench_line_under_rocprof.json 2> $OUT/stats.err || exit 2
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python bench.py --steps 20 --warmup 3 --no-hbm-leg --sustain-seconds 0 --host-steps 0 $COMMON > $OUT/bench_line_under_rocprof.json 2> $OUT/stats.err || exit 2
 echo "pass 2: FETCH_SIZE" >> $OUT/progress.txt
 timeout -k 10 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python bench.py --steps 5 --warmup 1 --check 0 --sustain-seconds 0 --host-steps 0 --no-hbm-leg $COMMON > /dev/null 2> $OUT/fetch.err || exit 3
 echo "pass 3: WRITE_SIZE" >> $OUT/progress.txt

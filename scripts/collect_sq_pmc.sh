@@ -16,7 +16,7 @@ for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SA
            "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_LDS_CMD_FIFO_FULL SQ_LDS_DATA_FIFO_FULL SQ_INST_CYCLES_SALU SQ_THREAD_CYCLES_VALU SQ_INST_LEVEL_LDS" \
            "SQ_INSTS_LDS_LOAD SQ_INSTS_LDS_STORE SQ_INSTS_LDS_ATOMIC SQ_INSTS_LDS_LOAD_BANDWIDTH SQ_VMEM_TA_ADDR_FIFO_FULL SQ_VMEM_TA_CMD_FIFO_FULL SQ_INST_LEVEL_VMEM SQ_BUSY_CU_CYCLES"; do
   i=$((i+1))
-  timeout -k 10 300 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $OUT/p$i -- python bench.py --steps 3 --warmup 1 --reps 1 --no-cpu-baseline --check 0 "$@" > /dev/null 2> $OUT/p$i.err || echo "pass $i failed" >> $OUT/failed.txt
+  timeout -k 10 300 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $OUT/p$i -- python bench.py --steps 3 --warmup 1 --reps 1 --no-cpu-baseline --check 0 --no-hbm-leg --sustain-seconds 0 --host-steps 0 "$@" > /dev/null 2> $OUT/p$i.err || echo "pass $i failed" >> $OUT/failed.txt
 done
 python - "$OUT" "${KERNEL:-scan_kernel}" <<'PY'
 import collections, csv, glob, json, sys

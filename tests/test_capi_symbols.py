@@ -24,6 +24,12 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
     raw = ctypes.CDLL(_lib.LIB_PATH)        # the HIP runtime is already bound by the `lib` fixture
     for name in declared:
         assert hasattr(raw, name), name
+    # ... and nothing else: every dpq_* the library exports is declared in the header (developer diagnostics included)
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = sorted({line.split()[-1] for line in out.splitlines() if line.split() and line.split()[-1].startswith("dpq_")
+                       and line.split()[-2] in ("T", "t", "W")})
+    assert exported == declared, sorted(set(exported) ^ set(declared))
     assert lib.dpq_version() == 100
     assert lib.dpq_strerror(0) == b"ok" and lib.dpq_strerror(-3) == b"malformed DTC stream"
 
@@ -91,3 +97,17 @@ def test_cli_approx_tree_builds_the_index_without_gpu(built, tmp_path):
     api.dtc_validate(payload, n)
     vec_id = api.read_qnode_ids(os.path.join(d, "M8K256_Approx_TreeNodesDFS_N%d" % n), n)
     assert sorted(vec_id.tolist()) == list(range(n))
+
+
+def test_developer_diagnostics_are_refused_outside_dev_mode(lib):
+    """dpq_debug_* (declared in the header's developer section) answer DPQ_ERR_STATE unless the process runs with DPQ_DEV=1,
+    and read no environment variable before that check."""
+    import ctypes as ct
+    if os.environ.get("DPQ_DEV", "0") not in ("", "0"):
+        pytest.skip("DPQ_DEV is set in this environment")
+    ms = ct.c_float()
+    fake = ct.c_void_p(0x1000)   # never dereferenced: the mode check comes first
+    assert lib.dpq_debug_scan_time(fake, 1, 0, 1, 0, ms) == -7
+    assert lib.dpq_debug_select_time(fake, 1, 10, 0, 1, ms) == -7
+    assert lib.dpq_debug_strand1_stamps(fake, None, 0) == -7
+    assert b"DPQ_DEV=1" in lib.dpq_last_error()
