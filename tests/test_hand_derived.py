@@ -344,6 +344,61 @@ def test_oracle_stream_across_a_4k_block(oracle, tmp_path):
     assert 0 in exact and d_fd.tolist() == [0.0] * 8 and sorted(ids_fd.tolist()) == ANSWER_C_ZERO
 
 
+# G / H. The ORDER in which equal distances leave the reference's heap (h:2851-2853 priority_queue with cmp_max, admission
+#    h:2909-2914, drain h:2977-2982), worked through libstdc++'s __push_heap / __adjust_heap BY HAND.  cmp_max compares the
+#    distance only, so ties are decided by where the sift operations stop, not by ids.  T[m][k] = (m + 1) k; every node is a
+#    depth-1 child of the root that sets position 0, so a node's distance is its byte.
+#
+# G. N = 7, k = 3, distances by id: 5 3 5 7 5 1 9 -- three equal keys AT the cut.
+#    push (5,0):           c = [(5,0)]
+#    push (3,1): hole 1, parent 0: 5 < 3 ? no                                   c = [(5,0) (3,1)]
+#    push (5,2): hole 2, parent 0: 5 < 5 ? no                                   c = [(5,0) (3,1) (5,2)]
+#    (7,3): 7 < top 5 ? no.   (5,4): 5 < 5 ? no (strict: the first seen stay).
+#    (1,5): 1 < 5: pop -- value = c[2] = (5,2), c[2] = c[0]; __adjust_heap(hole 0, len 2, value): the loop does not run
+#           (0 < (2-1)/2 = 0 fails); len even and second == (2-2)/2: second = 2, c[0] = c[1] = (3,1), hole 1;
+#           __push_heap(hole 1, top 0, (5,2)): parent 0: 3 < 5 ? yes: c[1] = (3,1), hole 0; stop: c[0] = (5,2)
+#           -> the root (5,0) is what left; c = [(5,2) (3,1)]; push (1,5): hole 2, parent 0: 5 < 1 ? no  c = [(5,2) (3,1) (1,5)]
+#    (9,6): no.   drain: results[2] = (5,2); then (3,1); then (1,5).
+#    The reference answers ids [5, 1, 2] -- id 2, NOT the first-seen id 0, carries the boundary distance.
+STREAM_G = bytes([5, 0, 0, 0, 0, 0, 0, 0,
+                  0x11, 0x01, 3, 0x01, 5,        # nodes 1, 2: depth 1 each, position 0 <- 3, 5
+                  0x11, 0x01, 7, 0x01, 5,        # nodes 3, 4
+                  0x11, 0x01, 1, 0x01, 9])       # nodes 5, 6
+ANSWER_G = ([5, 1, 2], [1.0, 3.0, 5.0])
+# H. N = 5, k = 3, distances by id: 4 2 2 9 8 -- two equal keys INSIDE the list.
+#    push (4,0); push (2,1): 4 < 2 ? no; push (2,2): 4 < 2 ? no                  c = [(4,0) (2,1) (2,2)]
+#    (9,3), (8,4): not below the top 4.
+#    drain: results[2] = (4,0); pop: value = (2,2), __adjust_heap(0, 2, value): len even, second == 0: c[0] = c[1] = (2,1),
+#           hole 1; __push_heap(1, 0, (2,2)): parent 0: 2 < 2 ? no: c[1] = (2,2)   c = [(2,1) (2,2)]
+#           results[1] = (2,1); results[0] = (2,2).
+#    The reference emits the equal pair as ids 2, 1 -- not in ascending id order.
+STREAM_H = bytes([4, 0, 0, 0, 0, 0, 0, 0,
+                  0x11, 0x01, 2, 0x01, 2,
+                  0x11, 0x01, 9, 0x01, 8])
+ANSWER_H = ([2, 1, 0], [2.0, 2.0, 4.0])
+
+
+def test_oracle_heap_order_of_equal_distances(oracle):
+    """Both oracle restatements (the C++ one on the real std::priority_queue, the Python one with libstdc++'s sift
+    routines written out) return the hand-derived reference order; the tie-aware comparator accepts exactly the
+    canonical alternatives (ascending id) this build returns and nothing with a wrong distance or a foreign id."""
+    from oracle import dtc_oracle as O
+    lut = np_table(int_table())
+    for stream, n, (ids, ds), canon in ((STREAM_G, 7, ANSWER_G, [5, 1, 0]), (STREAM_H, 5, ANSWER_H, [1, 2, 0])):
+        got_i, got_d = both_scans(oracle, stream, n, lut, 3)
+        assert got_i.tolist() == ids and got_d.tolist() == ds
+        book = scan_by_the_book(stream, n, int_table(), 3)
+        assert [float(d) for _, d in book] == [float(b) for b in stream[:1]] + [float(stream[10 + 5 * (j // 2) + 2 * (j % 2)]) for j in range(n - 1)]
+        pl = np.frombuffer(stream, dtype=np.uint8)
+        _, _, alld, _ = oracle.scan_lut(pl, n, lut, 3, want_all=True)
+        ok, msg = O.tie_aware_equal(np.array(canon), np.array(ds, dtype=np.float32), got_i, got_d, alld, n)
+        assert ok, msg
+        wrong = list(canon)
+        wrong[-1] = 3                                    # id 3 (distance 7 / 9) does not belong to the boundary group
+        ok, _ = O.tie_aware_equal(np.array(wrong), np.array(ds, dtype=np.float32), got_i, got_d, alld, n)
+        assert not ok
+
+
 def test_oracle_double_against_float_admission(oracle):
     got_i, got_d = both_scans(oracle, STREAM_D, 3, np_table(table_d()), 1)
     assert got_i.tolist() == ANSWER_D[0] and got_d.view(np.uint32).tolist() == ANSWER_D[1]
@@ -418,6 +473,10 @@ def test_product_on_hand_derived_streams(lib):
     assert run(STREAM_B, 9, 5) == ([0, 1, 2, 3, 8], [0.0, 1.0, 17.0, 98.0, 256.0])
     ids, d = run(stream_c(), 2001, 16)
     assert d == [0.0] * 8 + [1.0] * 8 and ids[:8] == ANSWER_C_ZERO and ids[8:] == ANSWER_C_ONE   # canonical tie order: ascending id
+    # G, H (squared tables: distance = byte^2): where the reference's heap order picks ids [5,1,2] / [2,1,0], this build
+    # returns the canonical choice, ascending (distance, id), with the same distances
+    assert run(STREAM_G, 7, 3) == ([5, 1, 0], [1.0, 9.0, 25.0])
+    assert run(STREAM_H, 5, 3) == ([1, 2, 0], [4.0, 4.0, 16.0])
 
 
 @pytest.mark.gpu
