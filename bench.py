@@ -450,28 +450,46 @@ def main():
                      "ms_per_step": 1e3 * el / n_done,
                      "note": "the same steps back to back for >= %.1f s, a host synchronisation every %d steps" % (args.sustain_seconds, args.steps)}
 
-    # Host-to-host rate through the drop-in entry point dpq_query_batch (host pointers in and out: PCIe both ways and a
-    # synchronous call per batch), pinned host buffers; never used for `value`.
+    # Host-to-host rate through the drop-in boundary (host pointers in and out, PCIe both ways), page-locked buffers; never
+    # used for `value`.  Pipelined (dpq_query_batch_host_async: the copies of neighbouring batches beside a batch's
+    # kernels, settled by dpq_finish every `steps` batches) and, beside it, one synchronous dpq_query_batch per batch.
     host_to_host = None
     if world == 1 and args.host_steps > 0:
-        hq = [torch.from_numpy(b).pin_memory() for b in batches_np]
-        h_ids = torch.empty((nq, k), dtype=torch.int32).pin_memory()
-        h_d = torch.empty((nq, k), dtype=torch.float32).pin_memory()
+        hq = [api.pin_host(np.ascontiguousarray(b)) for b in batches_np]
+        h_out = [(api.pin_host(np.empty((nq, k), dtype=np.int32)), api.pin_host(np.empty((nq, k), dtype=np.float32))) for _ in range(4)]
         import ctypes as _ct
         from deltapq_amd import _lib as _l
         fn = _l.load().dpq_query_batch
         for i in range(2):
-            _l.check(fn(idx._h, _ct.c_void_p(hq[i % N_BATCHES].data_ptr()), nq, k, _ct.c_void_p(h_ids.data_ptr()), _ct.c_void_p(h_d.data_ptr())), "dpq_query_batch")
+            _l.check(fn(idx._h, _ct.c_void_p(hq[i % N_BATCHES].ctypes.data), nq, k, _ct.c_void_p(h_out[0][0].ctypes.data),
+                        _ct.c_void_p(h_out[0][1].ctypes.data)), "dpq_query_batch")
         t0 = time.perf_counter()
         for i in range(args.host_steps):
-            _l.check(fn(idx._h, _ct.c_void_p(hq[i % N_BATCHES].data_ptr()), nq, k, _ct.c_void_p(h_ids.data_ptr()), _ct.c_void_p(h_d.data_ptr())), "dpq_query_batch")
-        el = time.perf_counter() - t0
+            _l.check(fn(idx._h, _ct.c_void_p(hq[i % N_BATCHES].ctypes.data), nq, k, _ct.c_void_p(h_out[0][0].ctypes.data),
+                        _ct.c_void_p(h_out[0][1].ctypes.data)), "dpq_query_batch")
+        el_sync = time.perf_counter() - t0
+        for i in range(4):
+            idx.query_batch_host_async(hq[i % N_BATCHES], k, *h_out[i % 4])
+        idx.finish()
+        h_reps = []
+        for _ in range(5):
+            t0 = time.perf_counter()
+            for i in range(args.host_steps):
+                idx.query_batch_host_async(hq[i % N_BATCHES], k, *h_out[i % 4])
+            idx.finish()
+            h_reps.append(time.perf_counter() - t0)
+        el = float(np.median(h_reps))
         host_to_host = {"value": nq * args.host_steps / el, "unit": "queries/s", "ms_per_step": 1e3 * el / args.host_steps,
                         "steps": args.host_steps,
-                        "note": "dpq_query_batch: pinned host queries in (%d KB), ids + distances out (%d KB) per step, one synchronous call per batch"
-                                % (nq * args.dim * 4 // 1024, nq * k * 8 // 1024)}
+                        "note": "dpq_query_batch_host_async + dpq_finish: page-locked host queries in (%d KB), ids + distances out (%d KB) "
+                                "per step, up to four batches in flight, median of 5 runs of %d steps"
+                                % (nq * args.dim * 4 // 1024, nq * k * 8 // 1024, args.host_steps),
+                        "synchronous_dpq_query_batch": {"value": nq * args.host_steps / el_sync, "ms_per_step": 1e3 * el_sync / args.host_steps}}
         if args.check > 0 and wl["whole"]:
-            parity_gate(args, wl, batches_np[(args.host_steps - 1) % N_BATCHES][:4], h_ids.numpy(), h_d.numpy(), budget_s=5.0)
+            last = (args.host_steps - 1)
+            parity_gate(args, wl, batches_np[last % N_BATCHES][:4], h_out[last % 4][0], h_out[last % 4][1], budget_s=5.0)
+        for a in hq + [x for pair in h_out for x in pair]:
+            api.unpin_host(a)
 
     aux_steps = max(1, min(args.steps, 8))
     idx.profile_enable(1)

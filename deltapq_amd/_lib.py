@@ -99,6 +99,9 @@ SYMBOLS = [
     ("dpq_merge_topk_device", ctypes.c_int,
      [_VP, _VP, ctypes.c_int, ctypes.c_int, ctypes.c_int, _VP, _VP, ctypes.c_int, _VP]),
     ("dpq_merge_topk_device_packed", ctypes.c_int, [_VP, ctypes.c_int, ctypes.c_int, ctypes.c_int, _VP, _VP, ctypes.c_int, _VP]),
+    ("dpq_query_batch_host_async", ctypes.c_int, [_VP, _VP, ctypes.c_int, ctypes.c_int, _VP, _VP]),
+    ("dpq_pin_host", ctypes.c_int, [_VP, c_i64]),
+    ("dpq_unpin_host", ctypes.c_int, [_VP]),
     ("dpq_profile_enable", ctypes.c_int, [_VP, ctypes.c_int]),
     ("dpq_profile_reset", ctypes.c_int, [_VP]),
     ("dpq_profile_read", ctypes.c_int, [_VP, P(Profile)]),

@@ -305,6 +305,15 @@ class DeltaPQIndex:
               "dpq_query_batch")
         return ids, dists
 
+    def query_batch_host_async(self, queries, top_k, ids, dists):
+        """dpq_query_batch_host_async: host arrays in and out, enqueued only -- up to four batches in flight, queries up and
+        results down beside the kernels.  `queries` (float32 [nq][D], C-contiguous), `ids` (int32 [nq][k]) and `dists`
+        (float32 [nq][k]) belong to the library until finish(); pin them (pin_host) for the copies to overlap."""
+        assert queries.dtype == np.float32 and queries.flags.c_contiguous and ids.dtype == np.int32 and dists.dtype == np.float32
+        assert ids.flags.c_contiguous and dists.flags.c_contiguous and ids.shape == dists.shape == (queries.shape[0], top_k)
+        check(self._lib.dpq_query_batch_host_async(self._h, _np_ptr(queries), queries.shape[0], top_k, _np_ptr(ids), _np_ptr(dists)),
+              "dpq_query_batch_host_async")
+
     def query_batch_torch(self, queries, top_k, out_ids=None, out_dists=None, wait=True, ordered=False):
         """Device tensors in/out on torch's current stream (no host copies).  wait=False
         (dpq_query_batch_device_async) only enqueues the batch: keep the tensors alive and do
@@ -360,6 +369,16 @@ class DeltaPQIndex:
 
     def __exit__(self, *exc):
         self.close()
+
+
+def pin_host(arr):
+    """Page-lock a numpy array's memory (hipHostRegister through the library): host-to-host batches then overlap their copies."""
+    check(_lib.load().dpq_pin_host(_np_ptr(arr), arr.nbytes), "dpq_pin_host")
+    return arr
+
+
+def unpin_host(arr):
+    check(_lib.load().dpq_unpin_host(_np_ptr(arr)), "dpq_unpin_host")
 
 
 def merge_topk_host(ids, dists):

@@ -157,7 +157,25 @@ struct dpq_index {
         hipStream_t stream;          // the stream it runs on (the caller's, or one of the two lane streams)
         hipStream_t user_stream;     // the stream the caller enqueued it on
         int flag_slot;
+        int host_slot = -1;          // >= 0: a dpq_query_batch_host_async batch staged in host_slots[host_slot]
     };
+    // dpq_query_batch_host_async: up to kHostSlots batches in flight, each with its own staging buffers; queries go up
+    // on copy_in (the lanes' batches wait for it), results come down on copy_out behind the batch's last kernel
+    static constexpr int kHostSlots = 4;
+    struct HostSlot {
+        float* d_q = nullptr;
+        int32_t* d_ids = nullptr;
+        float* d_d = nullptr;
+        size_t qf = 0, oe = 0;       // capacities (floats / elements)
+        int32_t* h_ids = nullptr;    // the caller's buffers of the batch in flight
+        float* h_d = nullptr;
+        size_t n_out = 0;
+        bool busy = false, redo = false;
+        hipEvent_t kernels_done = nullptr;
+    };
+    HostSlot host_slots[kHostSlots];
+    hipStream_t copy_in = nullptr, copy_out = nullptr;
+    uint64_t host_seq = 0;
     // Pipelined batches alternate between two LANES = two workspaces + two internal streams, so that a batch's
     // table build runs under the previous batch's scan (the scan fills every CU's LDS and half its wave slots:
     // the LUT kernel needs neither) and its bootstrap next to the previous batch's select.  The d_* workspace
@@ -1725,6 +1743,14 @@ int dpq_close(dpq_index* x) {
     hipFree(x->d_q_stage);
     hipFree(x->d_ids_stage);
     hipFree(x->d_dists_stage);
+    for (auto& hs : x->host_slots) {
+        hipFree(hs.d_q);
+        hipFree(hs.d_ids);
+        hipFree(hs.d_d);
+        if (hs.kernels_done) hipEventDestroy(hs.kernels_done);
+    }
+    if (x->copy_in) hipStreamDestroy(x->copy_in);
+    if (x->copy_out) hipStreamDestroy(x->copy_out);
     if (x->h_overflow) hipHostFree(x->h_overflow);
     if (x->h_any) hipHostFree(x->h_any);
     hipFree(x->d_counters);
@@ -1778,9 +1804,27 @@ int dpq_finish(dpq_index* x) {
         // a query of this batch dropped candidates: answer the batch again, synchronously (it reruns what overflows)
         x->finish_reruns++;
         int rc = run_batch(x, p.d_queries, p.nq, p.top_k, p.d_ids, p.d_dists, p.stream);
+        if (p.host_slot >= 0) x->host_slots[p.host_slot].redo = true;  // its results went down before this
         if (rc && !first_rc) {
             first_rc = rc;
             first_msg = g_last_error;
+        }
+    }
+    // host-to-host batches: their results are on the way down (copy_out), or go down again after a rerun
+    bool any_host = false;
+    for (auto& hs : x->host_slots) any_host = any_host || hs.busy;
+    if (any_host) {
+        hipError_t e = x->copy_out ? hipStreamSynchronize(x->copy_out) : hipSuccess;
+        for (auto& hs : x->host_slots) {
+            if (hs.busy && hs.redo && e == hipSuccess) {
+                e = hipMemcpy(hs.h_ids, hs.d_ids, hs.n_out * sizeof(int32_t), hipMemcpyDeviceToHost);
+                if (e == hipSuccess) e = hipMemcpy(hs.h_d, hs.d_d, hs.n_out * sizeof(float), hipMemcpyDeviceToHost);
+            }
+            hs.busy = hs.redo = false;
+        }
+        if (e != hipSuccess && !first_rc) {
+            first_rc = DPQ_ERR_HIP;
+            first_msg = std::string("dpq_finish (results to the host): ") + hipGetErrorString(e);
         }
     }
     if (first_rc) return fail(first_rc, first_msg);
@@ -1790,7 +1834,7 @@ int dpq_finish(dpq_index* x) {
 
 namespace {
 int enqueue_async(dpq_index* x, const float* d_queries, int nq, int top_k, int32_t* d_ids, float* d_dists, void* hip_stream,
-                  bool allow_lanes);
+                  bool allow_lanes, int host_slot = -1);
 }
 
 int dpq_query_batch_device_async(dpq_index* x, const float* d_queries, int nq, int top_k, int32_t* d_ids,
@@ -1815,7 +1859,7 @@ int dpq_finish_count(dpq_index* x, int32_t* rerun_batches) {
 
 namespace {
 int enqueue_async(dpq_index* x, const float* d_queries, int nq, int top_k, int32_t* d_ids, float* d_dists, void* hip_stream,
-                  bool allow_lanes) {
+                  bool allow_lanes, int host_slot) {
     {
     int rc = check_batch_args(x, d_queries, nq, top_k, d_ids, d_dists);
     if (rc || nq == 0) return rc;
@@ -1882,7 +1926,7 @@ int enqueue_async(dpq_index* x, const float* d_queries, int nq, int top_k, int32
                        d_dists + (size_t)base * top_k, stream, slot);
         if (rc) return rc;
         x->pending.push_back({d_queries + (size_t)base * D, n, top_k, d_ids + (size_t)base * top_k,
-                              d_dists + (size_t)base * top_k, stream, user, slot});
+                              d_dists + (size_t)base * top_k, stream, user, slot, host_slot});
     }
     if (x->prof) {
         x->prof_acc.query_batches++;
@@ -1954,6 +1998,89 @@ int dpq_query_batch(dpq_index* x, const float* queries, int nq, int top_k, int32
     DPQ_HIP(hipDeviceSynchronize());
     DPQ_HIP(hipMemcpy(ids, x->d_ids_stage, oe * sizeof(int32_t), hipMemcpyDeviceToHost));
     DPQ_HIP(hipMemcpy(dists, x->d_dists_stage, oe * sizeof(float), hipMemcpyDeviceToHost));
+    return DPQ_OK;
+    });
+}
+
+// The reference's interface is host vectors in, host results out (h:2805-2810), one call per query (main:328-339).  Pipelined:
+// the queries of batch i + 1 go up and the results of batch i - 1 come down (two copy streams) beside batch i's kernels
+// (the two lanes of dpq_query_batch_device_async); dpq_finish settles everything and answers again, synchronously, any
+// batch in which a query overflowed its candidate buffers.
+int dpq_query_batch_host_async(dpq_index* x, const float* queries, int nq, int top_k, int32_t* ids, float* dists) {
+    return guarded([&]() -> int {
+    if (!x || !queries || !ids || !dists || nq < 0) return fail(DPQ_ERR_ARG, "NULL argument or nq < 0");
+    int rc = check_batch_args(x, queries, nq, top_k, ids, dists);
+    if (rc || nq == 0) return rc;
+    DPQ_HIP(hipSetDevice(x->device));
+    if (!x->copy_in) {
+        DPQ_HIP(hipStreamCreateWithFlags(&x->copy_in, hipStreamNonBlocking));
+        DPQ_HIP(hipStreamCreateWithFlags(&x->copy_out, hipStreamNonBlocking));
+    }
+    // batches enqueued through another entry point (another caller stream) are settled first: enqueue_async does that
+    int slot = (int)(x->host_seq % dpq_index::kHostSlots);
+    if (x->host_slots[slot].busy) {  // every slot in flight: settle them all (the oldest is the one wanted)
+        if ((rc = dpq_finish(x))) return rc;
+    }
+    x->host_seq++;
+    dpq_index::HostSlot& hs = x->host_slots[slot];
+    const size_t qf = (size_t)nq * x->M * x->Ds, oe = (size_t)nq * top_k;
+    if (qf > hs.qf) {
+        hipFree(hs.d_q);
+        hs.d_q = nullptr;
+        hs.qf = 0;
+        if ((rc = dev_alloc(&hs.d_q, qf))) return rc;
+        hs.qf = qf;
+    }
+    if (oe > hs.oe) {
+        hipFree(hs.d_ids);
+        hipFree(hs.d_d);
+        hs.d_ids = nullptr;
+        hs.d_d = nullptr;
+        hs.oe = 0;
+        if ((rc = dev_alloc(&hs.d_ids, oe)) || (rc = dev_alloc(&hs.d_d, oe))) return rc;
+        hs.oe = oe;
+    }
+    if (!hs.kernels_done) DPQ_HIP(hipEventCreateWithFlags(&hs.kernels_done, hipEventDisableTiming));
+    // (pageable caller memory makes this copy synchronous with the host; pinned memory -- dpq_pin_host -- lets it overlap)
+    DPQ_HIP(hipMemcpyAsync(hs.d_q, queries, qf * sizeof(float), hipMemcpyHostToDevice, x->copy_in));
+    const size_t first = x->pending.size();
+    if ((rc = enqueue_async(x, hs.d_q, nq, top_k, hs.d_ids, hs.d_d, x->copy_in, true, slot))) return rc;
+    // (enqueue_async may have settled older batches: the entries of this one are the pending tail)
+    const size_t begin = std::min(first, x->pending.size());
+    hs.h_ids = ids;
+    hs.h_d = dists;
+    hs.n_out = oe;
+    hs.busy = true;
+    hs.redo = false;
+    // results down once the batch's last kernel is through: the copy waits on every stream the batch's parts ran on
+    std::vector<hipStream_t> seen;
+    for (size_t i = begin; i < x->pending.size(); ++i) {
+        const auto& p = x->pending[i];
+        if (p.host_slot != slot || std::find(seen.begin(), seen.end(), p.stream) != seen.end()) continue;
+        seen.push_back(p.stream);
+        DPQ_HIP(hipEventRecord(hs.kernels_done, p.stream));
+        DPQ_HIP(hipStreamWaitEvent(x->copy_out, hs.kernels_done, 0));
+    }
+    DPQ_HIP(hipMemcpyAsync(ids, hs.d_ids, oe * sizeof(int32_t), hipMemcpyDeviceToHost, x->copy_out));
+    DPQ_HIP(hipMemcpyAsync(dists, hs.d_d, oe * sizeof(float), hipMemcpyDeviceToHost, x->copy_out));
+    return DPQ_OK;
+    });
+}
+
+// Page-locks / releases caller memory (hipHostRegister) so that dpq_query_batch_host_async's copies run beside the kernels;
+// for callers that do not link the HIP runtime themselves.
+int dpq_pin_host(void* ptr, int64_t bytes) {
+    return guarded([&]() -> int {
+    if (!ptr || bytes <= 0) return fail(DPQ_ERR_ARG, "NULL pointer or no bytes");
+    DPQ_HIP(hipHostRegister(ptr, (size_t)bytes, hipHostRegisterDefault));
+    return DPQ_OK;
+    });
+}
+
+int dpq_unpin_host(void* ptr) {
+    return guarded([&]() -> int {
+    if (!ptr) return fail(DPQ_ERR_ARG, "NULL pointer");
+    DPQ_HIP(hipHostUnregister(ptr));
     return DPQ_OK;
     });
 }

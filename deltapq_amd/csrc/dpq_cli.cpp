@@ -301,8 +301,24 @@ int main(int argc, char* argv[]) {
 
     const double t0 = Elapsed();  // main:327
     if (gpus == 1) {
-        rc = dpq_query_batch(shards[0], queries.data(), (int)nq, top_k, ids.data(), dists.data());
-        if (rc) return die("dpq_query_batch", rc);
+        // the reference's loop, one query per call (main:328-339), as batches in flight: host buffers in and out, the
+        // copies of neighbouring batches beside a batch's kernels (dpq_query_batch_host_async, page-locked buffers)
+        const int64_t chunk = 1024;
+        const int D = PQ_M * cDs;
+        dpq_pin_host(queries.data(), (int64_t)(queries.size() * sizeof(float)));   // (not fatal if refused: the copies then run unpipelined)
+        dpq_pin_host(ids.data(), (int64_t)(ids.size() * sizeof(int32_t)));
+        dpq_pin_host(dists.data(), (int64_t)(dists.size() * sizeof(float)));
+        for (int64_t q0 = 0; q0 < nq && !rc; q0 += chunk) {
+            const int n = (int)std::min<int64_t>(chunk, nq - q0);
+            rc = dpq_query_batch_host_async(shards[0], queries.data() + (size_t)q0 * D, n, top_k, ids.data() + (size_t)q0 * top_k,
+                                            dists.data() + (size_t)q0 * top_k);
+        }
+        if (rc) return die("dpq_query_batch_host_async", rc);
+        rc = dpq_finish(shards[0]);
+        if (rc) return die("dpq_finish", rc);
+        dpq_unpin_host(queries.data());
+        dpq_unpin_host(ids.data());
+        dpq_unpin_host(dists.data());
     } else {
         std::vector<int> rcs((size_t)gpus, 0);
         std::vector<std::string> msgs((size_t)gpus);

@@ -310,6 +310,15 @@ int dpq_query_batch_device(dpq_index* idx, const float* d_queries, int nq, int t
 int dpq_query_batch_device_async(dpq_index* idx, const float* d_queries, int nq, int top_k, int32_t* d_ids,
                                  float* d_dists, void* hip_stream);
 int dpq_finish(dpq_index* idx);
+/* The same pipeline with HOST buffers in and out -- the reference's interface (h:2805-2810: host query, host results),
+ * its per-query loop (main:328-339) turned into batches in flight: the queries of batch i + 1 go up and the results of
+ * batch i - 1 come down on two copy streams beside batch i's kernels.  Up to four batches in flight (a fifth call
+ * settles the earlier ones first); `queries`, `ids` and `dists` belong to the library until dpq_finish(idx) returns.  The
+ * copies overlap only from page-locked memory: dpq_pin_host / dpq_unpin_host (hipHostRegister) for callers that do not
+ * link the HIP runtime; pageable memory works, without the overlap. */
+int dpq_query_batch_host_async(dpq_index* idx, const float* queries, int nq, int top_k, int32_t* ids, float* dists);
+int dpq_pin_host(void* ptr, int64_t bytes);
+int dpq_unpin_host(void* ptr);
 /* Merge n_lists partial top-k lists per query (lists[l][nq][top_k]) into the
  * final top_k by (distance, id).  Host version for the single-process
  * multi-GPU CLI, device version for use after an RCCL all-gather. */

@@ -178,6 +178,40 @@ def test_pipelined_batches_on_two_lanes_and_streams(gpu, oracle, codebook):
             assert np.all(np.diff(dists.cpu().numpy(), axis=1) >= 0) and ids.min().item() >= 0
 
 
+def test_host_to_host_batches_in_flight(gpu, oracle, codebook):
+    """dpq_query_batch_host_async (the reference's interface: host query vectors in, host result lists out, h:2805-2810;
+    its per-query loop main:328-339 as batches in flight): seven batches of different sizes enqueued back to back -- more
+    than the four staging slots, so the fifth settles the first four -- from page-locked and from pageable memory, on
+    both decode placements; a batch that overflows its candidate buffers is answered again by finish() and goes down a
+    second time.  Every list equals the synchronous call's and the oracle's."""
+    from deltapq_amd import synth
+    n, k = 120_000, 40
+    tree, payload, _ = make_case(n, seed=411)
+    qs = synth.make_queries(1500, 128, seed=412)
+    cuts = [(0, 300), (300, 301), (301, 700), (700, 704), (704, 1100), (1100, 1163), (1163, 1500)]
+    for pinned, kw in ((True, {}), (False, {}), (True, dict(cand_capacity=64))):
+        with gpu.DeltaPQIndex.open_memory(payload, n, 8, 256, **kw) as idx:
+            idx.set_codebook(codebook)
+            want_i, want_d = idx.query_batch(qs, k)
+            q_in = [np.ascontiguousarray(qs[lo:hi]) for lo, hi in cuts]
+            out_i = [np.full((hi - lo, k), -7, dtype=np.int32) for lo, hi in cuts]
+            out_d = [np.full((hi - lo, k), -7.0, dtype=np.float32) for lo, hi in cuts]
+            if pinned:
+                for a in q_in + out_i + out_d:
+                    gpu.pin_host(a)
+            for q, oi, od in zip(q_in, out_i, out_d):
+                idx.query_batch_host_async(q, k, oi, od)
+            reruns = idx.finish()
+            if pinned:
+                for a in q_in + out_i + out_d:
+                    gpu.unpin_host(a)
+        assert (reruns > 0) == ("cand_capacity" in kw), (kw, reruns)
+        got_i, got_d = np.concatenate(out_i), np.concatenate(out_d)
+        assert np.array_equal(got_i, want_i) and np.array_equal(got_d.view(np.uint32), want_d.view(np.uint32)), (pinned, kw)
+    pick = [0, 300, 702, 1499]
+    assert_parity(want_i[pick], want_d[pick], oracle_topk(oracle, payload, n, codebook, qs[pick], k), n)
+
+
 def test_stream_ordered_batches_feed_device_consumers(gpu, oracle, codebook):
     """dpq_query_batch_device_ordered: the result is consumed on the device in stream order (here: copied by a torch
     op enqueued right behind it, as the sharded driver's pack + all-gather are), no host round trip; finish() reports
