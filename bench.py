@@ -456,7 +456,8 @@ def main():
     host_to_host = None
     if world == 1 and args.host_steps > 0:
         hq = [api.pin_host(np.ascontiguousarray(b)) for b in batches_np]
-        h_out = [(api.pin_host(np.empty((nq, k), dtype=np.int32)), api.pin_host(np.empty((nq, k), dtype=np.float32))) for _ in range(4)]
+        NH = 16   # batches in flight own their result buffers (dpq_query_batch_host_async: up to sixteen)
+        h_out = [(api.pin_host(np.empty((nq, k), dtype=np.int32)), api.pin_host(np.empty((nq, k), dtype=np.float32))) for _ in range(NH)]
         import ctypes as _ct
         from deltapq_amd import _lib as _l
         fn = _l.load().dpq_query_batch
@@ -469,25 +470,25 @@ def main():
                         _ct.c_void_p(h_out[0][1].ctypes.data)), "dpq_query_batch")
         el_sync = time.perf_counter() - t0
         for i in range(4):
-            idx.query_batch_host_async(hq[i % N_BATCHES], k, *h_out[i % 4])
+            idx.query_batch_host_async(hq[i % N_BATCHES], k, *h_out[i % NH])
         idx.finish()
         h_reps = []
         for _ in range(5):
             t0 = time.perf_counter()
             for i in range(args.host_steps):
-                idx.query_batch_host_async(hq[i % N_BATCHES], k, *h_out[i % 4])
+                idx.query_batch_host_async(hq[i % N_BATCHES], k, *h_out[i % NH])
             idx.finish()
             h_reps.append(time.perf_counter() - t0)
         el = float(np.median(h_reps))
         host_to_host = {"value": nq * args.host_steps / el, "unit": "queries/s", "ms_per_step": 1e3 * el / args.host_steps,
                         "steps": args.host_steps,
                         "note": "dpq_query_batch_host_async + dpq_finish: page-locked host queries in (%d KB), ids + distances out (%d KB) "
-                                "per step, up to four batches in flight, median of 5 runs of %d steps"
+                                "per step, up to sixteen batches in flight (results written by the select kernel into the mapped buffers), median of 5 runs of %d steps"
                                 % (nq * args.dim * 4 // 1024, nq * k * 8 // 1024, args.host_steps),
                         "synchronous_dpq_query_batch": {"value": nq * args.host_steps / el_sync, "ms_per_step": 1e3 * el_sync / args.host_steps}}
         if args.check > 0 and wl["whole"]:
             last = (args.host_steps - 1)
-            parity_gate(args, wl, batches_np[last % N_BATCHES][:4], h_out[last % 4][0], h_out[last % 4][1], budget_s=5.0)
+            parity_gate(args, wl, batches_np[last % N_BATCHES][:4], h_out[last % NH][0], h_out[last % NH][1], budget_s=5.0)
         for a in hq + [x for pair in h_out for x in pair]:
             api.unpin_host(a)
 

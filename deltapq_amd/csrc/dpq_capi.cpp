@@ -161,7 +161,7 @@ struct dpq_index {
     };
     // dpq_query_batch_host_async: up to kHostSlots batches in flight, each with its own staging buffers; queries go up
     // on copy_in (the lanes' batches wait for it), results come down on copy_out behind the batch's last kernel
-    static constexpr int kHostSlots = 4;
+    static constexpr int kHostSlots = 16;
     struct HostSlot {
         float* d_q = nullptr;
         int32_t* d_ids = nullptr;
@@ -171,6 +171,7 @@ struct dpq_index {
         float* h_d = nullptr;
         size_t n_out = 0;
         bool busy = false, redo = false;
+        bool direct = false;         // the result buffers are page-locked and mapped: the select kernel writes them itself
         hipEvent_t kernels_done = nullptr;
     };
     HostSlot host_slots[kHostSlots];
@@ -1816,7 +1817,7 @@ int dpq_finish(dpq_index* x) {
     if (any_host) {
         hipError_t e = x->copy_out ? hipStreamSynchronize(x->copy_out) : hipSuccess;
         for (auto& hs : x->host_slots) {
-            if (hs.busy && hs.redo && e == hipSuccess) {
+            if (hs.busy && hs.redo && !hs.direct && e == hipSuccess) {
                 e = hipMemcpy(hs.h_ids, hs.d_ids, hs.n_out * sizeof(int32_t), hipMemcpyDeviceToHost);
                 if (e == hipSuccess) e = hipMemcpy(hs.h_d, hs.d_d, hs.n_out * sizeof(float), hipMemcpyDeviceToHost);
             }
@@ -2031,7 +2032,14 @@ int dpq_query_batch_host_async(dpq_index* x, const float* queries, int nq, int t
         if ((rc = dev_alloc(&hs.d_q, qf))) return rc;
         hs.qf = qf;
     }
-    if (oe > hs.oe) {
+    // Page-locked result buffers (dpq_pin_host / hipHostRegister / hipHostMalloc) are mapped into the device's address
+    // space: the select kernel then writes the lists straight into them (posted writes over PCIe) and no copy is
+    // enqueued at all -- a hipMemcpyAsync costs the host ~10 us, three of them per batch held the pipelined rate at the
+    // synchronous call's.  Pageable buffers take staging buffers and copies on copy_out.
+    void *m_ids = nullptr, *m_d = nullptr;
+    const bool direct = hipHostGetDevicePointer(&m_ids, ids, 0) == hipSuccess && hipHostGetDevicePointer(&m_d, dists, 0) == hipSuccess;
+    if (!direct) (void)hipGetLastError();  // (an unregistered pointer is not an error of this call)
+    if (!direct && oe > hs.oe) {
         hipFree(hs.d_ids);
         hipFree(hs.d_d);
         hs.d_ids = nullptr;
@@ -2044,7 +2052,9 @@ int dpq_query_batch_host_async(dpq_index* x, const float* queries, int nq, int t
     // (pageable caller memory makes this copy synchronous with the host; pinned memory -- dpq_pin_host -- lets it overlap)
     DPQ_HIP(hipMemcpyAsync(hs.d_q, queries, qf * sizeof(float), hipMemcpyHostToDevice, x->copy_in));
     const size_t first = x->pending.size();
-    if ((rc = enqueue_async(x, hs.d_q, nq, top_k, hs.d_ids, hs.d_d, x->copy_in, true, slot))) return rc;
+    int32_t* const out_ids = direct ? static_cast<int32_t*>(m_ids) : hs.d_ids;
+    float* const out_d = direct ? static_cast<float*>(m_d) : hs.d_d;
+    if ((rc = enqueue_async(x, hs.d_q, nq, top_k, out_ids, out_d, x->copy_in, true, slot))) return rc;
     // (enqueue_async may have settled older batches: the entries of this one are the pending tail)
     const size_t begin = std::min(first, x->pending.size());
     hs.h_ids = ids;
@@ -2052,6 +2062,8 @@ int dpq_query_batch_host_async(dpq_index* x, const float* queries, int nq, int t
     hs.n_out = oe;
     hs.busy = true;
     hs.redo = false;
+    hs.direct = direct;
+    if (direct) return DPQ_OK;
     // results down once the batch's last kernel is through: the copy waits on every stream the batch's parts ran on
     std::vector<hipStream_t> seen;
     for (size_t i = begin; i < x->pending.size(); ++i) {

@@ -312,10 +312,11 @@ int dpq_query_batch_device_async(dpq_index* idx, const float* d_queries, int nq,
 int dpq_finish(dpq_index* idx);
 /* The same pipeline with HOST buffers in and out -- the reference's interface (h:2805-2810: host query, host results),
  * its per-query loop (main:328-339) turned into batches in flight: the queries of batch i + 1 go up and the results of
- * batch i - 1 come down on two copy streams beside batch i's kernels.  Up to four batches in flight (a fifth call
- * settles the earlier ones first); `queries`, `ids` and `dists` belong to the library until dpq_finish(idx) returns.  The
- * copies overlap only from page-locked memory: dpq_pin_host / dpq_unpin_host (hipHostRegister) for callers that do not
- * link the HIP runtime; pageable memory works, without the overlap. */
+ * batch i - 1 come down beside batch i's kernels.  Up to sixteen batches in flight (a seventeenth call
+ * settles the earlier ones first); `queries`, `ids` and `dists` belong to the library until dpq_finish(idx) returns.  Page-locked
+ * buffers (dpq_pin_host / dpq_unpin_host = hipHostRegister, for callers that do not link the HIP runtime) make it a
+ * pipeline: the queries go up on a copy stream and the result lists are written by the select kernel straight into the
+ * mapped buffers; pageable memory works through staging copies, without the overlap. */
 int dpq_query_batch_host_async(dpq_index* idx, const float* queries, int nq, int top_k, int32_t* ids, float* dists);
 int dpq_pin_host(void* ptr, int64_t bytes);
 int dpq_unpin_host(void* ptr);

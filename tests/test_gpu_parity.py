@@ -180,8 +180,8 @@ def test_pipelined_batches_on_two_lanes_and_streams(gpu, oracle, codebook):
 
 def test_host_to_host_batches_in_flight(gpu, oracle, codebook):
     """dpq_query_batch_host_async (the reference's interface: host query vectors in, host result lists out, h:2805-2810;
-    its per-query loop main:328-339 as batches in flight): seven batches of different sizes enqueued back to back -- more
-    than the four staging slots, so the fifth settles the first four -- from page-locked and from pageable memory, on
+    its per-query loop main:328-339 as batches in flight): seven batches of different sizes enqueued back to back from page-locked memory (result lists written by the select
+    kernel into the mapped buffers) and from pageable memory (staging copies), then twenty more than the sixteen slots, on
     both decode placements; a batch that overflows its candidate buffers is answered again by finish() and goes down a
     second time.  Every list equals the synchronous call's and the oracle's."""
     from deltapq_amd import synth
@@ -202,6 +202,13 @@ def test_host_to_host_batches_in_flight(gpu, oracle, codebook):
             for q, oi, od in zip(q_in, out_i, out_d):
                 idx.query_batch_host_async(q, k, oi, od)
             reruns = idx.finish()
+            if not kw:   # more calls than slots: the seventeenth settles the earlier ones
+                many = [(np.ascontiguousarray(qs[j:j + 3]), np.empty((3, k), np.int32), np.empty((3, k), np.float32)) for j in range(0, 60, 3)]
+                for q, oi, od in many:
+                    idx.query_batch_host_async(q, k, oi, od)
+                idx.finish()
+                for j, (q, oi, od) in enumerate(many):
+                    assert np.array_equal(oi, want_i[3 * j:3 * j + 3]) and np.array_equal(od.view(np.uint32), want_d[3 * j:3 * j + 3].view(np.uint32)), j
             if pinned:
                 for a in q_in + out_i + out_d:
                     gpu.unpin_host(a)
