@@ -100,6 +100,18 @@ def build_workload(args, device, rank, world, by_query):
     stream:   only this rank's part, as a self-contained stream with its global position (N > 1, index shards)."""
     from deltapq_amd import api, synth
     t0 = time.time()
+    # --index-dir: the pipeline-built index (codebook + DTC payload) cached on disk, so that a profiled run (rocprofv3
+    # --pmc passes collect counters per dispatch) holds the QUERY path only -- building 1 M codes at M = 16 inside the
+    # profiled process was 3.9 M dispatches and timed the counter passes out
+    cache = None
+    if args.index_dir and args.data == "pipeline":
+        os.makedirs(args.index_dir, exist_ok=True)
+        cache = os.path.join(args.index_dir, "pipeline_n%d_m%d_d%d.npz" % (args.n, args.m, args.dim))
+        if os.path.exists(cache):
+            z = np.load(cache)
+            kw = dict(shard_rank=0 if by_query else rank, shard_count=1 if by_query else world)
+            return dict(codebook=z["codebook"], payload=z["payload"], n_local=args.n, n_bytes_local=len(z["payload"]), open_kwargs=kw,
+                        offset=0, whole=True, gen_s=time.time() - t0, desc=str(z["desc"]) + " (index loaded from --index-dir)")
     if args.data == "pipeline":
         if args.n > 8_000_000:
             raise SystemExit("--data pipeline builds the whole index on every rank: use --data stream beyond 8 M codes")
@@ -112,9 +124,12 @@ def build_workload(args, device, rank, world, by_query):
         uniq = len(np.unique(codes.view("V%d" % args.m))) / args.n
         tree.close()
         kw = dict(shard_rank=0 if by_query else rank, shard_count=1 if by_query else world)
+        desc = "vectors->kmeans->PQ encode->built DeltaTree, %.1f%% unique codes" % (100 * uniq)
+        if cache and rank == 0:
+            np.savez(cache + ".tmp.npz", codebook=cb, payload=payload, desc=desc)
+            os.replace(cache + ".tmp.npz", cache)
         return dict(codebook=cb, payload=payload, n_local=args.n, n_bytes_local=len(payload), open_kwargs=kw, offset=0,
-                    whole=True, gen_s=time.time() - t0,
-                    desc="vectors->kmeans->PQ encode->built DeltaTree, %.1f%% unique codes" % (100 * uniq))
+                    whole=True, gen_s=time.time() - t0, desc=desc)
     cb = synth.make_codebook(args.m, 256, args.dim // args.m, seed=100)
     if by_query or world == 1:
         tree = synth.synth_tree_large(args.n, args.m, seed=102, mean_diffs=args.mean_diffs)
@@ -247,6 +262,10 @@ def main():
                          "holds the whole index and answers its own batch (weak scaling, no collective)")
     ap.add_argument("--sharded-streams", type=int, default=2,
                     help="index shards: stream-ordered steps alternate between this many torch streams (1 or 2)")
+    ap.add_argument("--index-dir", default="",
+                    help="--data pipeline: cache the built index (codebook + DTC payload) in this directory and load it from there "
+                         "when present: profiled runs then hold the query path only")
+    ap.add_argument("--build-only", action="store_true", help="with --index-dir: build + cache the index and exit")
     ap.add_argument("--no-hbm-leg", action="store_true",
                     help="skip the HBM-regime leg of the default N = 1 run (one query per call on a 125 M-code index, in a child process)")
     ap.add_argument("--no-replicas", action="store_true",
@@ -304,6 +323,10 @@ def main():
     by_query = world > 1 and args.shard == "query"
     nq, k = args.queries, args.topk
     wl = build_workload(args, local_rank, rank, world, by_query)
+    if args.build_only:
+        if rank == 0:
+            print(json.dumps({"built": wl["desc"], "seconds": wl["gen_s"], "index_dir": args.index_dir}))
+        return
 
     def open_index(**kw):
         idx = api.DeltaPQIndex.open_memory(wl["payload"], wl["n_local"], args.m, 256, device=local_rank,
