@@ -97,6 +97,12 @@ struct Tuning {
     bool relabel = true, fuse_quantise = true, async_overlap = true, boot_fullsort = false, tighten = true, strands = true,
          force_strands = false, strand1 = true;
     int s1_debug = 0;  // developer experiments of strand1_kernel  [DPQ_S1_DEBUG]
+    // a lane's scan waits for the other lane's previous select: 0 = never (default), 1 = only for the second batch of a
+    // burst, 2 = every batch  [DPQ_LANE_GATE].  Measured (scripts/gpu_lane_gate.sh, same box, M q/s): 0: 6.24 / 6.48,
+    // 1: 6.46 / 6.30, 2: 5.89 -- the gate turns the lanes' lockstep (both bootstraps, then both scans, then both selects:
+    // profiles/r04_timeline_default.txt) into the staggered order (profiles/r04_timeline_lane_gate.txt: a step = scan +
+    // select beside the other lane's bootstrap + a 12 us event wait) and the step does not get shorter: kept as a knob.
+    int lane_gate = 0;
     int s1_scatter = 0;  // ... its one level in the low-discrepancy strip order instead of storage order  [DPQ_S1_SCATTER=1]
     bool dummy_ = false;  // strand1: one query per pass takes strand1_kernel  [DPQ_STRAND1=0: strand_kernel<1>]
 };
@@ -193,6 +199,15 @@ struct dpq_index {
     int active_lane = 0;
     hipStream_t lane_stream[2] = {nullptr, nullptr};
     hipEvent_t lane_ready[2] = {nullptr, nullptr};   // recorded on the caller's stream: the batch's inputs are there
+    // recorded behind a laned batch's last select: the OTHER lane's next scan waits for it.  Without it the two lanes fall
+    // into lockstep (kernel-trace timeline, profiles/r04_timeline_*): both bootstraps side by side, then both scans one
+    // after the other -- the second scan's workgroups take every CU the first one frees, and the first batch's select
+    // (35 KB of LDS) starves until the second scan's tail: 2 scans + select + bootstrap per 2 steps.  With the wait a step is
+    // scan + max(select, the other lane's bootstrap).
+    hipEvent_t lane_select_done[2] = {nullptr, nullptr};
+    bool lane_select_recorded[2] = {false, false};
+    int run_lane = -1;               // >= 0 while run_batch enqueues a laned batch: its lane
+    bool gate_this_batch = false;    // the batch being enqueued is the second of a burst (one batch in flight, on the other lane)
     uint64_t async_seq = 0;
     hipStream_t ordered_stream[2] = {nullptr, nullptr};  // caller streams with stream-ordered batches: stream k <-> workspace k
     bool ordered_stream_set[2] = {false, false};
@@ -285,6 +300,7 @@ Tuning resolve_tuning(const dpq_open_opts& o) {
         v = 1; geti("DPQ_STRAND1", &v); t.strand1 = t.strand1 && v != 0;
         geti("DPQ_S1_DEBUG", &t.s1_debug);
         geti("DPQ_S1_SCATTER", &t.s1_scatter);
+        geti("DPQ_LANE_GATE", &t.lane_gate);
     }
     return t;
 }
@@ -681,6 +697,7 @@ int run_batch(dpq_index* x, const float* d_queries, int nq, int top_k, int32_t* 
         return DPQ_OK;
     }
     bool boot_built_tables = false;
+    bool scan_gate_passed = false;
     for (size_t l = 0; l < n_levels; ++l) {
         const bool final_pass = l + 1 == n_levels;
         if (l == 0 && x->boot) {
@@ -739,6 +756,12 @@ int run_batch(dpq_index* x, const float* d_queries, int nq, int top_k, int32_t* 
             se.shared_id = nullptr;
             se.shared_code = nullptr;
             se.shared_n = 0;
+            // a laned batch's first scan lets the other lane's previous batch finish its select first (see lane_select_done)
+            if (x->run_lane >= 0 && !scan_gate_passed && (x->tune.lane_gate == 1 ? x->gate_this_batch : x->tune.lane_gate == 2)) {
+                const int other = x->run_lane ^ 1;
+                if (x->lane_select_recorded[other]) DPQ_HIP(hipStreamWaitEvent(stream, x->lane_select_done[other], 0));
+                scan_gate_passed = true;
+            }
             // filter scan of the next slice of segments; appends behind the carried winners
             sa.seg_list = x->d_order + x->level_off[l];
             sa.n_seg_pass = x->level_cnt[l];
@@ -1713,6 +1736,7 @@ int dpq_close(dpq_index* x) {
     for (int l = 0; l < 2; ++l) {
         if (x->lane_stream[l]) hipStreamDestroy(x->lane_stream[l]);
         if (x->lane_ready[l]) hipEventDestroy(x->lane_ready[l]);
+        if (x->lane_select_done[l]) hipEventDestroy(x->lane_select_done[l]);
     }
     hipFree(x->d_st_ckpt);
     hipFree(x->d_st_mask);
@@ -1922,9 +1946,17 @@ int enqueue_async(dpq_index* x, const float* d_queries, int nq, int top_k, int32
             stream = x->lane_stream[lane];
             DPQ_HIP(hipEventRecord(x->lane_ready[lane], user));
             DPQ_HIP(hipStreamWaitEvent(stream, x->lane_ready[lane], 0));
+            if (!x->lane_select_done[lane]) DPQ_HIP(hipEventCreateWithFlags(&x->lane_select_done[lane], hipEventDisableTiming));
+            x->run_lane = lane;
+            x->gate_this_batch = x->pending.size() == 1;
         }
         rc = run_batch(x, d_queries + (size_t)base * D, n, top_k, d_ids + (size_t)base * top_k,
                        d_dists + (size_t)base * top_k, stream, slot);
+        if (x->run_lane >= 0 && !rc) {
+            hipError_t e = hipEventRecord(x->lane_select_done[x->run_lane], stream);
+            x->lane_select_recorded[x->run_lane] = e == hipSuccess;
+        }
+        x->run_lane = -1;
         if (rc) return rc;
         x->pending.push_back({d_queries + (size_t)base * D, n, top_k, d_ids + (size_t)base * top_k,
                               d_dists + (size_t)base * top_k, stream, user, slot, host_slot});

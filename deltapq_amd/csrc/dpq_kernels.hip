@@ -116,6 +116,14 @@ __global__ __launch_bounds__(256) void lut_build_kernel(const float* __restrict_
                                                          float* __restrict__ lut_min, uint32_t* __restrict__ cand_count,
                                                          uint32_t* __restrict__ overflow, const uint8_t* __restrict__ relabel,
                                                          float* __restrict__ lut_labels, uint32_t* __restrict__ tight_hist) {
+    // This kernel (and decode_list_kernel) runs UNDER the previous pipelined batch's scan: the scan's sixteen wavefronts per
+    // CU take instruction issue by age, and what is left made a 15 us table build take 85 us (kernel-trace timeline,
+    // profiles/r04_timeline_default.txt) -- on the critical path of the lane's next bootstrap.  Raised wave priority gives
+    // these few wavefronts the issue slots they ask for; the scan loses as much as they use, no more.
+#ifndef DPQ_UNDER_SCAN_PRIO
+#define DPQ_UNDER_SCAN_PRIO 3
+#endif
+    __builtin_amdgcn_s_setprio(DPQ_UNDER_SCAN_PRIO);
     const int q0 = blockIdx.x * kLutQueries, m = blockIdx.y, k = threadIdx.x;
     if (m == 0 && k < kLutQueries && q0 + k < n_slots) {
         if (cand_count) cand_count[q0 + k] = 0;
@@ -467,6 +475,7 @@ __global__ __launch_bounds__(256) void decode_list_kernel(const DeviceImage img,
     // relabel[m][code value] = the label the scratch (and the batch's tables) use; read from global memory (2-4 KB, L1):
     // this kernel must not ask for LDS -- a workgroup that does is only placed where a scan workgroup has retired, and
     // the decode of the next pipelined batch then runs in the scan's tail instead of under it (as lut_build_kernel did)
+    __builtin_amdgcn_s_setprio(DPQ_UNDER_SCAN_PRIO);  // (see lut_build_kernel)
     const int lane = threadIdx.x & 63;
     const int64_t j = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (j >= n_seg) return;
