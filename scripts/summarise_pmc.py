@@ -46,10 +46,14 @@ if "FETCH_SIZE" in sc and "WRITE_SIZE" in sc:
     summary["scan_kernel_avg_launch_ms_kernel_trace"] = sc["stats"]["avg_ns"] / 1e6
     summary["scan_kernel_hbm_GBps"] = summary["scan_kernel_hbm_bytes_per_launch"] / (summary["scan_kernel_avg_launch_ms_kernel_trace"] * 1e-3) / 1e9
 # the stream pass: strand_kernel (lane per run, M = 8 with a bootstrap) or stream_kernel (wavefront per chunk)
-st = next((v for k, v in summary["kernels"].items() if k.startswith("dpq::strand_kernel")), None) or \
-     next((v for k, v in summary["kernels"].items() if k.startswith("dpq::stream_kernel")), {})
-summary["stream_pass_kernel"] = next((k for k in summary["kernels"] if k.startswith("dpq::strand_kernel")), None) or \
-                                next((k for k in summary["kernels"] if k.startswith("dpq::stream_kernel")), None)
+def first(prefixes):
+    for pre in prefixes:
+        for k, v in summary["kernels"].items():
+            if k.startswith(pre):
+                return k, v
+    return None, {}
+# (one query per pass: strand1_kernel; several: strand_kernel; small shards / M = 16: stream_kernel)
+summary["stream_pass_kernel"], st = first(("dpq::strand1_kernel", "dpq::strand_kernel", "dpq::stream_kernel"))
 if "FETCH_SIZE" in st and "WRITE_SIZE" in st:   # one query per pass
     summary["stream_kernel_hbm_bytes_per_launch"] = 2 * st["FETCH_SIZE"]["mean_kib"] * 1024 + st["WRITE_SIZE"]["mean_kib"] * 1024
     summary["stream_kernel_avg_launch_ms_kernel_trace"] = st["stats"]["avg_ns"] / 1e6
