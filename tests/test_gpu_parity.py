@@ -434,29 +434,36 @@ def test_cli_query_matches_oracle(gpu, oracle, tmp_path):
         assert [int(t[0]) for t in top1[-50:]] == ids[:, 0].tolist()
 
 
-def test_full_size_sift1m_shape(gpu, oracle, codebook):
-    """BASELINE configs[1] at full size: 1M codes, top-100.  Full oracle parity on a
-    query sample plus size-independent properties on the whole batch."""
+def test_full_size_sift1m_shape(gpu, oracle):
+    """BASELINE configs[1] at full size, on the index the bench measures: 1 M SIFT-shaped vectors -> k-means codebook -> GPU
+    PQ encode -> GPU DeltaTree build -> DTC, one batch of 1000 queries, top-100.  Full oracle parity on 32 sampled queries,
+    size-independent properties on all 1000: ascending distances, k distinct ids in range, every distance = the fp64 sum of
+    the query's table entries over the decoded code of its id (rounded once), every node filtered exactly once per query."""
     from deltapq_amd import synth
-    n, nq, k = 1_000_000, 256, 100
-    tree = synth.synth_tree(n, 8, seed=102, mean_diffs=3.0)
-    payload, nb = synth.encode_dtc(tree)
-    qs = synth.make_queries(nq, 128, seed=101)
-    ids, dists, prof, info = run(gpu, payload, n, codebook, qs, k)
-    assert info["algorithmic_bytes"] == nb
-    sample = list(range(0, nq, 16))
-    assert_parity(ids[sample], dists[sample], oracle_topk(oracle, payload, n, codebook, qs[sample], k), n)
-    # properties for every query: ascending, unique ids in range, distance == fp64 sum over the decoded code
-    lut0 = oracle.build_lut(codebook, qs[1])
-    _, _, _, codes = oracle.scan_lut(payload, n, lut0, 1, want_all=True)
+    n, nq, k, M = 1_000_000, 1000, 100, 8
+    base = synth.make_clustered_vectors(n, 128, seed=100, n_clusters=20000, spread=12.0, centre_seed=7)
+    cb = synth.kmeans_codebook(base, M, 256, iters=6, seed=102)
+    codes = gpu.encode_pq(base, cb)
+    del base
+    tree = gpu.DeltaTree(codes, codebook=cb, device=0)
+    payload = tree.payload()
+    tree.close()
+    nb = len(payload)
+    qs = synth.make_clustered_vectors(nq, 128, seed=101, n_clusters=20000, spread=12.0, centre_seed=7)
+    ids, dists, prof, info = run(gpu, payload, n, cb, qs, k)
+    assert info["algorithmic_bytes"] == nb and 3.5 < nb / n < 5.5                 # ~4.3 B per code
+    sample = list(range(0, nq, 32))[:32]
+    assert_parity(ids[sample], dists[sample], oracle_topk(oracle, payload, n, cb, qs[sample], k), n)
+    lut0 = oracle.build_lut(cb, qs[1])
+    _, _, _, dcodes = oracle.scan_lut(payload, n, lut0, 1, want_all=True)
     assert np.all(np.diff(dists, axis=1) >= 0)
     for r in range(nq):
         assert len(set(ids[r].tolist())) == k and ids[r].min() >= 0 and ids[r].max() <= n
-        lut = oracle.build_lut(codebook, qs[r])
+        lut = oracle.build_lut(cb, qs[r])
         pos = np.where(ids[r] == n, n - 1, ids[r])
-        s = sum(lut[m, codes[pos, m]].astype(np.float64) for m in range(8)).astype(np.float32)
+        s = sum(lut[m, dcodes[pos, m]].astype(np.float64) for m in range(M)).astype(np.float32)
         assert np.array_equal(s.view(np.uint32), dists[r].view(np.uint32))
-    # every node scanned exactly once per query by the cascade
+    # every node scanned exactly once per query by the plan's levels
     assert prof["scan_node_query_pairs"] == info["n_segments"] * 64 * info["chunks_per_segment"] * nq
 
 
