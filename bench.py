@@ -45,7 +45,8 @@ def pmc_traffic(args, world):
     """HBM bytes per scan-kernel launch from the committed rocprofv3 --pmc passes (scripts/collect_pmc.sh:
     FETCH_SIZE and WRITE_SIZE in separate runs, gfx950 x2 read correction).  Valid for the workload it was
     taken on: the summary names it."""
-    for name in ("r03_pmc_summary_default.json", "r03_pmc_summary_125M.json", "r03_pmc_summary_125M_stream.json",
+    for name in ("r04_pmc_summary_default.json", "r04_pmc_summary_125M_stream.json", "r04_pmc_summary_m16_top1000.json",
+                 "r03_pmc_summary_default.json", "r03_pmc_summary_125M.json", "r03_pmc_summary_125M_stream.json",
                  "r02_pmc_summary_default.json", "r02_pmc_summary_125M.json", "r02_pmc_summary_125M_stream.json"):
         path = os.path.join(HERE, "profiles", name)
         if not os.path.exists(path):
