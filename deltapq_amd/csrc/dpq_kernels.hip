@@ -1745,11 +1745,14 @@ __global__ __launch_bounds__(kStrandThreads, Q >= 4 ? 2 : Q == 2 ? 3 : 4) void s
 //    entry[m][c] = min(floor((T[m][c] - min_m) s), 255), s = QT / (tau' - sum of minima) -- floor and min only lower an
 //    entry, so a node within the threshold has sum <= QT; what the bound lets through (a few per million nodes) is
 //    summed exactly (fp64 sum of the fp32 entries, the reference's distance) and compared as a whole (distance, id) key.
-//    The table is ONE 8-byte row per code value c -- byte m = entry of sub-space m -- stored once per LDS bank pair:
-//    Tq[c][lane mod 32], 64 KB.  A lane's ds_read_b64 at (c << 8 | (lane mod 32) << 3) then hits its own two banks
-//    whatever c is: eight conflict-free gathers = 16 LDS cycles per 64 nodes instead of ~56, and the address is one
-//    v_perm_b32 (the code byte lands on bits 8..15).  A lane owns its accumulator (32 bits: no saturation tricks, QT = 250
-//    units instead of the batched scan's 64).
+//    The table holds the eight entries of a code value c as TWO words (sub-spaces 0..3, 4..7), each stored once per LDS
+//    bank: word (c, half, lane mod 32) at c << 8 | half << 7 | (lane mod 32) << 2, 64 KB.  A lane's ds_read_u8 at
+//    (c << 8 | (lane mod 32) << 2) + offset:(half << 7 | m & 3) hits its own bank whatever c is (a 4-byte-class DS access
+//    serves 32 lanes per pass: SQ_LDS_BANK_CONFLICT 14 cycles per launch); the address is one v_perm_b32 (the code byte
+//    lands on bits 8..15), the eight bytes are added with v_add3_u32.  A lane owns its accumulator (no saturation tricks,
+//    QT = 250 units instead of the batched scan's 64).  (DPQ_S1_U8 = 0 keeps the round's first shape: 8-byte rows per
+//    bank pair read whole with ds_read_b64, the wanted byte added with v_dot4 against a one-hot constant: 2 VALU
+//    instructions per node more, 8 VGPRs more, 2 % slower.)
 //  * the changed bytes never touch LDS: a lane loads the <= 8 bytes of each of its next four nodes with FOUR unaligned
 //    8-byte global loads at exactly the node's byte offset (the wave prefix sum of the masks' popcounts gives a lane's
 //    offset in the phase, the popcounts of its own earlier masks the rest), a phase ahead.  No row parking, no
@@ -1775,10 +1778,16 @@ __global__ __launch_bounds__(kStrandThreads, Q >= 4 ? 2 : Q == 2 ? 3 : 4) void s
 #ifndef DPQ_S1_SKIP
 #define DPQ_S1_SKIP 0  // (timing experiments only, wrong results: 1 no ADC, 2 no stack / selector traffic, 4 no changed-byte loads)
 #endif
+#ifndef DPQ_S1_U8
+#define DPQ_S1_U8 1  // bound rows as two words per code value and bank, entries read with ds_read_u8 and added; 0: round 4's first shape, 8-byte rows + v_dot4
+#endif
 #ifndef DPQ_S1_DEPTH
 #define DPQ_S1_DEPTH 1  // phases the changed bytes are fetched ahead of their decode (headers: two more)
 #endif
-constexpr int kS1Threads = 1024, kS1Waves = kS1Threads / 64;
+#ifndef DPQ_S1_THREADS
+#define DPQ_S1_THREADS 1024
+#endif
+constexpr int kS1Threads = DPQ_S1_THREADS, kS1Waves = kS1Threads / 64;
 constexpr int kS1Buckets = 64;  // histogram words: bucket b = candidates under a cut of 4 b + 3 units
 // The global histogram (a.tight_hist, zero at launch) is kept in kS1Replicas copies 2 KB apart, a workgroup adds to copy
 // blockIdx % 8 and a look sums the copies: the few thousand adds of a launch's first microseconds otherwise queue up in
@@ -1787,7 +1796,7 @@ constexpr int kS1Replicas = 8, kS1ReplicaWords = 512;
 static_assert((DPQ_S1_QT >> 2) < kS1Buckets && DPQ_S1_QT <= 253, "a lane per bucket; 8 entries of 255 must reject");
 
 struct S1Lds {
-    static constexpr size_t kTq = 0;                                          // [256][32] x 8 B bound rows
+    static constexpr size_t kTq = 0;                                          // [256][2][32] x 4 B bound words ([256][32] x 8 B rows without DPQ_S1_U8)
     static constexpr size_t kSel = kTq + 256 * 32 * 8;                        // [16][32] x 4 B nibble selectors
     static constexpr size_t kStack = kSel + 16 * 32 * 4;                      // [waves][8][64] x 8 B ancestor stacks
     static constexpr size_t kT32 = kStack + (size_t)kS1Waves * 8 * 64 * 8;    // [8][256] f32 exact table
@@ -1810,6 +1819,7 @@ __device__ __forceinline__ uint32_t lds_ld32(uint32_t off) { return *(const DPQ_
 __device__ __forceinline__ void lds_st64(uint32_t off, uint2 v) { *(DPQ_LDS uint64_t*)(uintptr_t)off = ((uint64_t)v.y << 32) | v.x; }
 // a whole 8-byte row although one half is used: a ds_read_b64 of 32 lanes covers all 64 banks with (lane mod 32) * 8;
 // narrowed to ds_read_b32 the same addresses would meet two to a bank
+__device__ __forceinline__ uint32_t lds_ld8(uint32_t off) { return *(const DPQ_LDS uint8_t*)(uintptr_t)off; }
 __device__ __forceinline__ uint2 lds_ld64_whole(uint32_t off) {
     const uint64_t v = *(const volatile DPQ_LDS uint64_t*)(uintptr_t)off;
     return make_uint2((uint32_t)v, (uint32_t)(v >> 32));
@@ -1889,8 +1899,7 @@ __global__ __launch_bounds__(kS1Threads) void strand1_kernel(const ScanArgs a) {
     float* T32 = reinterpret_cast<float*>(smem + S1Lds::kT32);
     {
         const float* src = a.lut32 + (size_t)qq * TE;
-        T32[tid] = src[tid];
-        T32[tid + kS1Threads] = src[tid + kS1Threads];
+        for (int i = tid; i < TE; i += kS1Threads) T32[i] = src[i];
         if (tid < 16 * 32) reinterpret_cast<uint32_t*>(smem + S1Lds::kSel)[tid] = s1_nibble_sel((uint32_t)tid >> 5);
         __syncthreads();
         uint2* qtmp = reinterpret_cast<uint2*>(smem + S1Lds::kStack);  // the stacks' space, until the loop starts
@@ -1911,8 +1920,16 @@ __global__ __launch_bounds__(kS1Threads) void strand1_kernel(const ScanArgs a) {
         }
         __syncthreads();
         uint2* Tq = reinterpret_cast<uint2*>(smem + S1Lds::kTq);
-#pragma unroll
-        for (int i = 0; i < 256 * 32 / kS1Threads; ++i) Tq[tid + i * kS1Threads] = qtmp[(tid + i * kS1Threads) >> 5];
+        if constexpr (DPQ_S1_U8) {
+            // word (c, half, bank) at c << 8 | half << 7 | bank << 2: sub-spaces 4 half .. 4 half + 3 of code value c
+            uint32_t* Tw = reinterpret_cast<uint32_t*>(smem + S1Lds::kTq);
+            for (int w = tid; w < 256 * 64; w += kS1Threads) {
+                const uint2 row = qtmp[w >> 6];
+                Tw[w] = ((w >> 5) & 1) ? row.y : row.x;
+            }
+        } else {
+            for (int w = tid; w < 256 * 32; w += kS1Threads) Tq[w] = qtmp[w >> 5];
+        }
         if (tid == 0) {
             *reinterpret_cast<uint32_t*>(smem + S1Lds::kShare) = (uint32_t)QT;
             *reinterpret_cast<unsigned long long*>(smem + S1Lds::kShare + 8) = thr;
@@ -1925,7 +1942,7 @@ __global__ __launch_bounds__(kS1Threads) void strand1_kernel(const ScanArgs a) {
 
     stamp();
     // LDS byte offsets a lane uses all along
-    const uint32_t lane8 = (uint32_t)(lane & 31) * 8u;                                             // its copy of a bound row
+    const uint32_t lane8 = (uint32_t)(lane & 31) * (DPQ_S1_U8 ? 4u : 8u);                          // its copy of a bound row
     const uint32_t lane_sel = (uint32_t)S1Lds::kSel + (uint32_t)(lane & 31) * 4u;                  // ... of a selector
     // row -1 of its stack column: depth 0 (the root, mask 0xFF: every byte replaced) reads a parent that does not matter
     // from the 512 bytes in front of the stack -- the previous wavefront's row 7 or the end of the selectors: valid LDS
@@ -2103,6 +2120,14 @@ __global__ __launch_bounds__(kS1Threads) void strand1_kernel(const ScanArgs a) {
                 uint32_t row[M];
 #pragma unroll
                 for (int m = 0; m < M; ++m) row[m] = __builtin_amdgcn_perm(code[m >> 2], lane8, 0x0c0c0400u + ((uint32_t)(m & 3) << 8));
+                if constexpr (DPQ_S1_U8) {
+                    uint32_t e[M];
+#pragma unroll
+                    for (int m = 0; m < M; ++m) e[m] = lds_ld8(row[m] + (uint32_t)(((m >> 2) << 7) | (m & 3)));
+                    if (st + 1 < kPhaseLen) dc = dec_reads(st + 1);
+                    sum[st] = ((e[0] + e[1] + e[2]) + (e[3] + e[4])) + (e[5] + e[6] + e[7]);
+                    continue;
+                }
                 uint2 e[M];
 #pragma unroll
                 for (int m = 0; m < M; ++m) e[m] = lds_ld64_whole(row[m]);
@@ -3058,7 +3083,10 @@ static hipError_t launch_strand_q(const ScanArgs& a, int n_slots, hipStream_t st
     return hipGetLastError();
 }
 
-int strand1_workgroups(int n_strips) { return std::max(1, std::min(256, n_strips)); }
+#ifndef DPQ_S1_MAX_WGS
+#define DPQ_S1_MAX_WGS 256  // (timing experiments: fewer CUs)
+#endif
+int strand1_workgroups(int n_strips) { return std::max(1, std::min(DPQ_S1_MAX_WGS, n_strips)); }
 
 // One query per pass: the bound-table kernel.  One workgroup of 16 wavefronts per CU; strips go to the workgroups
 // first, so a short list still reaches every CU.
