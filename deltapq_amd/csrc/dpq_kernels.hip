@@ -3164,7 +3164,9 @@ hipError_t launch_select(const SelectArgs& a, int M, int n_slots, hipStream_t st
     // and a 1024- or 2048-key final sort: 512 threads (the blocks per CU are set by the keys' LDS either way).  Measured
     // (scripts/gpu_select_threads.sh; M q/s at 256 / 512 / 1024 threads): top-300 4.33 / 4.07 / 3.64, top-512 3.40 / 3.24 /
     // 3.07, top-1000 2.28 / 2.32 / 2.10, M = 16 top-1000 1.27 / 1.32 / 1.23, top-2048 1.20 / 1.30 / 1.20.
-    const int threads = a.threads > 0 ? a.threads : level0 ? 512 : a.top_k > 512 ? 512 : 256;
+    // A handful of slots (the one-query and stream calls): a block per slot leaves the chip empty and the block's own chain is
+    // the call's -- 1024 threads: 4 K candidates of a one-query pass over 64 M codes 33.0 / 23.8 / 19.3 us at 256 / 512 / 1024.
+    const int threads = a.threads > 0 ? a.threads : n_slots <= 16 ? 1024 : level0 ? 512 : a.top_k > 512 ? 512 : 256;
     if (M == 8) return threads >= 1024 ? launch_select_m<8, 1024>(a, n_slots, stream)
                      : threads >= 512 ? launch_select_m<8, 512>(a, n_slots, stream) : launch_select_m<8, 256>(a, n_slots, stream);
     if (M == 16) return threads >= 1024 ? launch_select_m<16, 1024>(a, n_slots, stream)
