@@ -389,3 +389,29 @@ def test_strand1_decode_rules(lib, n):
     codes = synth.decode_tree_codes(tree)
     soa = api.HostSoA(payload, n, 8, multi_index_stride=1)
     assert np.array_equal(decode_strands_like_strand1(soa, n), codes)
+
+
+def test_strand1_bound_table_address_map():
+    """strand1_kernel's bound table in LDS (dpq_kernels.hip, DPQ_S1_U8): the eight entries of code value c as two words
+    (sub-spaces 0..3, 4..7), each stored once per bank -- word (c, half, bank) at c << 8 | half << 7 | bank << 2.  The fill
+    loop and the read address (one v_perm_b32: code byte to bits 8..15, (lane mod 32) << 2 below it, sub-space in the
+    ds_read_u8 offset field) restated in numpy: every lane reads entry[m][c] and the 32 lanes of a pass hit 32 banks."""
+    rng = np.random.default_rng(5)
+    entry = rng.integers(0, 256, size=(8, 256), dtype=np.uint8)  # [m][c]
+    lds = np.zeros(256 * 64 * 4, dtype=np.uint8)
+    # the fill: word w of the table = (c = w >> 6, half = (w >> 5) & 1, bank = w & 31)
+    w = np.arange(256 * 64)
+    c, half = w >> 6, (w >> 5) & 1
+    for b in range(4):
+        lds[4 * w + b] = entry[4 * half + b, c]
+    assert lds.size == 64 * 1024
+    lane = np.arange(64)
+    lane4 = (lane & 31) << 2
+    codes = rng.integers(0, 256, size=(64, 8), dtype=np.uint8)  # a code per lane
+    for m in range(8):
+        addr = (codes[:, m].astype(np.uint32) << 8) | lane4  # the v_perm_b32
+        addr = addr + (((m >> 2) << 7) | (m & 3))             # the instruction's offset field
+        assert np.array_equal(lds[addr], entry[m, codes[:, m]])
+        banks = (addr >> 2) & 31                              # 4-byte banks; a 4-byte-class DS access serves 32 lanes per pass
+        assert np.array_equal(banks[:32], lane[:32] & 31) and len(set(banks[:32])) == 32
+        assert np.array_equal(banks[32:], lane[32:] & 31) and len(set(banks[32:])) == 32
