@@ -1776,7 +1776,7 @@ __global__ __launch_bounds__(kStrandThreads, Q >= 4 ? 2 : Q == 2 ? 3 : 4) void s
 #define DPQ_S1_QT 250  // units of the bound table that span (tau' - sum of minima); entries saturate at 255
 #endif
 #ifndef DPQ_S1_SKIP
-#define DPQ_S1_SKIP 0  // (timing experiments only, wrong results: 1 no ADC, 2 no stack / selector traffic, 4 no changed-byte loads)
+#define DPQ_S1_SKIP 0  // (timing experiments only, wrong results: 1 no ADC, 2 no stack / selector traffic, 4 no changed-byte loads, 8 one of the four, 16 the four from a cache-resident 64 KB)
 #endif
 #ifndef DPQ_S1_U8
 #define DPQ_S1_U8 1  // bound rows as two words per code value and bank, entries read with ds_read_u8 and added; 0: round 4's first shape, 8-byte rows + v_dot4
@@ -2053,6 +2053,19 @@ __global__ __launch_bounds__(kS1Threads) void strand1_kernel(const ScanArgs a) {
                 r.w[0] = make_uint2(off, o1), r.w[1] = make_uint2(o1, o2), r.w[2] = make_uint2(o2, o3), r.w[3] = make_uint2(o3, (uint32_t)(uintptr_t)base);
                 return r;
             }
+            if constexpr ((DPQ_S1_SKIP & 8) != 0) {  // one of the four loads (the others' registers: copies)
+                __builtin_memcpy(&r.w[0], base + off, 8);
+                r.w[1] = make_uint2(r.w[0].x + o1, r.w[0].y), r.w[2] = make_uint2(r.w[0].x + o2, r.w[0].y), r.w[3] = make_uint2(r.w[0].x + o3, r.w[0].y);
+                return r;
+            }
+            if constexpr ((DPQ_S1_SKIP & 16) != 0) {  // the four loads, from the image's first 64 KB (cache-resident)
+                const unsigned char* b0 = a.img.st_delta + (((size_t)(uint32_t)__builtin_amdgcn_readlane((int)pb, gc) * 16) & 0xf000u);
+                __builtin_memcpy(&r.w[0], b0 + off, 8);
+                __builtin_memcpy(&r.w[1], b0 + o1, 8);
+                __builtin_memcpy(&r.w[2], b0 + o2, 8);
+                __builtin_memcpy(&r.w[3], b0 + o3, 8);
+                return r;
+            }
             __builtin_memcpy(&r.w[0], base + off, 8);  // byte addresses: unaligned 8-byte loads
             __builtin_memcpy(&r.w[1], base + o1, 8);
             __builtin_memcpy(&r.w[2], base + o2, 8);
@@ -2079,6 +2092,9 @@ __global__ __launch_bounds__(kS1Threads) void strand1_kernel(const ScanArgs a) {
             bq[D] = load_bytes(g + D, hq[D]);
             const Hdr hdr = hq[0];
             uint32_t codes[kPhaseLen][2], sum[kPhaseLen];
+#if defined(DPQ_S1_PAD_VALU) || defined(DPQ_S1_PAD_SALU) || defined(DPQ_S1_PAD_LDS)
+            uint32_t pad_v[4] = {1u, 2u, 3u, 4u}, pad_s = 5u, pad_l[4] = {0u, 0u, 0u, 0u};
+#endif
             // The four steps as a software pipeline over the LDS round trips: step s + 1's parent and selectors are read
             // behind step s's eight bound-row gathers and before their sums -- one round trip per step instead of two.
             struct Dec {
@@ -2126,6 +2142,26 @@ __global__ __launch_bounds__(kS1Threads) void strand1_kernel(const ScanArgs a) {
                     for (int m = 0; m < M; ++m) e[m] = lds_ld8(row[m] + (uint32_t)(((m >> 2) << 7) | (m & 3)));
                     if (st + 1 < kPhaseLen) dc = dec_reads(st + 1);
                     sum[st] = ((e[0] + e[1] + e[2]) + (e[3] + e[4])) + (e[5] + e[6] + e[7]);
+#if defined(DPQ_S1_PAD_VALU) || defined(DPQ_S1_PAD_SALU) || defined(DPQ_S1_PAD_LDS)
+                    {  // (timing experiments: instructions that do nothing, per step)
+#ifdef DPQ_S1_PAD_VALU
+#pragma unroll
+                        for (int i = 0; i < DPQ_S1_PAD_VALU; ++i) asm volatile("v_perm_b32 %0, %0, %1, %2" : "+v"(pad_v[i & 3]) : "v"(lane8), "v"(code[0]));
+#endif
+#ifdef DPQ_S1_PAD_SALU
+#pragma unroll
+                        for (int i = 0; i < DPQ_S1_PAD_SALU; ++i) asm volatile("s_mov_b32 %0, %0" : "+s"(pad_s));
+#endif
+#ifdef DPQ_S1_PAD_LDS
+#pragma unroll
+                        for (int i = 0; i < DPQ_S1_PAD_LDS; ++i) {
+                            uint32_t t;
+                            asm volatile("ds_read_u8 %0, %1 offset:%2" : "=v"(t) : "v"(row[i & 7]), "n"(4 * (i & 7)));
+                            pad_l[i & 3] = t;
+                        }
+#endif
+                    }
+#endif
                     continue;
                 }
                 uint2 e[M];
@@ -2140,6 +2176,9 @@ __global__ __launch_bounds__(kS1Threads) void strand1_kernel(const ScanArgs a) {
                 }
                 sum[st] = acc0 + acc1;
             }
+#if defined(DPQ_S1_PAD_VALU) || defined(DPQ_S1_PAD_SALU) || defined(DPQ_S1_PAD_LDS)
+            asm volatile("" ::"v"(pad_v[0]), "v"(pad_v[1]), "v"(pad_v[2]), "v"(pad_v[3]), "s"(pad_s), "v"(pad_l[0]), "v"(pad_l[1]), "v"(pad_l[2]), "v"(pad_l[3]));
+#endif
             // what the bound lets through: the reference's distance and the whole (distance, id) key
             const uint32_t cutp = (uint32_t)cut + 1u;
             if (__ballot(min(min(sum[0], sum[1]), min(sum[2], sum[3])) <= cutp) && !(dbg & 1)) {
