@@ -1781,6 +1781,9 @@ __global__ __launch_bounds__(kStrandThreads, Q >= 4 ? 2 : Q == 2 ? 3 : 4) void s
 #ifndef DPQ_S1_U8
 #define DPQ_S1_U8 1  // bound rows as two words per code value and bank, entries read with ds_read_u8 and added; 0: round 4's first shape, 8-byte rows + v_dot4
 #endif
+#ifndef DPQ_S1_PAIR
+#define DPQ_S1_PAIR 1  // two changed-byte loads per phase serve the four nodes where a pair's bytes fit one 8-byte window; 0: four loads
+#endif
 #ifndef DPQ_S1_DEPTH
 #define DPQ_S1_DEPTH 1  // phases the changed bytes are fetched ahead of their decode (headers: two more)
 #endif
@@ -2066,6 +2069,16 @@ __global__ __launch_bounds__(kS1Threads) void strand1_kernel(const ScanArgs a) {
                 __builtin_memcpy(&r.w[3], b0 + o3, 8);
                 return r;
             }
+            if constexpr (DPQ_S1_PAIR) {
+                // Two loads serve the four nodes wherever a pair's bytes fit one 8-byte window (the second node's are the first
+                // load's, shifted: below); only the lanes whose pair runs past it load the second node's bytes themselves.
+                __builtin_memcpy(&r.w[0], base + off, 8);
+                __builtin_memcpy(&r.w[2], base + o2, 8);
+                asm volatile("" : "=v"(r.w[1].x), "=v"(r.w[1].y), "=v"(r.w[3].x), "=v"(r.w[3].y));  // (whatever they hold: read only where loaded)
+                if (o2 - off > 8u) __builtin_memcpy(&r.w[1], base + o1, 8);
+                if (off + mine - o2 > 8u) __builtin_memcpy(&r.w[3], base + o3, 8);
+                return r;
+            }
             __builtin_memcpy(&r.w[0], base + off, 8);  // byte addresses: unaligned 8-byte loads
             __builtin_memcpy(&r.w[1], base + o1, 8);
             __builtin_memcpy(&r.w[2], base + o2, 8);
@@ -2121,7 +2134,15 @@ __global__ __launch_bounds__(kS1Threads) void strand1_kernel(const ScanArgs a) {
             Dec dc = dec_reads(0);
 #pragma unroll
             for (int st = 0; st < kPhaseLen; ++st) {
-                const uint2 raw = bq[0].w[st];
+                uint2 raw = bq[0].w[st];
+                if constexpr (DPQ_S1_PAIR) {
+                    if (st & 1) {  // a pair's second node: its own load where the pair ran past 8 bytes, else the first node's window shifted
+                        const uint32_t pa = (uint32_t)__popc((hdr.masks >> (8 * (st - 1))) & 0xffu), pn = (uint32_t)__popc((hdr.masks >> (8 * st)) & 0xffu);
+                        const uint2 fst = bq[0].w[st - 1];
+                        const uint64_t sh = ((((uint64_t)fst.y << 32) | fst.x) >> ((8u * pa) & 63u));
+                        if (pa + pn <= 8u) raw = make_uint2((uint32_t)sh, (uint32_t)(sh >> 32));
+                    }
+                }
                 const uint32_t raw_hi = (uint32_t)((((uint64_t)raw.y << 32) | raw.x) >> (8 * __popc(dc.lo)));
                 uint32_t* code = codes[st];
                 code[0] = __builtin_amdgcn_perm(dc.parent.x, raw.x, dc.sel_lo);
