@@ -1785,7 +1785,7 @@ __global__ __launch_bounds__(kStrandThreads, Q >= 4 ? 2 : Q == 2 ? 3 : 4) void s
 #define DPQ_S1_PAIR 1  // two changed-byte loads per phase serve the four nodes where a pair's bytes fit one 8-byte window; 0: four loads
 #endif
 #ifndef DPQ_S1_DEPTH
-#define DPQ_S1_DEPTH 1  // phases the changed bytes are fetched ahead of their decode (headers: two more)
+#define DPQ_S1_DEPTH 1  // phases the changed bytes are fetched ahead of their decode, 1 .. 3 (headers: four ahead; 2: 215 against 217 us)
 #endif
 #ifndef DPQ_S1_THREADS
 #define DPQ_S1_THREADS 1024
@@ -2045,13 +2045,13 @@ __global__ __launch_bounds__(kS1Threads) void strand1_kernel(const ScanArgs a) {
         };
         auto load_bytes = [&](int g, const Hdr& h) -> Bytes {
             const int gc = min(g, GROUPS - 1);
+            Bytes r;
             // where the lane's bytes start in the phase (lane after lane): wave prefix sum of the lanes' byte counts
             const uint32_t mine = (uint32_t)__popc(h.masks);  // <= 32
             const uint32_t off = wave_inclusive_sum(mine) - mine;
             const unsigned char* base = a.img.st_delta + (size_t)(uint32_t)__builtin_amdgcn_readlane((int)pb, gc) * 16;
             const uint32_t o1 = off + (uint32_t)__popc(h.masks & 0xffu), o2 = off + (uint32_t)__popc(h.masks & 0xffffu),
                            o3 = off + (uint32_t)__popc(h.masks & 0xffffffu);
-            Bytes r;
             if constexpr ((DPQ_S1_SKIP & 4) != 0) {
                 r.w[0] = make_uint2(off, o1), r.w[1] = make_uint2(o1, o2), r.w[2] = make_uint2(o2, o3), r.w[3] = make_uint2(o3, (uint32_t)(uintptr_t)base);
                 return r;
@@ -2085,14 +2085,23 @@ __global__ __launch_bounds__(kS1Threads) void strand1_kernel(const ScanArgs a) {
             __builtin_memcpy(&r.w[3], base + o3, 8);
             return r;
         };
-        Hdr hq[D + 2];
-        Bytes bq[D + 1];
+        // Headers and bytes wait in RINGS of R slots with compile-time indices -- the phase loop is unrolled R times -- so that
+        // no register is ever copied from one queue position to the next: a copy of a register a load is still writing is a
+        // wait for that load (the shifted queues of the first version drained every prefetch at the bottom of each phase
+        // as soon as the bytes were fetched more than one phase ahead).
+        constexpr int R = 4;
+        static_assert(D >= 1 && D < R && GROUPS % R == 0, "the header of phase g + D must be in its slot when phase g starts");
+        Hdr hq[R];
+        Bytes bq[R];
 #pragma unroll
-        for (int i = 0; i < D + 2; ++i) hq[i] = load_hdr(i);
+        for (int i = 0; i < R; ++i) hq[i] = load_hdr(i);
 #pragma unroll
         for (int i = 0; i < D; ++i) bq[i] = load_bytes(i, hq[i]);
 #pragma unroll 1
-        for (int g = 0; g < GROUPS; ++g) {
+        for (int g0 = 0; g0 < GROUPS; g0 += R)
+#pragma unroll
+        for (int u = 0; u < R; ++u) {
+            const int g = g0 + u;
             if (hist) {
                 // inside the first strip: wavefronts 0..3 after 1, 2, 4, 8 phases (drains that wavefront's prefetches, once)
                 if (first_strip && wave < 4 && g == (1 << wave)) look();
@@ -2101,9 +2110,10 @@ __global__ __launch_bounds__(kS1Threads) void strand1_kernel(const ScanArgs a) {
 #endif
                 if (first_strip || (g % DPQ_S1_REFRESH) == 0) refresh();
             }
-            const Hdr h_new = load_hdr(g + D + 2);
-            bq[D] = load_bytes(g + D, hq[D]);
-            const Hdr hdr = hq[0];
+            const Hdr hdr = hq[u];
+            hq[u] = load_hdr(g + R);  // (past the strip: the last phase again, never used)
+            bq[(u + D) % R] = load_bytes(g + D, hq[(u + D) % R]);
+            const Bytes& cur = bq[u];
             uint32_t codes[kPhaseLen][2], sum[kPhaseLen];
 #if defined(DPQ_S1_PAD_VALU) || defined(DPQ_S1_PAD_SALU) || defined(DPQ_S1_PAD_LDS)
             uint32_t pad_v[4] = {1u, 2u, 3u, 4u}, pad_s = 5u, pad_l[4] = {0u, 0u, 0u, 0u};
@@ -2134,11 +2144,11 @@ __global__ __launch_bounds__(kS1Threads) void strand1_kernel(const ScanArgs a) {
             Dec dc = dec_reads(0);
 #pragma unroll
             for (int st = 0; st < kPhaseLen; ++st) {
-                uint2 raw = bq[0].w[st];
+                uint2 raw = cur.w[st];
                 if constexpr (DPQ_S1_PAIR) {
                     if (st & 1) {  // a pair's second node: its own load where the pair ran past 8 bytes, else the first node's window shifted
                         const uint32_t pa = (uint32_t)__popc((hdr.masks >> (8 * (st - 1))) & 0xffu), pn = (uint32_t)__popc((hdr.masks >> (8 * st)) & 0xffu);
-                        const uint2 fst = bq[0].w[st - 1];
+                        const uint2 fst = cur.w[st - 1];
                         const uint64_t sh = ((((uint64_t)fst.y << 32) | fst.x) >> ((8u * pa) & 63u));
                         if (pa + pn <= 8u) raw = make_uint2((uint32_t)sh, (uint32_t)(sh >> 32));
                     }
@@ -2247,11 +2257,6 @@ __global__ __launch_bounds__(kS1Threads) void strand1_kernel(const ScanArgs a) {
                     ++slow_entries;
                 }
             }
-#pragma unroll
-            for (int i = 0; i < D + 1; ++i) hq[i] = hq[i + 1];
-            hq[D + 1] = h_new;
-#pragma unroll
-            for (int i = 0; i < D; ++i) bq[i] = bq[i + 1];
         }
         first_strip = false;
         stamp();
