@@ -1782,7 +1782,7 @@ __global__ __launch_bounds__(kStrandThreads, Q >= 4 ? 2 : Q == 2 ? 3 : 4) void s
 #define DPQ_S1_U8 1  // bound rows as two words per code value and bank, entries read with ds_read_u8 and added; 0: round 4's first shape, 8-byte rows + v_dot4
 #endif
 #ifndef DPQ_S1_PAIR
-#define DPQ_S1_PAIR 1  // two changed-byte loads per phase serve the four nodes where a pair's bytes fit one 8-byte window; 0: four loads
+#define DPQ_S1_PAIR 2  // two changed-byte loads per phase serve the four nodes where a pair's bytes fit one window: 1 = 8-byte windows, 2 = 12, 3 = 16 (always); 0: four loads
 #endif
 #ifndef DPQ_S1_DEPTH
 #define DPQ_S1_DEPTH 1  // phases the changed bytes are fetched ahead of their decode, 1 .. 3 (headers: four ahead; 2: 215 against 217 us)
@@ -2038,6 +2038,7 @@ __global__ __launch_bounds__(kS1Threads) void strand1_kernel(const ScanArgs a) {
         };
         struct Bytes {
             uint2 w[kPhaseLen];  // the (up to) eight changed bytes of each of them, from the node's first byte on
+            uint32_t x[4];       // (DPQ_S1_PAIR >= 2: the third (and fourth) dwords of the 12- (16-) byte windows of nodes 0 and 2)
         };
         auto load_hdr = [&](int g) -> Hdr {
             const int gc = min(g, GROUPS - 1);  // (past the strip: the last phase again, never used)
@@ -2067,6 +2068,25 @@ __global__ __launch_bounds__(kS1Threads) void strand1_kernel(const ScanArgs a) {
                 __builtin_memcpy(&r.w[1], b0 + o1, 8);
                 __builtin_memcpy(&r.w[2], b0 + o2, 8);
                 __builtin_memcpy(&r.w[3], b0 + o3, 8);
+                return r;
+            }
+            if constexpr (DPQ_S1_PAIR == 3) {  // 16-byte windows: a pair always fits
+                uint32_t a4[4], c4[4];
+                __builtin_memcpy(a4, base + off, 16);
+                __builtin_memcpy(c4, base + o2, 16);
+                r.w[0] = make_uint2(a4[0], a4[1]), r.x[0] = a4[2], r.x[2] = a4[3], r.w[2] = make_uint2(c4[0], c4[1]), r.x[1] = c4[2], r.x[3] = c4[3];
+                return r;
+            }
+            if constexpr (DPQ_S1_PAIR == 2) {
+                // As below with 12-byte windows: a pair runs past one in 0.3 % of the lanes, so the second node's own load is
+                // skipped by most wavefronts altogether (the branch around it is wave-uniform) instead of issued for a few lanes.
+                uint32_t a3[3], c3[3];
+                __builtin_memcpy(a3, base + off, 12);
+                __builtin_memcpy(c3, base + o2, 12);
+                r.w[0] = make_uint2(a3[0], a3[1]), r.x[0] = a3[2], r.w[2] = make_uint2(c3[0], c3[1]), r.x[1] = c3[2];
+                asm volatile("" : "=v"(r.w[1].x), "=v"(r.w[1].y), "=v"(r.w[3].x), "=v"(r.w[3].y));
+                if (o2 - off > 12u) __builtin_memcpy(&r.w[1], base + o1, 8);
+                if (off + mine - o2 > 12u) __builtin_memcpy(&r.w[3], base + o3, 8);
                 return r;
             }
             if constexpr (DPQ_S1_PAIR) {
@@ -2145,7 +2165,23 @@ __global__ __launch_bounds__(kS1Threads) void strand1_kernel(const ScanArgs a) {
 #pragma unroll
             for (int st = 0; st < kPhaseLen; ++st) {
                 uint2 raw = cur.w[st];
-                if constexpr (DPQ_S1_PAIR) {
+                if constexpr (DPQ_S1_PAIR == 3) {
+                    if (st & 1) {  // bytes [pa, pa + 8) of the first node's 16-byte window
+                        const uint32_t pa = (uint32_t)__popc((hdr.masks >> (8 * (st - 1))) & 0xffu);
+                        const uint32_t w0 = cur.w[st - 1].x, w1 = cur.w[st - 1].y, w2 = cur.x[st >> 1], w3 = cur.x[2 + (st >> 1)];
+                        const bool s1 = pa >= 4u, s2 = pa >= 8u;
+                        const uint32_t d0 = s2 ? w2 : s1 ? w1 : w0, d1 = s2 ? w3 : s1 ? w2 : w1, d2 = s2 ? 0u : s1 ? w3 : w2;
+                        raw = make_uint2(__builtin_amdgcn_alignbyte(d1, d0, pa & 3u), __builtin_amdgcn_alignbyte(d2, d1, pa & 3u));
+                    }
+                } else if constexpr (DPQ_S1_PAIR == 2) {
+                    if (st & 1) {  // bytes [pa, pa + 8) of the first node's 12-byte window, unless the pair ran past it
+                        const uint32_t pa = (uint32_t)__popc((hdr.masks >> (8 * (st - 1))) & 0xffu), pn = (uint32_t)__popc((hdr.masks >> (8 * st)) & 0xffu);
+                        const uint32_t w0 = cur.w[st - 1].x, w1 = cur.w[st - 1].y, w2 = cur.x[st >> 1];
+                        const bool s1 = pa >= 4u, s2 = pa >= 8u;
+                        const uint32_t d0 = s2 ? w2 : s1 ? w1 : w0, d1 = s2 ? 0u : s1 ? w2 : w1, d2 = s1 ? 0u : w2;
+                        if (pa + pn <= 12u) raw = make_uint2(__builtin_amdgcn_alignbyte(d1, d0, pa & 3u), __builtin_amdgcn_alignbyte(d2, d1, pa & 3u));
+                    }
+                } else if constexpr (DPQ_S1_PAIR) {
                     if (st & 1) {  // a pair's second node: its own load where the pair ran past 8 bytes, else the first node's window shifted
                         const uint32_t pa = (uint32_t)__popc((hdr.masks >> (8 * (st - 1))) & 0xffu), pn = (uint32_t)__popc((hdr.masks >> (8 * st)) & 0xffu);
                         const uint2 fst = cur.w[st - 1];
