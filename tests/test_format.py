@@ -415,3 +415,28 @@ def test_strand1_bound_table_address_map():
         banks = (addr >> 2) & 31                              # 4-byte banks; a 4-byte-class DS access serves 32 lanes per pass
         assert np.array_equal(banks[:32], lane[:32] & 31) and len(set(banks[:32])) == 32
         assert np.array_equal(banks[32:], lane[32:] & 31) and len(set(banks[32:])) == 32
+
+
+def test_strand1_pair_window_extraction():
+    """strand1_kernel (DPQ_S1_PAIR = 2): the second node of a pair takes bytes [p, p + 8) of the first node's 12-byte window
+    -- a dword select on p >= 4 / p >= 8 and two v_alignbyte_b32 -- instead of a load of its own.  The rule restated in numpy
+    for every p in 0..8: what it yields equals the window's bytes from p on (zeros behind the twelfth), so whenever the pair's
+    bytes fit the window (p + the second node's count <= 12) the node reads exactly the bytes at its own offset."""
+    rng = np.random.default_rng(11)
+
+    def alignbyte(hi, lo, s):
+        return (((hi.astype(np.uint64) << np.uint64(32)) | lo.astype(np.uint64)) >> np.uint64(8 * s)).astype(np.uint32)
+
+    win = rng.integers(0, 256, size=(1000, 12), dtype=np.uint8)
+    w = win.view("<u4")  # [1000][3]
+    w0, w1, w2 = w[:, 0], w[:, 1], w[:, 2]
+    zero = np.zeros_like(w0)
+    padded = np.concatenate([win, np.zeros((1000, 8), np.uint8)], axis=1)
+    for p in range(9):
+        s1, s2 = p >= 4, p >= 8
+        d0 = w2 if s2 else w1 if s1 else w0
+        d1 = zero if s2 else w2 if s1 else w1
+        d2 = zero if s1 else w2
+        lo, hi = alignbyte(d1, d0, p & 3), alignbyte(d2, d1, p & 3)
+        got = np.stack([lo, hi], axis=1).view(np.uint8)
+        assert np.array_equal(got, padded[:, p:p + 8]), p
