@@ -92,7 +92,9 @@ struct Tuning {
     int coarse_below = 128;
     int plan_ratios[3] = {0, 0, 0};
     int boot_cap = 0, boot_target = 0;
+    int boot_variant = 1;  // bootstrap_kernel's V (dpq_kernels.hip); 0 = the kernel of rounds 2 - 3  [DPQ_BOOT_VARIANT]
     int select_threads = 0;  // select_kernel block size, 0 = by top_k  [DPQ_SELECT_THREADS]
+    int select_fast = 1;     // the last level of a small top_k from one histogram pass (select_kernel)  [DPQ_SELECT_FAST=0: radix select]
     int64_t batch_tile_nodes = (int64_t)16 << 20;
     bool relabel = true, fuse_quantise = true, async_overlap = true, boot_fullsort = false, tighten = true, strands = true,
          force_strands = false, strand1 = true;
@@ -287,6 +289,7 @@ Tuning resolve_tuning(const dpq_open_opts& o) {
         if (const char* e = getenv("DPQ_PLAN_RATIOS")) sscanf(e, "%d,%d,%d", &t.plan_ratios[0], &t.plan_ratios[1], &t.plan_ratios[2]);
         geti("DPQ_BOOT_CAP", &t.boot_cap);
         geti("DPQ_BOOT_TARGET", &t.boot_target);
+        geti("DPQ_BOOT_VARIANT", &t.boot_variant);
         if (const char* e = getenv("DPQ_BATCH_TILE_NODES")) t.batch_tile_nodes = std::max<int64_t>(1, atoll(e));
         int v = 1;
         geti("DPQ_RELABEL", &v); t.relabel = t.relabel && v != 0;
@@ -295,6 +298,7 @@ Tuning resolve_tuning(const dpq_open_opts& o) {
         v = 0; geti("DPQ_BOOT_FULLSORT", &v); t.boot_fullsort = t.boot_fullsort || v != 0;
         v = 1; geti("DPQ_TIGHTEN", &v); t.tighten = t.tighten && v != 0;
         geti("DPQ_SELECT_THREADS", &t.select_threads);
+        geti("DPQ_SELECT_FAST", &t.select_fast);
         v = 1; geti("DPQ_STRANDS", &v); t.strands = t.strands && v != 0;
         t.force_strands = t.force_strands || v == 2;
         v = 1; geti("DPQ_STRAND1", &v); t.strand1 = t.strand1 && v != 0;
@@ -671,6 +675,7 @@ int run_batch(dpq_index* x, const float* d_queries, int nq, int top_k, int32_t* 
 
     dpq::SelectArgs se{};
     se.threads = x->tune.select_threads;
+    se.fast_final = x->tune.select_fast;
     se.cand_count = x->d_cand_count;
     se.cand_key = x->d_cand_key;
     se.cand_stride = stride;
@@ -726,11 +731,18 @@ int run_batch(dpq_index* x, const float* d_queries, int nq, int top_k, int32_t* 
             ba.cap = std::max(std::min(cap_env > 0 ? cap_env : cap_auto, 16384), std::max(top_k, 2048));
             ba.cap = (ba.cap + 63) / 64 * 64;
             const int target_env = x->tune.boot_target;
-            ba.target = target_env > 0 ? std::min(ba.cap, std::max(target_env, top_k)) : ba.cap;
+            // Cells are walked in rounds until `target` nodes are evaluated.  At top_k <= 256 two thirds of the key list are
+            // enough: the 1 % of the queries whose first round of cells brings fewer than `cap` nodes (sparse neighbourhoods:
+            // 9 of 1000 on the bench index) then stop there instead of walking a second round -- they were the launch's
+            // last blocks (dev_boot_stamps.py: span 25.4 -> 22.4 us), their thresholds come from >= 2048 nodes instead of
+            // 3072 and the scan's own tightening does the rest (exact checks and candidates per query unchanged).
+            const int target_auto = top_k <= 256 ? std::max(top_k, ba.cap * 2 / 3) : ba.cap;
+            ba.target = target_env > 0 ? std::min(ba.cap, std::max(target_env, top_k)) : target_auto;
             ba.thr_key = x->d_thr_key;
             ba.cand_count = x->d_cand_count;
             ba.fp32_accum = x->plain ? 1 : 0;
             ba.stamps = x->d_boot_stamps;
+            ba.variant = x->tune.boot_variant;
             ba.n_queries = nq;
             // DPQ_OPT_NO_FUSE_QUANTISE: the first level's tables from quantise_kernel, as for every later level
             const bool fuse = x->tune.fuse_quantise;
@@ -2412,6 +2424,18 @@ int dpq_debug_boot_stamps(dpq_index* x, int nq, double* out) {
         fprintf(stderr, "%s blocks: span %.2f us; lifetime min %.2f median %.2f p90 %.2f max %.2f us; start offset median %.2f p90 %.2f max %.2f us\n",
                 half ? "select" : "bootstrap", (double)(t1 - t0) / 100.0, life.front(), pct(life, 0.5), pct(life, 0.9), life.back(),
                 pct(start, 0.5), pct(start, 0.9), start.back());
+        if (!half) {  // bootstrap blocks by the rounds of cells they walked (slot 5 of a block's stamps)
+            double sum[4] = {0, 0, 0, 0}, mx[4] = {0, 0, 0, 0};
+            int cnt[4] = {0, 0, 0, 0};
+            for (int q = 0; q < nq; ++q) {
+                const int r = (int)std::min<unsigned long long>(h[o + (size_t)q * 8 + 5], 4) - 1;
+                if (r < 0) continue;
+                const double l = (double)(h[o + (size_t)q * 8 + 7] - h[o + (size_t)q * 8 + 6]) / 100.0;
+                sum[r] += l, mx[r] = std::max(mx[r], l), cnt[r]++;
+            }
+            for (int r = 0; r < 4; ++r)
+                if (cnt[r]) fprintf(stderr, "  %d%s round(s): %d blocks, lifetime mean %.2f max %.2f us\n", r + 1, r == 3 ? "+" : "", cnt[r], sum[r] / cnt[r], mx[r]);
+        }
     }
     for (int half = 0; half < 2; ++half)
         for (int q = 0; q < nq; ++q)

@@ -108,6 +108,7 @@ struct SelectArgs {
     int32_t keep_thr;              // 1: thr_key = min(thr_key, this level's k-th key) (levels after a bootstrap)
     unsigned long long* stamps;    // developer diagnostics (NULL in product calls): [slots][8] s_memtime marks
     int32_t threads;               // block size (256 / 512 / 1024); 0 = by top_k (launch_select)
+    int32_t fast_final;            // 1: the last level of a top_k <= 256 ranks what one histogram pass leaves (select_kernel)
 };
 
 // Threshold bootstrap from the inverted multi-index (see bootstrap_kernel).
@@ -132,6 +133,7 @@ struct BootArgs {
     uint4* qtab;
     const float* lut_min;          // [query][M][4]
     unsigned long long* stamps;    // developer diagnostics (NULL in product calls): [slots][8] s_memtime marks
+    int32_t variant;               // bootstrap_kernel's V: 1 = round 4's kernel (one-pass threshold), 0 = round 3's, kept for A/B
 };
 
 // Builds the exact tables of queries [0, nq) and clears the candidate counters / overflow flags of

@@ -2456,6 +2456,75 @@ __device__ uint64_t block_radix_select(const K* keys_in, int n, int rank, uint32
     return prefix + lo;
 }
 
+// An UPPER BOUND of the rank-th smallest of the 32-bit keys[0..n) (LDS) from ONE histogram pass: 2^BITS bins over
+// (key - min) cut from the top set bit of (max - min) downwards; the bound is the upper edge of the bin the rank falls
+// into (never above max), i.e. less than (max - min) / 2^(BITS - 1) above the exact answer -- on fp32 distances of one
+// query 2^-9 of a binade at most, a tenth of a filter unit.  Three barriers and 32-bit arithmetic (block_radix_select:
+// about fourteen, on widened keys).  lo / hi: the calling thread's own minimum / maximum over the keys IT wrote (every
+// key counted by some thread); hist: [2^BITS] words, xch: [2 * waves + 1] words; rank <= n, no padding keys.
+template <int BITS>
+__device__ uint32_t block_kth_bound_u32(const uint32_t* keys, int n, int rank, uint32_t lo, uint32_t hi, uint32_t* hist,
+                                        uint32_t* xch, int tid, int nthreads) {
+    constexpr int NB = 1 << BITS;
+    static_assert(NB % 256 == 0, "wave 0 scans NB / 64 bins per lane, four at a time");
+    for (int i = tid; i < NB; i += nthreads) hist[i] = 0u;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        lo = min(lo, (uint32_t)__shfl_xor((int)lo, off, 64));
+        hi = max(hi, (uint32_t)__shfl_xor((int)hi, off, 64));
+    }
+    const int nw = nthreads >> 6;
+    if ((tid & 63) == 0) {
+        xch[2 * (tid >> 6)] = lo;
+        xch[2 * (tid >> 6) + 1] = hi;
+    }
+    __syncthreads();
+    for (int w = 0; w < nw; ++w) {
+        lo = min(lo, xch[2 * w]);
+        hi = max(hi, xch[2 * w + 1]);
+    }
+    const uint32_t span = hi - lo;
+    const int hi_bit = span ? 31 - __clz((int)span) : 0;
+    const int shift = hi_bit >= BITS ? hi_bit - (BITS - 1) : 0;
+    for (int i = tid; i < n; i += nthreads) atomicAdd(&hist[(keys[i] - lo) >> shift], 1u);
+    __syncthreads();
+    if (tid < 64) {  // wave 0: lane l owns bins [PER l, PER (l + 1))
+        constexpr int PER = NB / 64;
+        uint32_t h[PER];
+        uint32_t mine = 0;
+#pragma unroll
+        for (int j = 0; j < PER; j += 4) {
+            const uint4 v = *reinterpret_cast<const uint4*>(hist + PER * tid + j);
+            h[j] = v.x; h[j + 1] = v.y; h[j + 2] = v.z; h[j + 3] = v.w;
+            mine += v.x + v.y + v.z + v.w;
+        }
+        uint32_t incl = mine;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t up = (uint32_t)__shfl_up((int)incl, off, 64);
+            if (tid >= off) incl += up;
+        }
+        const uint32_t before = incl - mine;
+        if (before < (uint32_t)rank && (uint32_t)rank <= incl) {  // exactly one lane
+            uint32_t r = (uint32_t)rank - before;
+            int bin = PER * tid + PER - 1;
+            bool found = false;
+#pragma unroll
+            for (int j = 0; j < PER; ++j) {
+                if (!found && r <= h[j]) {
+                    bin = PER * tid + j;
+                    found = true;
+                }
+                if (!found) r -= h[j];
+            }
+            xch[2 * nw] = (uint32_t)bin;
+        }
+    }
+    __syncthreads();
+    const uint64_t edge = (uint64_t)lo + ((((uint64_t)xch[2 * nw]) + 1ull) << shift) - 1ull;
+    return edge < (uint64_t)hi ? (uint32_t)edge : hi;
+}
+
 __device__ __forceinline__ int32_t report_id(uint32_t pos, int64_t n_total) {
     // h:2949, 2970: for even N the trailing node is pushed as i+1 == N, not N-1.
     if ((n_total & 1) == 0 && (int64_t)pos == n_total - 1) return (int32_t)n_total;
@@ -2505,6 +2574,7 @@ __global__ __launch_bounds__(THREADS) void select_kernel(const SelectArgs a) {
     uint32_t* region_n = a.cand_count + (size_t)slot * kRegionStride;
     uint64_t* keys = skeys;
     int n = 0;
+    uint32_t dlo = 0xffffffffu, dhi = 0u;  // extremes of the distance bits of the keys this thread gathered
     if (tid == 0) {
         counters[0] = 0;
         counters[1] = 0;
@@ -2592,7 +2662,11 @@ __global__ __launch_bounds__(THREADS) void select_kernel(const SelectArgs a) {
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int i = i0 + tid + u * THREADS;
-                if (i < n) keys[i] = v[u];
+                if (i < n) {
+                    keys[i] = v[u];
+                    dlo = min(dlo, (uint32_t)(v[u] >> 32));
+                    dhi = max(dhi, (uint32_t)(v[u] >> 32));
+                }
             }
         }
     }
@@ -2600,6 +2674,103 @@ __global__ __launch_bounds__(THREADS) void select_kernel(const SelectArgs a) {
     mark(1);
     const int n_valid = n - (int)counters[1];
     const int kk = min(a.top_k, n_valid);
+    // The last level of a small top_k (round 4): the output order comes from counting smaller winners anyway, so the
+    // exact k-th key is not needed first -- ONE histogram pass (1024 bins over (key - least distance) from the top set bit
+    // of the span) finds the bin the k-th key lies in, everything up to that bin is ranked by counting and the first k
+    // ranks are written.  Two passes and the single-key fetch of the radix select (9 barriers) become one (3).  The
+    // histogram and the ranked list live behind the keys in the block's key area; a crowded bin (ties by the thousand)
+    // takes the exact way below.  The slot's threshold for a rerun after an overflow is the bin's upper edge.
+    const int n_even = (n + 1) & ~1;
+    if (a.fast_final && !shared && a.final_pass && kk == a.top_k && kk <= DPQ_RANK_BY_COUNT_MAX && keys == skeys &&
+        n_even + 1024 <= n_lds_keys) {
+        uint32_t* h1 = reinterpret_cast<uint32_t*>(skeys + n_even);  // [1024]
+        uint64_t* wp = skeys + n_even + 512;                          // [512]
+        for (int i = tid; i < 1024; i += THREADS) h1[i] = 0u;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            dlo = min(dlo, (uint32_t)__shfl_xor((int)dlo, off, 64));
+            dhi = max(dhi, (uint32_t)__shfl_xor((int)dhi, off, 64));
+        }
+        if ((tid & 63) == 0) {
+            hist[2 * (tid >> 6)] = dlo;
+            hist[2 * (tid >> 6) + 1] = dhi;
+        }
+        __syncthreads();
+        for (int w = 0; w < THREADS / 64; ++w) {
+            dlo = min(dlo, hist[2 * w]);
+            dhi = max(dhi, hist[2 * w + 1]);
+        }
+        const uint64_t lo64 = (uint64_t)dlo << 32, hi64 = ((uint64_t)dhi << 32) | 0xffffffffull;
+        const int hi_bit = 63 - __clzll((long long)(hi64 - lo64));  // >= 31; <= 62: distance bits are those of a float >= 0
+        const int shift = hi_bit - 9;
+        for (int i = tid; i < n; i += THREADS) atomicAdd(&h1[(uint32_t)((keys[i] - lo64) >> shift)], 1u);
+        __syncthreads();
+        if (tid < 64) {  // wave 0: lane l owns bins [16 l, 16 l + 16)
+            uint32_t h[16], mine = 0;
+#pragma unroll
+            for (int j = 0; j < 16; j += 4) {
+                const uint4 v = *reinterpret_cast<const uint4*>(h1 + 16 * tid + j);
+                h[j] = v.x; h[j + 1] = v.y; h[j + 2] = v.z; h[j + 3] = v.w;
+                mine += v.x + v.y + v.z + v.w;
+            }
+            uint32_t incl = mine;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t up = (uint32_t)__shfl_up((int)incl, off, 64);
+                if (tid >= off) incl += up;
+            }
+            const uint32_t before = incl - mine;
+            if (before < (uint32_t)kk && (uint32_t)kk <= incl) {  // exactly one lane
+                uint32_t upto = before;
+                int bin = 16 * tid + 15;
+                bool found = false;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    if (!found) {
+                        upto += h[j];
+                        if (upto >= (uint32_t)kk) {
+                            bin = 16 * tid + j;
+                            found = true;
+                        }
+                    }
+                }
+                bcast[0] = (uint32_t)bin;
+                bcast[1] = upto;  // keys up to and including the bin
+            }
+        }
+        __syncthreads();
+        const uint32_t bin = bcast[0];
+        const int upto = (int)bcast[1];
+        if (upto <= min(512, kk + 128)) {  // block-uniform
+            if (tid == 0) {
+                const uint64_t edge = lo64 + (((uint64_t)bin + 1ull) << shift) - 1ull;
+                uint64_t t = edge < hi64 ? edge : hi64;
+                if (a.keep_thr) t = min(t, a.thr_key[slot]);
+                a.thr_key[slot] = t;
+            }
+            for (int i = tid; i < n; i += THREADS) {
+                const uint64_t key = keys[i];
+                if ((uint32_t)((key - lo64) >> shift) <= bin) wp[atomicAdd(&counters[0], 1u)] = key;
+            }
+            __syncthreads();
+            mark(2);
+            mark(3);
+            for (int i = tid; i < upto; i += THREADS) {
+                const uint64_t mine = wp[i];
+                int rank = 0;
+                for (int j = 0; j < upto; ++j) rank += wp[j] < mine ? 1 : 0;
+                if (rank < kk) {
+                    const size_t o = (size_t)q * a.top_k + rank;
+                    a.out_ids[o] = report_id((uint32_t)(mine & 0xffffffffu), a.n_codes_total);
+                    a.out_dists[o] = __uint_as_float((uint32_t)(mine >> 32));
+                }
+            }
+            mark(4);
+            if (a.stamps && tid == 0) a.stamps[(size_t)slot * 8 + 7] = __builtin_amdgcn_s_memrealtime();
+            return;
+        }
+        __syncthreads();  // hist / bcast are reused by the exact way
+    }
     uint64_t kth = ~0ull;
     if (kk > 0) kth = block_radix_select(keys, n, kk, hist, bcast, tid, THREADS);
     mark(2);
@@ -2692,7 +2863,16 @@ constexpr int kBootCellsPerThread = 2;
 constexpr int kBootBatch = 6;    // nodes a thread has in flight: cap / threads at the default cap (every step of the chain is a global or LDS round trip)
 // kBootPairs (multi-index classes = sub-space pairs): dpq_format.h
 
-template <int M>
+// V = 1 (round 4): the threshold from ONE histogram pass (block_kth_bound_u32) instead of the exact k-th key by a radix
+// select -- the block is latency-bound (wavefronts wait 59 % of their cycles, LDS array 48 % busy, VALU a third:
+// profiles/r04b_sq_bootstrap_counters.json), and the select was eleven of its barriers: 31.7 -> 25.6 us per launch.
+// V = 0: the kernel of rounds 2 - 3, kept for A/B (BootArgs.variant).  Measured and not kept (scripts/experiments/
+// r04_bootstrap_*.patch): six CONSECUTIVE nodes per thread over a list of the non-empty cells (one search + a window of
+// cell starts instead of six searches: +3 us -- the entry loads of a wave-instruction then touch six times the cache lines),
+// table fields four entries per thread (+2.6 us: same reason, the byte stores), the 64 nearest centroids ranked by counting
+// with v_readlane instead of 21 shuffle stages (rank phase 6.4 K -> 9.1 K cycles), a cell's two bounds as one 8-byte load
+// and the fields' minima fetched ahead of the threshold (nothing).
+template <int M, int V>
 // M = 8: four blocks per CU (40 KB of LDS each) = 8 wavefronts per SIMD: the register budget (SGPRs included:
 // 800 per SIMD) must allow it; M = 16: three blocks (48 KB)
 __global__ __launch_bounds__(kBootThreads, M <= 8 ? 8 : 6) void bootstrap_kernel(const BootArgs a) {
@@ -2802,6 +2982,8 @@ __global__ __launch_bounds__(kBootThreads, M <= 8 ? 8 : 6) void bootstrap_kernel
     mark(1);
 
     int have = 0;  // keys so far (block-uniform)
+    int rounds = 0;
+    uint32_t key_lo = 0xffffffffu, key_hi = 0u;  // of the keys this thread wrote (V & 1)
     // Every class walks its 65536 cells in the order w = 0, 1, ...: shell t = floor(sqrt(w)) (= max of the two
     // centroid ranks), position s = w - t^2 inside it; s <= t: ranks (i, j) = (t, s), else (s - t - 1, t).  A round
     // takes the next kBootCells / P cells of every class, class-interleaved (u = P (w - w0) + p), so that
@@ -2886,21 +3068,34 @@ __global__ __launch_bounds__(kBootThreads, M <= 8 ? 8 : 6) void bootstrap_kernel
                 float d = 0.0f;
 #pragma unroll
                 for (int m = 0; m < M; ++m) d += T[m * 256 + ((code[r][m >> 2] >> (8 * (m & 3))) & 0xffu)];
-                if (v < take) keys[have + v] = __float_as_uint(d);
+                if (v < take) {
+                    keys[have + v] = __float_as_uint(d);
+                    if constexpr (V & 1) {
+                        key_lo = min(key_lo, __float_as_uint(d));
+                        key_hi = max(key_hi, __float_as_uint(d));
+                    }
+                }
             }
         }
         have += take;
+        ++rounds;
         w0 += n_w;
         __syncthreads();  // pre / cstart / wave_sum are rewritten by the next round
         mark(3);
         if (have >= a.cap) break;
     }
+    if (a.stamps && tid == 0) a.stamps[(size_t)slot * 8 + 5] = (unsigned long long)rounds;
     uint64_t kth = ~0ull;  // fewer than k nodes in the whole multi-index: no threshold
     if (have >= a.top_k) {
         // k nodes have an fp32-summed distance <= d; their exact distances (fp64 sum rounded once; the plain scan:
         // fp32 sum in position order) are within 2^-20 of it, so d * (1 + 2^-19), rounded up, with the largest id
         // is >= the keys of k real nodes: a valid upper bound of the final k-th key.
-        const uint32_t dbits = (uint32_t)block_radix_select(keys, have, a.top_k, hist, bcast, tid, kBootThreads);
+        // (V & 1: the histogram lives where the rounds kept their cell lists -- cstart and pre, 5000 bytes)
+        uint32_t dbits;
+        if constexpr (V & 1)
+            dbits = block_kth_bound_u32<10>(keys, have, a.top_k, key_lo, key_hi, cstart, hist, tid, kBootThreads);
+        else
+            dbits = (uint32_t)block_radix_select(keys, have, a.top_k, hist, bcast, tid, kBootThreads);
         const float bound = __double2float_ru((double)__uint_as_float(dbits) * (1.0 + 0x1p-19));
         kth = ((uint64_t)__float_as_uint(bound) << 32) | 0xffffffffull;
     }
@@ -2930,25 +3125,31 @@ size_t bootstrap_lds_bytes(int M, int cap) {
     return (size_t)cap * 4 + (size_t)M * 256 * 4 + (size_t)kBootCells * 4 + (1024 + 4) * 2 + 2 * kBootPairs * 256 + (264 + 2 + 8) * 4;
 }
 
+template <int V>
+static hipError_t launch_bootstrap_variant(const BootArgs& a, int M, int n_slots, size_t lds, hipStream_t stream) {
+    if (M == 8) {
+        static std::atomic<bool> done[64] = {};
+        hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&bootstrap_kernel<8, V>), 128 * 1024, done);  // + a few static words
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((bootstrap_kernel<8, V>), dim3((unsigned)n_slots), dim3(kBootThreads), lds, stream, a);
+    } else if (M == 16) {
+        static std::atomic<bool> done[64] = {};
+        hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&bootstrap_kernel<16, V>), 128 * 1024, done);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((bootstrap_kernel<16, V>), dim3((unsigned)n_slots), dim3(kBootThreads), lds, stream, a);
+    } else {
+        return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
 hipError_t launch_bootstrap(const BootArgs& a, int M, int n_slots, hipStream_t stream) {
     if (n_slots <= 0) return hipSuccess;
     if (a.cap < a.top_k || a.cap < 2048 || a.cap > 16384 || !a.cell_start || (a.n_classes != 1 && a.n_classes != kBootPairs))
         return hipErrorInvalidValue;  // the rank sort borrows 8 KB of the key list
     const size_t lds = bootstrap_lds_bytes(M, a.cap);
-    if (M == 8) {
-        static std::atomic<bool> done[64] = {};
-        hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&bootstrap_kernel<8>), 128 * 1024, done);  // + a few static words
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(bootstrap_kernel<8>, dim3((unsigned)n_slots), dim3(kBootThreads), lds, stream, a);
-    } else if (M == 16) {
-        static std::atomic<bool> done[64] = {};
-        hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&bootstrap_kernel<16>), 128 * 1024, done);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(bootstrap_kernel<16>, dim3((unsigned)n_slots), dim3(kBootThreads), lds, stream, a);
-    } else {
-        return hipErrorInvalidValue;
-    }
-    return hipGetLastError();
+    return (a.variant & 1) ? launch_bootstrap_variant<1>(a, M, n_slots, lds, stream)
+                           : launch_bootstrap_variant<0>(a, M, n_slots, lds, stream);
 }
 
 // ---------------------------------------------------------------------------

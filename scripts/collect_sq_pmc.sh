@@ -18,7 +18,8 @@ for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SA
   i=$((i+1))
   timeout -k 10 300 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $OUT/p$i -- python bench.py --steps 3 --warmup 1 --reps 1 --no-cpu-baseline --check 0 --no-hbm-leg --sustain-seconds 0 --host-steps 0 "$@" > /dev/null 2> $OUT/p$i.err || echo "pass $i failed" >> $OUT/failed.txt
 done
-python - "$OUT" "${KERNEL:-scan_kernel}" <<'PY'
+for K in $(echo "${KERNEL:-scan_kernel}" | tr ',' ' '); do   # KERNEL: one kernel or a comma-separated list (a summary each)
+python - "$OUT" "$K" <<'PY'
 import collections, csv, glob, json, sys
 out, kernel = sys.argv[1], sys.argv[2]
 agg = collections.defaultdict(list)
@@ -32,8 +33,10 @@ for f in glob.glob(out + "/p*/*/*_counter_collection.csv"):
 res = {k: {"dispatches": len(v), "mean": sum(v) / len(v), "max": max(v)} for k, v in agg.items()}
 res["_kernel"] = kernel
 res["_scan_kernel_mean_ns_under_pmc"] = sum(dur) / max(1, len(dur))
-json.dump(res, open(out + "/sq_summary.json", "w"), indent=1)
+json.dump(res, open(out + ("/sq_summary.json" if kernel == "scan_kernel" else "/sq_summary_%s.json" % kernel), "w"), indent=1)
+print("==", kernel)
 for k, v in sorted(res.items()):
     print(k, v if not isinstance(v, dict) else round(v["mean"]))
 PY
+done
 rm -rf $OUT/p?/
