@@ -727,7 +727,9 @@ int run_batch(dpq_index* x, const float* d_queries, int nq, int top_k, int32_t* 
             // 1.05 / 1.10 / 1.00 M q/s.  Round 3, one level + in-scan tightening (scripts/gpu_boot_cap_large_k.sh),
             // 4096 / 6144 / 8192 / 12288: top-512 3.11 / 3.27 / 3.25 / 3.16, top-1000 1.76 / 1.96 / 2.10 / 2.28,
             // top-2048 0.74 / 0.97 / 1.06 / 1.20, M = 16 top-1000 1.04 / 1.17 / 1.22 / 1.27 M q/s.
-            const int cap_auto = top_k <= 256 ? (x->M <= 8 ? 3072 : 6144) : (top_k <= 640 && x->M <= 8) ? 6144 : 12288;
+            // (5888, not 6144, keys where the block is meant to stay at four per CU: 39 KB is what four blocks per CU take --
+            // see select_list_keys; M = 16 holds 16 KB of tables and runs three per CU either way)
+            const int cap_auto = top_k <= 256 ? (x->M <= 8 ? 3072 : 6144) : (top_k <= 640 && x->M <= 8) ? 5888 : 12288;
             ba.cap = std::max(std::min(cap_env > 0 ? cap_env : cap_auto, 16384), std::max(top_k, 2048));
             ba.cap = (ba.cap + 63) / 64 * 64;
             const int target_env = x->tune.boot_target;

@@ -2536,6 +2536,26 @@ __device__ __forceinline__ int32_t report_id(uint32_t pos, int64_t n_total) {
 // it was the rule up to 2 x THREADS winners; top-300 3.91 -> 4.33 M q/s, top-512 3.20 -> 3.40 M with the sort from 257 on)
 #define DPQ_RANK_BY_COUNT_MAX 256
 #endif
+// Candidate keys a block of the later levels holds in LDS: what leaves the block within 39 KB together with the winner area
+// behind the list (four blocks per CU, so the 1024 blocks of a batch are resident at once): 3968 keys at top-100, 3520 at
+// top-512, 3072 at top-1000, 1984 at top-2048 (longer lists are selected from their HBM copy, as lists beyond kSortMax always
+// were).
+// The winner area behind the list (8-byte units): the exact way's winner array (top_k rounded up to a power of two, for
+// its bitonic network), or the last level's histogram (1024 words) + bucket-sorted winner list (top_k + kBucketSlack) --
+// whichever is larger, so that the last level's bucket sort always has its room whatever the list holds.
+constexpr int kBucketSlack = 256;  // keys the k-th key's bin may bring beyond top_k, and the fullest bin the bucket sort ranks
+__host__ __device__ inline int select_area_keys(int top_k) {
+    int kp = 1;
+    while (kp < top_k) kp <<= 1;
+    return kp > 512 + kBucketSlack + top_k ? kp : 512 + kBucketSlack + top_k;
+}
+// (39 KB, not 40: with 40 824 B per block the per-block stamps showed three blocks per CU -- a quarter of a batch's blocks
+// started 19 us late -- while 39 256 B run four)
+__host__ __device__ inline int select_list_keys(int top_k) {
+    const int room = (39936 - 16 - 266 * 4 - select_area_keys(top_k) * 8) / 8;
+    return room >= kSortMax ? kSortMax : (room > 1024 ? room : 1024) & ~63;
+}
+
 // THREADS: 512 for level 0 (3840 nodes to evaluate), 256 for the later levels (about a thousand keys: fewer
 // wavefronts per barrier, 16-19 us instead of 19-21)
 template <int M, int THREADS>
@@ -2550,14 +2570,15 @@ __global__ __launch_bounds__(THREADS) void select_kernel(const SelectArgs a) {
     // LDS: [candidate keys][winner keys, histogram | level 0: the query's exact tables][counters].
     // The tables are dead once the level-0 list is evaluated, so they share their space with what the
     // selection needs afterwards: a level-0 block stays under 40 KB and four of them fit a CU.
-    const int n_lds_keys = a.shared_id ? min(a.shared_n, kSortMax) : kSortMax;
+    const int n_lds_keys = a.shared_id ? min(a.shared_n, kSortMax) : select_list_keys(a.top_k);
     uint64_t* skeys = reinterpret_cast<uint64_t*>(smem);                              // [n_lds_keys] candidate keys
     unsigned char* shared_area = smem + (size_t)n_lds_keys * 8;
     float* T = reinterpret_cast<float*>(shared_area);                                 // [M][256], level 0 only
     uint64_t* wkeys = reinterpret_cast<uint64_t*>(shared_area);                       // [KP] winner keys
-    uint32_t* hist = reinterpret_cast<uint32_t*>(wkeys + KP);                         // [kRegionStride + 1 <= 264]
+    const int AREA = a.shared_id ? KP : select_area_keys(a.top_k);                    // 8-byte units behind the list
+    uint32_t* hist = reinterpret_cast<uint32_t*>(wkeys + AREA);                       // [kRegionStride + 1 <= 264]
     uint32_t* bcast = hist + 264;                                                     // [2]
-    const size_t select_bytes = (size_t)KP * 8 + 266 * 4, table_bytes = a.shared_id ? (size_t)TE * 4 : 0;
+    const size_t select_bytes = (size_t)AREA * 8 + 266 * 4, table_bytes = a.shared_id ? (size_t)TE * 4 : 0;
     uint32_t* counters = reinterpret_cast<uint32_t*>(shared_area + (select_bytes > table_bytes ? select_bytes : table_bytes));  // [2]: winners, padding nodes
 
     const int slot = blockIdx.x;
@@ -2643,7 +2664,7 @@ __global__ __launch_bounds__(THREADS) void select_kernel(const SelectArgs a) {
         __syncthreads();
         n = (int)rstart[R];
         // keys live in LDS for the usual list sizes, in HBM scratch for huge ones (overflow reruns)
-        if (n > kSortMax) keys = a.scratch + (size_t)slot * a.cand_stride;
+        if (n > n_lds_keys) keys = a.scratch + (size_t)slot * a.cand_stride;
         // flat gather: key i of the list sits in the region r with rstart[r] <= i < rstart[r + 1]; every thread
         // has all its loads in flight at once (a region-by-region copy is a chain of global round trips)
         for (int i0 = 0; i0 < n; i0 += 4 * THREADS) {
@@ -2674,17 +2695,22 @@ __global__ __launch_bounds__(THREADS) void select_kernel(const SelectArgs a) {
     mark(1);
     const int n_valid = n - (int)counters[1];
     const int kk = min(a.top_k, n_valid);
-    // The last level of a small top_k (round 4): the output order comes from counting smaller winners anyway, so the
-    // exact k-th key is not needed first -- ONE histogram pass (1024 bins over (key - least distance) from the top set bit
-    // of the span) finds the bin the k-th key lies in, everything up to that bin is ranked by counting and the first k
-    // ranks are written.  Two passes and the single-key fetch of the radix select (9 barriers) become one (3).  The
-    // histogram and the ranked list live behind the keys in the block's key area; a crowded bin (ties by the thousand)
-    // takes the exact way below.  The slot's threshold for a rerun after an overflow is the bin's upper edge.
+    // The LAST level (round 4): selection and order from ONE histogram pass -- a bucket sort.  1024 bins over (key - least
+    // distance bits << 32) from the top set bit of the span (the gather kept the distance extremes in registers); wave 0
+    // scans the bins, finds the bin B the k-th key lies in and turns the counts into bin starts; every key of a bin <= B is
+    // scattered to its bin's range of the winner list (the bin's word is its cursor: one LDS atomic per winner), and a
+    // winner's output rank = its bin's start + the smaller keys INSIDE its bin (one to three keys per bin as a rule).  Three
+    // barriers and two passes over the keys, against the radix select's two or three passes + single-key fetch + winner
+    // compaction (nine barriers, six passes) followed by kk broadcast reads per winner (top_k <= 256) or a bitonic network of
+    // 55 barrier stages (top-1000).  The histogram and the winner list live behind the keys (select_area_keys keeps their
+    // room whatever the list holds; the keys may be in the HBM scratch).  A crowded bin (more than kBucketSlack keys: ties by the
+    // hundred) or a k-th bin that brings more than kBucketSlack keys too many takes the exact way below.  The slot's threshold for a rerun after an overflow is
+    // bin B's upper edge.
     const int n_even = (n + 1) & ~1;
-    if (a.fast_final && !shared && a.final_pass && kk == a.top_k && kk <= DPQ_RANK_BY_COUNT_MAX && keys == skeys &&
-        n_even + 1024 <= n_lds_keys) {
-        uint32_t* h1 = reinterpret_cast<uint32_t*>(skeys + n_even);  // [1024]
-        uint64_t* wp = skeys + n_even + 512;                          // [512]
+    const int fast_base = keys == skeys ? n_even : 0;  // u64 units of the key + winner area in use by the keys
+    if (a.fast_final && !shared && a.final_pass && kk == a.top_k) {  // (fast_base <= n_lds_keys, 512 + kk + kBucketSlack <= AREA)
+        uint32_t* h1 = reinterpret_cast<uint32_t*>(skeys + fast_base);  // [1024]
+        uint64_t* wp = skeys + fast_base + 512;                          // [kk + kBucketSlack]
         for (int i = tid; i < 1024; i += THREADS) h1[i] = 0u;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
@@ -2720,28 +2746,42 @@ __global__ __launch_bounds__(THREADS) void select_kernel(const SelectArgs a) {
                 if (tid >= off) incl += up;
             }
             const uint32_t before = incl - mine;
-            if (before < (uint32_t)kk && (uint32_t)kk <= incl) {  // exactly one lane
-                uint32_t upto = before;
-                int bin = 16 * tid + 15;
-                bool found = false;
+            // the bin of the k-th key (found by exactly one lane), the keys up to and including it
+            const bool owner = before < (uint32_t)kk && (uint32_t)kk <= incl;
+            uint32_t run = before, bin = 0, upto = 0, start[16];
+            bool found = false;
 #pragma unroll
-                for (int j = 0; j < 16; ++j) {
-                    if (!found) {
-                        upto += h[j];
-                        if (upto >= (uint32_t)kk) {
-                            bin = 16 * tid + j;
-                            found = true;
-                        }
-                    }
+            for (int j = 0; j < 16; ++j) {
+                start[j] = run;
+                run += h[j];
+                if (owner && !found && run >= (uint32_t)kk) {
+                    bin = (uint32_t)(16 * tid + j);
+                    upto = run;
+                    found = true;
                 }
-                bcast[0] = (uint32_t)bin;
-                bcast[1] = upto;  // keys up to and including the bin
+            }
+            const int src = __ffsll((unsigned long long)__ballot(owner)) - 1;  // kk <= n: some lane owns it
+            bin = (uint32_t)__shfl((int)bin, src, 64);
+            upto = (uint32_t)__shfl((int)upto, src, 64);
+            uint32_t crowd = 0;  // the fullest bin up to B
+#pragma unroll
+            for (int j = 0; j < 16; ++j) crowd = max(crowd, (uint32_t)(16 * tid + j) <= bin ? h[j] : 0u);
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) crowd = max(crowd, (uint32_t)__shfl_xor((int)crowd, off, 64));
+            // counts -> bin starts (the scatter's cursors)
+#pragma unroll
+            for (int j = 0; j < 16; j += 4)
+                *reinterpret_cast<uint4*>(h1 + 16 * tid + j) = make_uint4(start[j], start[j + 1], start[j + 2], start[j + 3]);
+            if (tid == 0) {
+                bcast[0] = bin;
+                bcast[1] = upto;
+                hist[64] = crowd;
             }
         }
         __syncthreads();
         const uint32_t bin = bcast[0];
         const int upto = (int)bcast[1];
-        if (upto <= min(512, kk + 128)) {  // block-uniform
+        if (upto <= kk + kBucketSlack && hist[64] <= (uint32_t)kBucketSlack) {  // block-uniform
             if (tid == 0) {
                 const uint64_t edge = lo64 + (((uint64_t)bin + 1ull) << shift) - 1ull;
                 uint64_t t = edge < hi64 ? edge : hi64;
@@ -2750,15 +2790,19 @@ __global__ __launch_bounds__(THREADS) void select_kernel(const SelectArgs a) {
             }
             for (int i = tid; i < n; i += THREADS) {
                 const uint64_t key = keys[i];
-                if ((uint32_t)((key - lo64) >> shift) <= bin) wp[atomicAdd(&counters[0], 1u)] = key;
+                const uint32_t b = (uint32_t)((key - lo64) >> shift);
+                if (b <= bin) wp[atomicAdd(&h1[b], 1u)] = key;
             }
             __syncthreads();
             mark(2);
             mark(3);
+            // bin b now spans [h1[b - 1], h1[b]) of the winner list (its cursor ran to the next bin's start)
             for (int i = tid; i < upto; i += THREADS) {
                 const uint64_t mine = wp[i];
-                int rank = 0;
-                for (int j = 0; j < upto; ++j) rank += wp[j] < mine ? 1 : 0;
+                const uint32_t b = (uint32_t)((mine - lo64) >> shift);
+                const int s0 = b ? (int)h1[b - 1] : 0, e0 = (int)h1[b];
+                int rank = s0;
+                for (int j = s0; j < e0; ++j) rank += wp[j] < mine ? 1 : 0;
                 if (rank < kk) {
                     const size_t o = (size_t)q * a.top_k + rank;
                     a.out_ids[o] = report_id((uint32_t)(mine & 0xffffffffu), a.n_codes_total);
@@ -2871,7 +2915,10 @@ constexpr int kBootBatch = 6;    // nodes a thread has in flight: cap / threads 
 // cell starts instead of six searches: +3 us -- the entry loads of a wave-instruction then touch six times the cache lines),
 // table fields four entries per thread (+2.6 us: same reason, the byte stores), the 64 nearest centroids ranked by counting
 // with v_readlane instead of 21 shuffle stages (rank phase 6.4 K -> 9.1 K cycles), a cell's two bounds as one 8-byte load
-// and the fields' minima fetched ahead of the threshold (nothing).
+// and the fields' minima fetched ahead of the threshold (nothing); the histogram filled WHILE the nodes are evaluated, over a
+// range fixed by the block's first batch of keys, so that no key is stored and the block's LDS stops growing with the nodes
+// it evaluates (top-1000: 65 KB = two blocks per CU -> 24.5 KB = four): top-100 22.5 -> 23.0 us and a looser bound,
+// top-1000 + 1 %, top-512 - 2 % (profiles/r04b_boot_online_histogram_ab.txt): the blocks per CU were not what bounds it.
 template <int M, int V>
 // M = 8: four blocks per CU (40 KB of LDS each) = 8 wavefronts per SIMD: the register budget (SGPRs included:
 // 800 per SIMD) must allow it; M = 16: three blocks (48 KB)
@@ -3275,8 +3322,9 @@ size_t scan_lds_bytes(int M) { return M <= 8 ? ScanLds<8>::kBytes : ScanLds<16>:
 size_t select_lds_bytes(int M, int top_k, int n_shared) {
     size_t kp = 1;
     while (kp < (size_t)top_k) kp <<= 1;
-    const size_t n_keys = n_shared > 0 ? (size_t)std::min(n_shared, kSortMax) : (size_t)kSortMax;
-    const size_t select_bytes = kp * 8 + 266 * 4, table_bytes = n_shared > 0 ? (size_t)M * 256 * 4 : 0;
+    const size_t n_keys = n_shared > 0 ? (size_t)std::min(n_shared, kSortMax) : (size_t)select_list_keys(top_k);
+    const size_t area = n_shared > 0 ? kp : (size_t)select_area_keys(top_k);
+    const size_t select_bytes = area * 8 + 266 * 4, table_bytes = n_shared > 0 ? (size_t)M * 256 * 4 : 0;
     return n_keys * 8 + std::max(select_bytes, table_bytes) + 16;
 }
 
@@ -3452,7 +3500,7 @@ template <int M, int THREADS>
 static hipError_t launch_select_m(const SelectArgs& a, int n_slots, hipStream_t stream) {
     static std::atomic<bool> done[64] = {};
     hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&select_kernel<M, THREADS>),
-                                      select_lds_bytes(M, kMaxTopK, kSortMax), done);
+                                      64 * 1024, done);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL((select_kernel<M, THREADS>), dim3((unsigned)n_slots), dim3(THREADS),
                        select_lds_bytes(M, a.top_k, a.shared_id ? a.shared_n : 0), stream, a);

@@ -4,8 +4,9 @@ of the k-th key leaves the results bit-identical; these tests pin WHY the bound 
 
 * block_kth_bound_u32 (bootstrap_kernel<M, V & 1>): 1024 bins over (key - min) cut from the top set bit of (max - min);
   the threshold is the upper edge of the bin the rank falls into, never above max.
-* select_kernel's last level for top_k <= 256 (SelectArgs.fast_final): 1024 bins over (key - least distance bits << 32)
-  of the 64-bit keys; everything up to the rank's bin is ranked by counting and the first k ranks are written.
+* select_kernel's last level (SelectArgs.fast_final): a bucket sort -- 1024 bins over (key - least distance bits << 32) of the
+  64-bit keys; the keys up to the rank's bin are scattered to their bins' ranges (bin starts = prefix of the counts) and a
+  key's output rank is its bin's start + the smaller keys inside its bin.
 """
 import numpy as np
 import pytest
@@ -57,7 +58,8 @@ def test_bootstrap_bound_degenerate_spans():
 
 
 def fast_final(keys, k):
-    """select_kernel, fast_final: returns the k winners in output order, or None where the kernel takes the exact way."""
+    """select_kernel, fast_final (a bucket sort): returns the k winners in output order and the slot's rerun threshold, or
+    (None, None) where the kernel takes the exact way."""
     keys = np.asarray(keys, dtype=np.uint64)
     dlo, dhi = int(keys.min() >> np.uint64(32)), int(keys.max() >> np.uint64(32))
     lo64, hi64 = dlo << 32, (dhi << 32) | 0xffffffff
@@ -66,21 +68,33 @@ def fast_final(keys, k):
     shift = hi_bit - 9
     bins = ((keys - np.uint64(lo64)) >> np.uint64(shift)).astype(np.int64)
     assert bins.max() < 1024
-    incl = np.cumsum(np.bincount(bins, minlength=1024))
-    b = int(np.searchsorted(incl, k, side="left"))
+    hist = np.bincount(bins, minlength=1024)
+    incl = np.cumsum(hist)
+    b = int(np.searchsorted(incl, k, side="left"))           # the bin of the k-th key
     upto = int(incl[b])
-    if upto > min(512, k + 128):
+    if upto > k + 64 or hist[: b + 1].max() > 64:            # crowded: the radix select
         return None, None
     edge = min(lo64 + ((b + 1) << shift) - 1, hi64)
-    plus = keys[bins <= b]                                   # compacted in any order
-    ranks = (plus[None, :] < plus[:, None]).sum(axis=1)      # keys are unique: rank = number of smaller ones
+    start = incl - hist                                       # counts -> bin starts = the scatter's cursors
+    cursor = start.copy()
+    wp = np.zeros(upto, dtype=np.uint64)
+    for key, bn in zip(keys, bins):                           # any order of arrival
+        if bn <= b:
+            wp[cursor[bn]] = key
+            cursor[bn] += 1
     out = np.zeros(k, dtype=np.uint64)
-    out[ranks[ranks < k]] = plus[ranks < k]
+    for i in range(upto):
+        mine = wp[i]
+        bn = int((int(mine) - lo64) >> shift)
+        s0, e0 = (int(cursor[bn - 1]) if bn else 0), int(cursor[bn])   # bin bn's range after the scatter
+        rank = s0 + int((wp[s0:e0] < mine).sum())
+        if rank < k:
+            out[rank] = mine
     return out, edge
 
 
 @pytest.mark.parametrize("seed", range(8))
-@pytest.mark.parametrize("n,k", [(400, 100), (130, 128), (3000, 256), (101, 100), (900, 10)])
+@pytest.mark.parametrize("n,k", [(400, 100), (130, 128), (3000, 256), (101, 100), (900, 10), (4800, 1000), (9000, 2048)])
 def test_fast_final_level_returns_the_k_smallest_in_order(seed, n, k):
     rng = np.random.default_rng(seed * 77 + n + k)
     d = rng.gamma(3.0, 7000.0, size=n).astype(np.float32)
