@@ -62,6 +62,23 @@ def pmc_traffic(args, world):
     return None, None, None
 
 
+def profile_launch_ms(args, world):
+    """The scan kernel's average launch duration in the committed rocprofv3 --kernel-trace --stats run of this workload
+    (profiles/*_kernel_stats.csv, summarised by scripts/collect_pmc.sh), so that a reader can recompute `roofline.frac`
+    from profiles/ alone: (ms, file) or (None, None) where no profile of this workload is committed."""
+    for name in ("r04_pmc_summary_default.json", "r04_pmc_summary_m16_top1000.json", "r03_pmc_summary_default.json"):
+        path = os.path.join(HERE, "profiles", name)
+        if not os.path.exists(path):
+            continue
+        with open(path) as f:
+            s = json.load(f)
+        w = s.get("workload", {})
+        if (w.get("n"), w.get("queries"), w.get("topk"), w.get("m"), w.get("data"), w.get("gpus")) == \
+                (args.n, args.queries, args.topk, args.m, args.data, world) and s.get("scan_kernel_avg_launch_ms_kernel_trace"):
+            return float(s["scan_kernel_avg_launch_ms_kernel_trace"]), name
+    return None, None
+
+
 def hbm_leg():
     """The regime the north star's HBM target is about, measured in the same run: ONE query per call (the reference's
     call shape) on an index far beyond L2 + Infinity Cache -- 125 M codes, one GPU's share of BASELINE configs[4] --
@@ -567,6 +584,7 @@ def main():
         lds_gbps = lds_total / (scan_ms_step * 1e-3) / 1e9 if scan_ms_step > 0 else 0.0
         traffic, pmc_launch_ms, pmc_name = pmc_traffic(args, world)
         avg_launch_ms = scan_ms_step / launches_step if launches_step else None
+        prof_ms, prof_name = profile_launch_ms(args, world)
         global_q = (world if by_query else 1) * nq
         bytes_per_code = float(all_stats[:, 2].sum()) / max(1.0, float(all_stats[:, 10].sum()))
         result = {
@@ -639,6 +657,11 @@ def main():
                             % (groups * QG if batch_decoded else QG)},
                 "launches_per_step": launches_step,
                 "avg_launch_ms": avg_launch_ms,
+                # the same kernel in the committed rocprofv3 --kernel-trace --stats run of this workload (one lane, another box /
+                # another run): what `frac` is when recomputed from profiles/ alone
+                "from_profiles": None if not (prof_ms and launches_step) else {
+                    "avg_launch_ms_kernel_trace": prof_ms, "source": "profiles/%s" % prof_name,
+                    "frac": lds_total / launches_step / (prof_ms * 1e-3) / 1e9 / (LDS_PEAK_GBPS * world)},
                 "scan_ms_per_step": scan_ms_step,
                 "select_ms_per_step": float(all_stats[:, 4].max()) / aux_steps,
                 "lut_ms_per_step": float(all_stats[:, 5].max()) / aux_steps,
