@@ -2558,8 +2558,12 @@ __host__ __device__ inline int select_list_keys(int top_k) {
 
 // THREADS: 512 for level 0 (3840 nodes to evaluate), 256 for the later levels (about a thousand keys: fewer
 // wavefronts per barrier, 16-19 us instead of 19-21)
+// Second launch bound (eight wavefronts per SIMD): without it the compiler took 94 + 6 SGPRs = 112 allocated, i.e. seven
+// wavefronts per SIMD (800 SGPRs each), and a CU held three 512-thread blocks instead of four -- every 512-thread launch
+// (top_k > 512) ran its 1000 blocks in two rounds (per-block stamps: a quarter of the blocks started 20 - 45 us late,
+// profiles/r04b_select_stamps_large_k.txt).
 template <int M, int THREADS>
-__global__ __launch_bounds__(THREADS) void select_kernel(const SelectArgs a) {
+__global__ __launch_bounds__(THREADS, 8) void select_kernel(const SelectArgs a) {
     constexpr int W = Cfg<M>::W;
     constexpr int TE = M * 256;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -2748,17 +2752,23 @@ __global__ __launch_bounds__(THREADS) void select_kernel(const SelectArgs a) {
             const uint32_t before = incl - mine;
             // the bin of the k-th key (found by exactly one lane), the keys up to and including it
             const bool owner = before < (uint32_t)kk && (uint32_t)kk <= incl;
-            uint32_t run = before, bin = 0, upto = 0, start[16];
+            uint32_t run = before, bin = 0, upto = 0;
             bool found = false;
+            // counts -> bin starts (the scatter's cursors), four bins at a time
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                start[j] = run;
-                run += h[j];
-                if (owner && !found && run >= (uint32_t)kk) {
-                    bin = (uint32_t)(16 * tid + j);
-                    upto = run;
-                    found = true;
+            for (int j = 0; j < 16; j += 4) {
+                uint32_t st[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    st[i] = run;
+                    run += h[j + i];
+                    if (owner && !found && run >= (uint32_t)kk) {
+                        bin = (uint32_t)(16 * tid + j + i);
+                        upto = run;
+                        found = true;
+                    }
                 }
+                *reinterpret_cast<uint4*>(h1 + 16 * tid + j) = make_uint4(st[0], st[1], st[2], st[3]);
             }
             const int src = __ffsll((unsigned long long)__ballot(owner)) - 1;  // kk <= n: some lane owns it
             bin = (uint32_t)__shfl((int)bin, src, 64);
@@ -2768,10 +2778,6 @@ __global__ __launch_bounds__(THREADS) void select_kernel(const SelectArgs a) {
             for (int j = 0; j < 16; ++j) crowd = max(crowd, (uint32_t)(16 * tid + j) <= bin ? h[j] : 0u);
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) crowd = max(crowd, (uint32_t)__shfl_xor((int)crowd, off, 64));
-            // counts -> bin starts (the scatter's cursors)
-#pragma unroll
-            for (int j = 0; j < 16; j += 4)
-                *reinterpret_cast<uint4*>(h1 + 16 * tid + j) = make_uint4(start[j], start[j + 1], start[j + 2], start[j + 3]);
             if (tid == 0) {
                 bcast[0] = bin;
                 bcast[1] = upto;

@@ -17,6 +17,6 @@ cp $G/r04_m16_top1000/r04_m16_top1000_kernel_stats.csv $P/ 2>/dev/null
 cp $G/r04_m16_top1000/r04_m16_top1000_pmc_summary.json $P/r04_pmc_summary_m16_top1000.json 2>/dev/null
 cp $G/r04final/r04_pytest_gpu.log $G/r04final/r04_fuzz.log $G/r04final/r04_fuzz_big.log $P/ 2>/dev/null
 cp $G/s1_skip.txt $P/r04_strand1_parts_left_out.txt 2>/dev/null
-cp $G/scaling/inputs.txt $P/r04_scaling_inputs.txt 2>/dev/null
+cp $G/scaling/inputs.txt $P/r04b_scaling_inputs.txt 2>/dev/null   # (r04_scaling_inputs.txt: the first half of the round)
 cp $G/prio_ab.txt $P/r04_lane_gate_and_priority_ab.txt 2>/dev/null
 ls -la $P | grep r04

@@ -834,6 +834,42 @@ def test_large_topk_takes_one_level_when_the_scan_tightens(gpu, oracle, M, k):
     assert_parity(res[0][0][sample], res[0][1][sample], oracle_topk(oracle, payload, n, cb, qs[sample], k), n)
 
 
+@pytest.mark.parametrize("M,k,dup", [(8, 1, False), (8, 100, False), (8, 100, True), (8, 256, False), (8, 300, False),
+                                     (8, 1000, False), (8, 2048, False), (16, 100, False), (16, 1000, False)])
+def test_histogram_selection_rules_change_nothing_but_the_work(gpu, oracle, monkeypatch, M, k, dup):
+    """Round 4's one-histogram-pass rules against the exact ones they replace, bit for bit, over top_k: the bootstrap's
+    threshold as the upper edge of the k-th key's bin (bootstrap_kernel<M, 1>; 0 = radix select) and the select kernel's last
+    level as a bucket sort (SelectArgs.fast_final; 0 = radix select + rank count / bitonic network).  Any valid upper bound of
+    the k-th key leaves the lists identical, and a bucket sort orders like any other sort; also on a duplicate-heavy index,
+    where crowded bins send the select down the exact way.  The developer switches are read at dpq_open_* under DPQ_DEV=1."""
+    from deltapq_amd import synth
+    n = 250_000
+    cb = synth.make_codebook(M, 256, 128 // M, seed=25)
+    tree = synth.synth_tree(n, M, seed=k + M + 3, mean_diffs=(0.4 if dup else 3.0) if M == 8 else 5.0)
+    payload, _ = synth.encode_dtc(tree)
+    qs = synth.make_queries(200, 128, seed=k + 7)
+    monkeypatch.setenv("DPQ_DEV", "1")
+    res = {}
+    for variant, fast in ((1, 1), (0, 0), (1, 0), (0, 1)):
+        monkeypatch.setenv("DPQ_BOOT_VARIANT", str(variant))
+        monkeypatch.setenv("DPQ_SELECT_FAST", str(fast))
+        with gpu.DeltaPQIndex.open_memory(payload, n, M, 256) as idx:
+            idx.set_codebook(cb)
+            idx.profile_enable(1)
+            idx.profile_reset()
+            ids, d = idx.query_batch(qs, k)
+            res[variant, fast] = (ids, d, idx.profile_read())
+    base = res[1, 1]
+    assert base[2]["bootstrap_launches"] >= 1
+    for key, (ids, d, prof) in res.items():
+        assert np.array_equal(ids, base[0]) and np.array_equal(d.view(np.uint32), base[1].view(np.uint32)), key
+        assert prof["scan_node_query_pairs"] == base[2]["scan_node_query_pairs"]
+    # the bound is at most one bin (2^-9 of the keys' span) above the exact k-th key: the work barely moves
+    assert res[1, 1][2]["exact_checks"] <= 1.1 * res[0, 0][2]["exact_checks"] + 64
+    sample = [0, 63, 64, 199]
+    assert_parity(base[0][sample], base[1][sample], oracle_topk(oracle, payload, n, cb, qs[sample], k), n)
+
+
 def test_codebook_can_be_set_again_between_scratch_batches(gpu, oracle, codebook):
     """dpq_set_codebook after batches that used the plain-code scratch and the relabelled tables (it once freed them):
     the same index answers for a second codebook and again for the first."""
