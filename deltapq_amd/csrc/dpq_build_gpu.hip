@@ -19,6 +19,7 @@
 #include <hipcub/hipcub.hpp>
 
 #include <cstdint>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -135,6 +136,37 @@ __global__ void bump_kernel(const uint32_t* __restrict__ is_child, const uint32_
     }
 }
 
+// Pre-filter of a position subset (round 4): only nodes whose masked key occurs at least TWICE among the active nodes can
+// be members of a clique, and at M = 16 they are a few per cent -- the sort / group / emit passes then run on those alone
+// (a node alone under its key changes nothing: group_kernel returns on groups of one; the members' relative order, hence the
+// stable sort's and the emitted edges' order, is what it was).  A hash table of 32-bit words tagged by the subset's epoch
+// (no clearing between subsets): the first node of a slot leaves `tag`, every later one raises it to `tag | 1`; a node is
+// kept iff its slot ends at `tag | 1`.  Equal keys share a slot, so no member of a clique is ever dropped; a collision of
+// different keys only keeps a node that the grouping then finds alone.
+__device__ __forceinline__ uint32_t key_slot(uint64_t lo, uint64_t hi, uint32_t slot_mask) {
+    uint64_t h = lo * 0x9E3779B97F4A7C15ull;
+    h ^= (hi + 0x7F4A7C159E3779B9ull) * 0xC2B2AE3D27D4EB4Full;
+    h ^= h >> 29;
+    h *= 0xBF58476D1CE4E5B9ull;
+    h ^= h >> 32;
+    return (uint32_t)h & slot_mask;
+}
+
+__global__ void hash_mark_kernel(const uint64_t* __restrict__ key_lo, const uint64_t* __restrict__ key_hi, int64_t n,
+                                 uint32_t tag, uint32_t slot_mask, uint32_t* __restrict__ table) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t* w = table + key_slot(key_lo[i], key_hi ? key_hi[i] : 0, slot_mask);
+    if (atomicMax(w, tag) >= tag) atomicMax(w, tag | 1u);  // tags grow with the epoch: an older subset's word is below `tag`
+}
+
+__global__ void hash_flag_kernel(const uint64_t* __restrict__ key_lo, const uint64_t* __restrict__ key_hi, int64_t n,
+                                 uint32_t tag, uint32_t slot_mask, const uint32_t* __restrict__ table,
+                                 uint8_t* __restrict__ flags) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) flags[i] = table[key_slot(key_lo[i], key_hi ? key_hi[i] : 0, slot_mask)] == (tag | 1u) ? 1 : 0;
+}
+
 __global__ void unmerged_flags_kernel(const uint32_t* __restrict__ ids, const uint8_t* __restrict__ merged, int64_t n,
                                       uint8_t* __restrict__ flags) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -165,6 +197,12 @@ int find_edges_gpu(const uint8_t* codes, int64_t n, int M, int max_height_folds,
              *d_cslot = nullptr, *d_fslot = nullptr, *d_edges = nullptr, *d_finalists = nullptr, *d_counters = nullptr,
              *d_num = nullptr, *d_perm_a = nullptr, *d_perm_b = nullptr;
     uint64_t *d_klo_a = nullptr, *d_klo_b = nullptr, *d_khi_a = nullptr, *d_khi_b = nullptr;
+    uint32_t *d_table = nullptr, *d_iota = nullptr, *d_pos = nullptr;  // the subsets' pre-filter (hash_mark_kernel)
+    // developer A/B: DPQ_DEV=1 DPQ_BUILD_PREFILTER=0 runs every subset's sort on all active nodes, as rounds 2 - 3 did
+    const char* dev_env = getenv("DPQ_DEV");
+    const char* pf_env = getenv("DPQ_BUILD_PREFILTER");
+    const bool prefilter = !(dev_env && atoi(dev_env) != 0 && pf_env && atoi(pf_env) == 0);
+    uint32_t slot_mask = 0, epoch = 0;
     void* d_temp = nullptr;
     size_t temp_bytes = 0;
     int64_t n_cur = n;
@@ -212,6 +250,16 @@ int find_edges_gpu(const uint8_t* codes, int64_t n, int M, int max_height_folds,
         GB_HIP(hipMalloc(&d_temp, temp_bytes));
     }
     hipLaunchKernelGGL(iota_kernel, dim3(blocks_for(n)), dim3(256), 0, 0, d_cur, n);
+    if (prefilter) {
+        size_t slots = 1u << 16;
+        while (slots < 4 * N && slots < ((size_t)1 << 30)) slots <<= 1;  // load factor <= 1/4: few nodes kept by collision
+        slot_mask = (uint32_t)(slots - 1);
+        GB_HIP(hipMalloc(&d_table, slots * 4));
+        GB_HIP(hipMemset(d_table, 0, slots * 4));
+        GB_HIP(hipMalloc(&d_iota, N * 4));
+        GB_HIP(hipMalloc(&d_pos, N * 4));
+        hipLaunchKernelGGL(iota_kernel, dim3(blocks_for(n)), dim3(256), 0, 0, d_iota, n);
+    }
 
     for (int diff = 0; diff <= M; ++diff) {
         position_subsets(M, M - diff, &combos);
@@ -231,6 +279,33 @@ int find_edges_gpu(const uint8_t* codes, int64_t n, int M, int max_height_folds,
             }
             hipLaunchKernelGGL(make_keys_kernel, dim3(blocks_for(n_act)), dim3(256), 0, 0, d_codes, M, d_act,
                                (int64_t)n_act, mlo, mhi, d_klo_a, wide ? d_khi_a : nullptr);
+            if (prefilter) {
+                const uint32_t tag = ++epoch << 1;  // < 2^31: at most 2^16 subsets per diff, M + 1 diffs
+                hipLaunchKernelGGL(hash_mark_kernel, dim3(blocks_for(n_act)), dim3(256), 0, 0, d_klo_a,
+                                   wide ? d_khi_a : nullptr, (int64_t)n_act, tag, slot_mask, d_table);
+                hipLaunchKernelGGL(hash_flag_kernel, dim3(blocks_for(n_act)), dim3(256), 0, 0, d_klo_a,
+                                   wide ? d_khi_a : nullptr, (int64_t)n_act, tag, slot_mask, d_table, d_flags);
+                tb = temp_bytes;
+                GB_HIP(hipcub::DeviceSelect::Flagged(d_temp, tb, d_iota, d_flags, d_pos, d_num, (int)n_act));
+                uint32_t n_keep = 0;
+                GB_HIP(hipMemcpy(&n_keep, d_num, 4, hipMemcpyDeviceToHost));
+                if (n_keep < 2) continue;  // no two active nodes agree on the kept positions: nothing to merge
+                if (n_keep < n_act) {
+                    // the kept nodes, in their order, take the place of the active list for the rest of this subset
+                    hipLaunchKernelGGL(gather_u32_kernel, dim3(blocks_for(n_keep)), dim3(256), 0, 0, d_act, d_pos,
+                                       (int64_t)n_keep, d_ids_b);
+                    hipLaunchKernelGGL(gather_u64_kernel, dim3(blocks_for(n_keep)), dim3(256), 0, 0, d_klo_a, d_pos,
+                                       (int64_t)n_keep, d_klo_b);
+                    GB_HIP(hipMemcpyAsync(d_act, d_ids_b, (size_t)n_keep * 4, hipMemcpyDeviceToDevice, 0));
+                    GB_HIP(hipMemcpyAsync(d_klo_a, d_klo_b, (size_t)n_keep * 8, hipMemcpyDeviceToDevice, 0));
+                    if (wide) {
+                        hipLaunchKernelGGL(gather_u64_kernel, dim3(blocks_for(n_keep)), dim3(256), 0, 0, d_khi_a, d_pos,
+                                           (int64_t)n_keep, d_khi_b);
+                        GB_HIP(hipMemcpyAsync(d_khi_a, d_khi_b, (size_t)n_keep * 8, hipMemcpyDeviceToDevice, 0));
+                    }
+                    n_act = n_keep;
+                }
+            }
             const uint64_t *s_lo = nullptr, *s_hi = nullptr;
             const uint32_t* s_ids = nullptr;
             if (!wide) {
@@ -299,6 +374,7 @@ int find_edges_gpu(const uint8_t* codes, int64_t n, int M, int max_height_folds,
     hipFree(d_cur); hipFree(d_act); hipFree(d_ids_a); hipFree(d_ids_b); hipFree(d_parent); hipFree(d_cslot);
     hipFree(d_fslot); hipFree(d_edges); hipFree(d_finalists); hipFree(d_counters); hipFree(d_num); hipFree(d_perm_a);
     hipFree(d_perm_b); hipFree(d_klo_a); hipFree(d_klo_b); hipFree(d_khi_a); hipFree(d_khi_b); hipFree(d_temp);
+    hipFree(d_table); hipFree(d_iota); hipFree(d_pos);
     return ok ? DPQ_OK : DPQ_ERR_HIP;
 }
 
