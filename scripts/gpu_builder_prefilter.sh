@@ -11,7 +11,7 @@ tail -2 $O/pytest_builder.log
 for pf in ${PFS:-1}; do
   step "1 M x M = 16 build, pre-filter $pf"
   rm -rf /tmp/idx16_$pf
-  ( export DPQ_DEV=1 DPQ_BUILD_PREFILTER=$pf; /usr/bin/time -v timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof$pf -- python bench.py --m 16 --topk 1000 --index-dir /tmp/idx16_$pf --build-only > $O/build$pf.json 2> $O/build$pf.err ) ; echo "rc=$?"
+  ( export DPQ_DEV=1 DPQ_BUILD_PREFILTER=$pf; timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof$pf -- python bench.py --m 16 --topk 1000 --index-dir /tmp/idx16_$pf --build-only > $O/build$pf.json 2> $O/build$pf.err ) ; echo "rc=$?"
   cat $O/build$pf.json | tail -1
   f=$(ls $O/prof$pf/*/*kernel_stats.csv | head -1)
   python - "$f" <<'PY' | tee $O/stats$pf.txt
