@@ -252,7 +252,8 @@ int find_edges_gpu(const uint8_t* codes, int64_t n, int M, int max_height_folds,
     hipLaunchKernelGGL(iota_kernel, dim3(blocks_for(n)), dim3(256), 0, 0, d_cur, n);
     if (prefilter) {
         size_t slots = 1u << 16;
-        while (slots < 4 * N && slots < ((size_t)1 << 30)) slots <<= 1;  // load factor <= 1/4: few nodes kept by collision
+        // load factor <= 1/16 (at 1/4 collisions alone kept 22 % of the nodes: profiles/r04b_builder_prefilter_m16.txt); 1 GB at most
+        while (slots < 16 * N && slots < ((size_t)1 << 28)) slots <<= 1;
         slot_mask = (uint32_t)(slots - 1);
         GB_HIP(hipMalloc(&d_table, slots * 4));
         GB_HIP(hipMemset(d_table, 0, slots * 4));
