@@ -41,10 +41,12 @@ int layout_tree(const uint8_t* codes, int64_t n, int M, int K, int max_height_fo
                 const std::vector<uint32_t>& finalists, std::vector<std::pair<uint32_t, uint32_t>>* edges, Tree* out,
                 std::string* err);
 void position_subsets(int M, int keep, std::vector<std::vector<int>>* out);  // lexicographic, create_tree.h:75-95
-// Edge search on the GPU (same groups, same parents, same edge order as find_edges_host).
+// Edge search on the GPU (same groups, same parents, same edge order as find_edges_host).  prefilter: every position
+// subset's sort / group / emit passes run on the nodes whose masked key occurs at least twice (hash_mark_kernel); false:
+// on all active nodes, as rounds 2 - 3 did (developer A/B: the same edges either way).
 int find_edges_gpu(const uint8_t* codes, int64_t n, int M, int max_height_folds, int device,
                    std::vector<uint32_t>* finalists, std::vector<std::pair<uint32_t, uint32_t>>* edges,
-                   std::string* err);
+                   std::string* err, bool prefilter = true);
 // Everything after the edge search on the GPU: the same Tree as layout_tree, array for array.
 int layout_tree_gpu(const uint8_t* codes, int64_t n, int M, int K, int max_height_folds, const float* codewords, int Ds,
                     const std::vector<uint32_t>& finalists, std::vector<std::pair<uint32_t, uint32_t>>* edges, int device,

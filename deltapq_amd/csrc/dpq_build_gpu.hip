@@ -19,7 +19,6 @@
 #include <hipcub/hipcub.hpp>
 
 #include <cstdint>
-#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -179,7 +178,7 @@ inline unsigned blocks_for(int64_t n) { return (unsigned)((n + 255) / 256); }
 
 int find_edges_gpu(const uint8_t* codes, int64_t n, int M, int max_height_folds, int device,
                    std::vector<uint32_t>* finalists_out, std::vector<std::pair<uint32_t, uint32_t>>* edges_out,
-                   std::string* err) {
+                   std::string* err, bool prefilter) {
     if (!codes || n < 1 || M < 1 || M > 16 || max_height_folds < 1) {
         if (err) *err = "bad argument to find_edges_gpu";
         return DPQ_ERR_ARG;
@@ -198,10 +197,6 @@ int find_edges_gpu(const uint8_t* codes, int64_t n, int M, int max_height_folds,
              *d_num = nullptr, *d_perm_a = nullptr, *d_perm_b = nullptr;
     uint64_t *d_klo_a = nullptr, *d_klo_b = nullptr, *d_khi_a = nullptr, *d_khi_b = nullptr;
     uint32_t *d_table = nullptr, *d_iota = nullptr, *d_pos = nullptr;  // the subsets' pre-filter (hash_mark_kernel)
-    // developer A/B: DPQ_DEV=1 DPQ_BUILD_PREFILTER=0 runs every subset's sort on all active nodes, as rounds 2 - 3 did
-    const char* dev_env = getenv("DPQ_DEV");
-    const char* pf_env = getenv("DPQ_BUILD_PREFILTER");
-    const bool prefilter = !(dev_env && atoi(dev_env) != 0 && pf_env && atoi(pf_env) == 0);
     uint32_t slot_mask = 0, epoch = 0;
     void* d_temp = nullptr;
     size_t temp_bytes = 0;

@@ -1461,7 +1461,9 @@ int dpq_tree_build_gpu(const uint8_t* codes, int64_t n_codes, int M, int K, int 
     std::string err;
     std::vector<uint32_t> finalists;
     std::vector<std::pair<uint32_t, uint32_t>> edges;
-    int rc = dpq::find_edges_gpu(codes, n_codes, M, max_height_folds, device, &finalists, &edges, &err);
+    // DPQ_DEV=1 DPQ_BUILD_PREFILTER=0: every position subset sorted whole, as rounds 2 - 3 did (developer A/B; same tree)
+    const bool prefilter = !(dev_mode() && getenv("DPQ_BUILD_PREFILTER") && atoi(getenv("DPQ_BUILD_PREFILTER")) == 0);
+    int rc = dpq::find_edges_gpu(codes, n_codes, M, max_height_folds, device, &finalists, &edges, &err, prefilter);
     if (rc) return fail(rc, err);
     dpq_tree* t = new dpq_tree();
     // DPQ_DEV=1 DPQ_BUILD_LAYOUT=host keeps the layout on the host (developer A/B; same tree either way)

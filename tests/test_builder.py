@@ -238,3 +238,36 @@ def test_gpu_edge_search_speed_and_structure_1m(lib):
     assert np.array_equal(tree_decode(dev), codes[dev.vec_id])
     print("GPU-assisted build of 1M codes: %.2f s, %.2f diffs/node" % (t_gpu, dev.stats["n_diffs"] / n))
     assert t_gpu < 20
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_subset_prefilter_rule_keeps_every_member_of_a_group(seed):
+    """find_edges_gpu's per-subset pre-filter (dpq_build_gpu.hip, hash_mark_kernel / hash_flag_kernel), restated in numpy: a
+    table of 32-bit words tagged by the subset's epoch; the first node of a slot leaves `tag`, every later arrival raises the
+    word to `tag | 1` (atomicMax, any order of arrival); a node is kept iff its slot ends at `tag | 1`.  Equal keys share a
+    slot, so every member of a group of >= 2 equal keys is kept whatever the arrival order and whatever older epochs left
+    in the table; a node alone under its key is kept only by a collision (and then changes nothing: the grouping returns on
+    groups of one).  CPU only -- the kernels are checked by test_gpu_edge_search_builds_the_identical_tree."""
+    rng = np.random.default_rng(seed)
+    n, slots = 5000, 1 << 12                                   # a crowded table: collisions on purpose
+    table = rng.integers(0, 7, size=slots, dtype=np.uint32)    # leftovers of older epochs (tags below this epoch's)
+    for epoch in (4, 5, 9):
+        tag = np.uint32(epoch << 1)
+        keys = rng.integers(0, 3000, size=n).astype(np.uint64)  # many groups of equal keys, many singletons
+        slot = ((keys * np.uint64(0x9E3779B97F4A7C15)) >> np.uint64(40)).astype(np.int64) & (slots - 1)
+        for i in rng.permutation(n):                            # atomicMax semantics, arbitrary arrival order
+            old = table[slot[i]]
+            table[slot[i]] = max(old, tag)
+            if old >= tag:
+                table[slot[i]] = max(table[slot[i]], tag | np.uint32(1))
+        keep = table[slot] == (tag | np.uint32(1))
+        uniq, counts = np.unique(keys, return_counts=True)
+        in_group = np.isin(keys, uniq[counts >= 2])
+        assert keep[in_group].all()                             # no member of a clique is ever dropped
+        lonely_kept = keep & ~in_group                          # kept by collision only: harmless, and not everything
+        assert lonely_kept.sum() < (~in_group).sum() or (~in_group).sum() == 0
+        # the kept nodes in their original order are what the stable sort then sees: the groups' relative order is unchanged
+        order_all = np.argsort(keys, kind="stable")
+        order_kept = np.flatnonzero(keep)[np.argsort(keys[keep], kind="stable")]
+        assert np.array_equal(order_all[np.isin(order_all, np.flatnonzero(in_group))],
+                              order_kept[np.isin(order_kept, np.flatnonzero(in_group))])
