@@ -138,32 +138,193 @@ __global__ void bump_kernel(const uint32_t* __restrict__ is_child, const uint32_
 // Pre-filter of a position subset (round 4): only nodes whose masked key occurs at least TWICE among the active nodes can
 // be members of a clique, and at M = 16 they are a few per cent -- the sort / group / emit passes then run on those alone
 // (a node alone under its key changes nothing: group_kernel returns on groups of one; the members' relative order, hence the
-// stable sort's and the emitted edges' order, is what it was).  A hash table of 32-bit words tagged by the subset's epoch
-// (no clearing between subsets): the first node of a slot leaves `tag`, every later one raises it to `tag | 1`; a node is
-// kept iff its slot ends at `tag | 1`.  Equal keys share a slot, so no member of a clique is ever dropped; a collision of
-// different keys only keeps a node that the grouping then finds alone.
-__device__ __forceinline__ uint32_t key_slot(uint64_t lo, uint64_t hi, uint32_t slot_mask) {
+// stable sort's and the emitted edges' order, is what it was), and a subset in which no key occurs twice ends there.
+// An open-addressing table of 64-bit words, epoch << 33 | pair << 32 | fingerprint, never cleared: a word of an older epoch
+// is free.  A node claims the first free word of its probe sequence (CAS) or, meeting its own fingerprint, sets the word's
+// pair bit; it is kept iff the word with its fingerprint ends with the pair bit set -- or it found no word in kProbes steps
+// (then so did every node with its key: all of them are kept).  Equal keys walk the same sequence, so no member of a clique
+// is ever dropped; two different keys with one fingerprint and one slot (2^-32) only keep a node the grouping finds alone.
+constexpr int kProbes = 8;
+__device__ __forceinline__ uint64_t key_hash(uint64_t lo, uint64_t hi) {
     uint64_t h = lo * 0x9E3779B97F4A7C15ull;
     h ^= (hi + 0x7F4A7C159E3779B9ull) * 0xC2B2AE3D27D4EB4Full;
     h ^= h >> 29;
     h *= 0xBF58476D1CE4E5B9ull;
     h ^= h >> 32;
-    return (uint32_t)h & slot_mask;
+    return h;
 }
 
 __global__ void hash_mark_kernel(const uint64_t* __restrict__ key_lo, const uint64_t* __restrict__ key_hi, int64_t n,
-                                 uint32_t tag, uint32_t slot_mask, uint32_t* __restrict__ table) {
+                                 uint32_t epoch, uint32_t slot_mask, unsigned long long* __restrict__ table) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    uint32_t* w = table + key_slot(key_lo[i], key_hi ? key_hi[i] : 0, slot_mask);
-    if (atomicMax(w, tag) >= tag) atomicMax(w, tag | 1u);  // tags grow with the epoch: an older subset's word is below `tag`
+    const uint64_t h = key_hash(key_lo[i], key_hi ? key_hi[i] : 0);
+    const uint32_t fp = (uint32_t)(h >> 32);
+    const unsigned long long mine = ((unsigned long long)epoch << 33) | fp;
+    uint32_t s = (uint32_t)h & slot_mask;
+    for (int p = 0; p < kProbes; ++p, s = (s + 1) & slot_mask) {
+        unsigned long long cur = __hip_atomic_load(table + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        while ((uint32_t)(cur >> 33) != epoch) {  // a word of an older epoch is free: claim it
+            const unsigned long long old = atomicCAS(table + s, cur, mine);
+            if (old == cur) return;
+            cur = old;  // somebody else took it in the meantime: look at what is there now
+        }
+        if ((uint32_t)cur == fp) {  // this key is here already: a pair
+            atomicOr(table + s, 1ull << 32);
+            return;
+        }
+    }
 }
 
 __global__ void hash_flag_kernel(const uint64_t* __restrict__ key_lo, const uint64_t* __restrict__ key_hi, int64_t n,
-                                 uint32_t tag, uint32_t slot_mask, const uint32_t* __restrict__ table,
+                                 uint32_t epoch, uint32_t slot_mask, const unsigned long long* __restrict__ table,
                                  uint8_t* __restrict__ flags) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) flags[i] = table[key_slot(key_lo[i], key_hi ? key_hi[i] : 0, slot_mask)] == (tag | 1u) ? 1 : 0;
+    if (i >= n) return;
+    const uint64_t h = key_hash(key_lo[i], key_hi ? key_hi[i] : 0);
+    const uint32_t fp = (uint32_t)(h >> 32);
+    uint32_t s = (uint32_t)h & slot_mask;
+    uint8_t keep = 1;  // no word within kProbes steps: kept (and so is every node with this key)
+    for (int p = 0; p < kProbes; ++p, s = (s + 1) & slot_mask) {
+        const unsigned long long cur = table[s];
+        if ((uint32_t)(cur >> 33) != epoch) break;  // (cannot happen before the node's own word; kept)
+        if ((uint32_t)cur == fp) {
+            keep = (uint8_t)((cur >> 32) & 1ull);
+            break;
+        }
+    }
+    flags[i] = keep;
+}
+
+// A position subset whose pre-filter kept at most kSmallMax nodes, in ONE launch of one block: what the radix sorts, the
+// gathers, group_kernel, the two scans, emit_kernel and bump_kernel do for a long list (about forty launches).  The kept
+// nodes (pos[i] indexes the active list, in its order) are sorted by (key_hi, key_lo, i) -- the order of the two stable
+// radix passes -- by a bitonic network in LDS; a thread per group head walks its group exactly as group_kernel does; the
+// children / finalists are appended in sorted order through block-wide prefix sums.
+constexpr int kSmallMax = 2048;
+constexpr int kSmallThreads = 1024;
+__global__ __launch_bounds__(kSmallThreads) void small_subset_kernel(
+    const uint64_t* __restrict__ key_lo, const uint64_t* __restrict__ key_hi, const uint32_t* __restrict__ act,
+    const uint32_t* __restrict__ pos, int n, int max_h_cap, uint8_t* __restrict__ heights, uint8_t* __restrict__ merged,
+    uint32_t* __restrict__ edges, uint32_t* __restrict__ finalists, uint32_t* __restrict__ counters) {
+    __shared__ uint64_t s_lo[kSmallMax], s_hi[kSmallMax];
+    __shared__ uint32_t s_id[kSmallMax], s_par[kSmallMax];
+    __shared__ uint16_t s_ix[kSmallMax];
+    __shared__ uint8_t s_child[kSmallMax], s_final[kSmallMax];
+    __shared__ uint32_t s_wave[2][kSmallThreads / 64];
+    const int tid = threadIdx.x;
+    const uint32_t base_e = counters[0], base_f = counters[1];  // read before anybody adds to them (thread 0, at the end)
+    int P = 2;
+    while (P < n) P <<= 1;
+    for (int i = tid; i < P; i += kSmallThreads) {
+        if (i < n) {
+            const uint32_t p = pos[i];
+            s_lo[i] = key_lo[p];
+            s_hi[i] = key_hi ? key_hi[p] : 0ull;
+            s_id[i] = act[p];
+        } else {  // padding sorts behind every real entry (its index is larger than any real one)
+            s_lo[i] = ~0ull;
+            s_hi[i] = ~0ull;
+            s_id[i] = 0xffffffffu;
+        }
+        s_ix[i] = (uint16_t)i;
+        s_child[i] = 0;
+        s_final[i] = 0;
+        s_par[i] = 0xffffffffu;
+    }
+    __syncthreads();
+    for (int k = 2; k <= P; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = tid; t < (P >> 1); t += kSmallThreads) {
+                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));  // t-th compare-exchange of the stage: bit j of i clear
+                const int ixj = i | j;
+                const bool up = (i & k) == 0;
+                const uint64_t ah = s_hi[i], bh = s_hi[ixj], al = s_lo[i], bl = s_lo[ixj];
+                const uint16_t ai = s_ix[i], bi = s_ix[ixj];
+                const bool a_gt_b = ah != bh ? ah > bh : al != bl ? al > bl : ai > bi;  // entries are distinct: the index decides
+                if (a_gt_b == up) {
+                    s_hi[i] = bh, s_hi[ixj] = ah;
+                    s_lo[i] = bl, s_lo[ixj] = al;
+                    s_ix[i] = bi, s_ix[ixj] = ai;
+                    const uint32_t x = s_id[i];
+                    s_id[i] = s_id[ixj], s_id[ixj] = x;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    // group heads walk their groups (group_kernel, h:534-600)
+    for (int i = tid; i < n; i += kSmallThreads) {
+        const uint64_t klo = s_lo[i], khi = s_hi[i];
+        if (i > 0 && s_lo[i - 1] == klo && s_hi[i - 1] == khi) continue;  // not a group head
+        int end = i + 1;
+        while (end < n && s_lo[end] == klo && s_hi[end] == khi) ++end;
+        if (end - i < 2) continue;
+        int max_h = -1, second_h = 0, pj = i;
+        for (int j = i; j < end; ++j) {  // tallest member, first wins (h:547-558)
+            const int h = heights[s_id[j]];
+            if (h > max_h) {
+                max_h = h;
+                pj = j;
+            }
+        }
+        const uint32_t parent = s_id[pj];
+        for (int j = i; j < end; ++j)
+            if (j != pj) {
+                const int h = heights[s_id[j]];
+                if (h > second_h) second_h = h;
+            }
+        if (second_h == max_h) heights[parent] = (uint8_t)(max_h + 1);  // h:569
+        if (max_h + 1 >= max_h_cap) {                                   // h:570-575
+            s_final[pj] = 1;
+            merged[parent] = 1;
+        }
+        for (int j = i; j < end; ++j)
+            if (j != pj) {
+                merged[s_id[j]] = 1;
+                s_child[j] = 1;
+                s_par[j] = parent;
+            }
+    }
+    __syncthreads();
+    // slots of the children / finalists in sorted order: thread t owns entries 2 t, 2 t + 1
+    const int e0 = 2 * tid, e1 = 2 * tid + 1;
+    const uint32_t c0 = e0 < n ? s_child[e0] : 0u, c1 = e1 < n ? s_child[e1] : 0u;
+    const uint32_t f0 = e0 < n ? s_final[e0] : 0u, f1 = e1 < n ? s_final[e1] : 0u;
+    uint32_t ci = c0 + c1, fi = f0 + f1;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t cu = (uint32_t)__shfl_up((int)ci, off, 64), fu = (uint32_t)__shfl_up((int)fi, off, 64);
+        if ((tid & 63) >= off) ci += cu, fi += fu;
+    }
+    if ((tid & 63) == 63) {
+        s_wave[0][tid >> 6] = ci;
+        s_wave[1][tid >> 6] = fi;
+    }
+    __syncthreads();
+    uint32_t cb = 0, fb = 0, ct = 0, ft = 0;
+    for (int w = 0; w < kSmallThreads / 64; ++w) {
+        const uint32_t cw = s_wave[0][w], fw = s_wave[1][w];
+        cb += w < (tid >> 6) ? cw : 0u, fb += w < (tid >> 6) ? fw : 0u;
+        ct += cw, ft += fw;
+    }
+    uint32_t cs = cb + ci - (c0 + c1), fs = fb + fi - (f0 + f1);  // exclusive prefixes at entry e0
+    if (c0) {
+        const size_t e = (size_t)base_e + cs;
+        edges[2 * e] = s_par[e0], edges[2 * e + 1] = s_id[e0];
+    }
+    cs += c0;
+    if (c1) {
+        const size_t e = (size_t)base_e + cs;
+        edges[2 * e] = s_par[e1], edges[2 * e + 1] = s_id[e1];
+    }
+    if (f0) finalists[(size_t)base_f + fs] = s_id[e0];
+    fs += f0;
+    if (f1) finalists[(size_t)base_f + fs] = s_id[e1];
+    if (tid == 0) {
+        counters[0] = base_e + ct;
+        counters[1] = base_f + ft;
+    }
 }
 
 __global__ void unmerged_flags_kernel(const uint32_t* __restrict__ ids, const uint8_t* __restrict__ merged, int64_t n,
@@ -196,7 +357,8 @@ int find_edges_gpu(const uint8_t* codes, int64_t n, int M, int max_height_folds,
              *d_cslot = nullptr, *d_fslot = nullptr, *d_edges = nullptr, *d_finalists = nullptr, *d_counters = nullptr,
              *d_num = nullptr, *d_perm_a = nullptr, *d_perm_b = nullptr;
     uint64_t *d_klo_a = nullptr, *d_klo_b = nullptr, *d_khi_a = nullptr, *d_khi_b = nullptr;
-    uint32_t *d_table = nullptr, *d_iota = nullptr, *d_pos = nullptr;  // the subsets' pre-filter (hash_mark_kernel)
+    unsigned long long* d_table = nullptr;  // the subsets' pre-filter (hash_mark_kernel)
+    uint32_t *d_iota = nullptr, *d_pos = nullptr;
     uint32_t slot_mask = 0, epoch = 0;
     void* d_temp = nullptr;
     size_t temp_bytes = 0;
@@ -247,11 +409,10 @@ int find_edges_gpu(const uint8_t* codes, int64_t n, int M, int max_height_folds,
     hipLaunchKernelGGL(iota_kernel, dim3(blocks_for(n)), dim3(256), 0, 0, d_cur, n);
     if (prefilter) {
         size_t slots = 1u << 16;
-        // load factor <= 1/16 (at 1/4 collisions alone kept 22 % of the nodes: profiles/r04b_builder_prefilter_m16.txt); 1 GB at most
-        while (slots < 16 * N && slots < ((size_t)1 << 28)) slots <<= 1;
+        while (slots < 4 * N && slots < ((size_t)1 << 27)) slots <<= 1;  // load <= 1/4 (probing resolves the collisions); 1 GB at most
         slot_mask = (uint32_t)(slots - 1);
-        GB_HIP(hipMalloc(&d_table, slots * 4));
-        GB_HIP(hipMemset(d_table, 0, slots * 4));
+        GB_HIP(hipMalloc(&d_table, slots * 8));
+        GB_HIP(hipMemset(d_table, 0, slots * 8));  // epoch 0 is never used
         GB_HIP(hipMalloc(&d_iota, N * 4));
         GB_HIP(hipMalloc(&d_pos, N * 4));
         hipLaunchKernelGGL(iota_kernel, dim3(blocks_for(n)), dim3(256), 0, 0, d_iota, n);
@@ -259,14 +420,19 @@ int find_edges_gpu(const uint8_t* codes, int64_t n, int M, int max_height_folds,
 
     for (int diff = 0; diff <= M; ++diff) {
         position_subsets(M, M - diff, &combos);
+        bool act_fresh = false;  // d_act / n_act_list are the active list of d_cur as it stands (nothing merged since)
+        uint32_t n_act_list = 0;
         for (const auto& kept : combos) {
             // act = unmerged ids of cur, order kept
-            hipLaunchKernelGGL(unmerged_flags_kernel, dim3(blocks_for(n_cur)), dim3(256), 0, 0, d_cur, d_merged, n_cur,
-                               d_flags);
             size_t tb = temp_bytes;
-            GB_HIP(hipcub::DeviceSelect::Flagged(d_temp, tb, d_cur, d_flags, d_act, d_num, (int)n_cur));
-            uint32_t n_act = 0;
-            GB_HIP(hipMemcpy(&n_act, d_num, 4, hipMemcpyDeviceToHost));
+            if (!act_fresh) {
+                hipLaunchKernelGGL(unmerged_flags_kernel, dim3(blocks_for(n_cur)), dim3(256), 0, 0, d_cur, d_merged, n_cur,
+                                   d_flags);
+                GB_HIP(hipcub::DeviceSelect::Flagged(d_temp, tb, d_cur, d_flags, d_act, d_num, (int)n_cur));
+                GB_HIP(hipMemcpy(&n_act_list, d_num, 4, hipMemcpyDeviceToHost));
+            }
+            act_fresh = false;
+            uint32_t n_act = n_act_list;
             if (n_act < 2) break;
             uint64_t mlo = 0, mhi = 0;
             for (int pos : kept) {
@@ -276,16 +442,25 @@ int find_edges_gpu(const uint8_t* codes, int64_t n, int M, int max_height_folds,
             hipLaunchKernelGGL(make_keys_kernel, dim3(blocks_for(n_act)), dim3(256), 0, 0, d_codes, M, d_act,
                                (int64_t)n_act, mlo, mhi, d_klo_a, wide ? d_khi_a : nullptr);
             if (prefilter) {
-                const uint32_t tag = ++epoch << 1;  // < 2^31: at most 2^16 subsets per diff, M + 1 diffs
+                ++epoch;  // < 2^31: at most 2^16 subsets per diff, M + 1 diffs
                 hipLaunchKernelGGL(hash_mark_kernel, dim3(blocks_for(n_act)), dim3(256), 0, 0, d_klo_a,
-                                   wide ? d_khi_a : nullptr, (int64_t)n_act, tag, slot_mask, d_table);
+                                   wide ? d_khi_a : nullptr, (int64_t)n_act, epoch, slot_mask, d_table);
                 hipLaunchKernelGGL(hash_flag_kernel, dim3(blocks_for(n_act)), dim3(256), 0, 0, d_klo_a,
-                                   wide ? d_khi_a : nullptr, (int64_t)n_act, tag, slot_mask, d_table, d_flags);
+                                   wide ? d_khi_a : nullptr, (int64_t)n_act, epoch, slot_mask, d_table, d_flags);
                 tb = temp_bytes;
                 GB_HIP(hipcub::DeviceSelect::Flagged(d_temp, tb, d_iota, d_flags, d_pos, d_num, (int)n_act));
                 uint32_t n_keep = 0;
                 GB_HIP(hipMemcpy(&n_keep, d_num, 4, hipMemcpyDeviceToHost));
-                if (n_keep < 2) continue;  // no two active nodes agree on the kept positions: nothing to merge
+                if (n_keep < 2) {  // no two active nodes agree on the kept positions: nothing to merge,
+                    act_fresh = true;  // and the active list stays what it is for the next subset
+                    continue;
+                }
+                if (n_keep <= (uint32_t)kSmallMax) {  // a short list: sort, group and emit in one launch
+                    hipLaunchKernelGGL(small_subset_kernel, dim3(1), dim3(kSmallThreads), 0, 0, d_klo_a,
+                                       wide ? d_khi_a : nullptr, d_act, d_pos, (int)n_keep, MAXH - 2, d_heights, d_merged,
+                                       d_edges, d_finalists, d_counters);
+                    continue;
+                }
                 if (n_keep < n_act) {
                     // the kept nodes, in their order, take the place of the active list for the rest of this subset
                     hipLaunchKernelGGL(gather_u32_kernel, dim3(blocks_for(n_keep)), dim3(256), 0, 0, d_act, d_pos,
