@@ -154,43 +154,70 @@ __device__ __forceinline__ uint64_t key_hash(uint64_t lo, uint64_t hi) {
     return h;
 }
 
-__global__ void hash_mark_kernel(const uint64_t* __restrict__ key_lo, const uint64_t* __restrict__ key_hi, int64_t n,
-                                 uint32_t epoch, uint32_t slot_mask, unsigned long long* __restrict__ table) {
+// The subset's masked keys of the unmerged nodes of the diff's list (`cur`, compacted once per diff: a node merged since
+// is skipped here, so no per-subset compaction), written for the passes behind and entered into the table.  Thread 0
+// also clears the counter of kept nodes that hash_flag_kernel (the next launch) adds to.
+__global__ void keys_mark_kernel(const uint8_t* __restrict__ codes, int M, const uint32_t* __restrict__ cur, int64_t n,
+                                 const uint8_t* __restrict__ merged, uint64_t mask_lo, uint64_t mask_hi,
+                                 uint64_t* __restrict__ key_lo, uint64_t* __restrict__ key_hi, uint32_t epoch,
+                                 uint32_t slot_mask, unsigned long long* __restrict__ table, uint32_t* __restrict__ n_kept) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) *n_kept = 0;
     if (i >= n) return;
-    const uint64_t h = key_hash(key_lo[i], key_hi ? key_hi[i] : 0);
+    const uint32_t id = cur[i];
+    if (merged[id]) return;
+    const uint8_t* c = codes + (size_t)id * M;
+    uint64_t lo = 0, hi = 0;
+    for (int m = 0; m < M && m < 8; ++m) lo |= (uint64_t)c[m] << (8 * m);
+    for (int m = 8; m < M; ++m) hi |= (uint64_t)c[m] << (8 * (m - 8));
+    lo &= mask_lo;
+    hi &= mask_hi;
+    key_lo[i] = lo;
+    if (key_hi) key_hi[i] = hi;
+    const uint64_t h = key_hash(lo, key_hi ? hi : 0);
     const uint32_t fp = (uint32_t)(h >> 32);
     const unsigned long long mine = ((unsigned long long)epoch << 33) | fp;
     uint32_t s = (uint32_t)h & slot_mask;
     for (int p = 0; p < kProbes; ++p, s = (s + 1) & slot_mask) {
-        unsigned long long cur = __hip_atomic_load(table + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        while ((uint32_t)(cur >> 33) != epoch) {  // a word of an older epoch is free: claim it
-            const unsigned long long old = atomicCAS(table + s, cur, mine);
-            if (old == cur) return;
-            cur = old;  // somebody else took it in the meantime: look at what is there now
+        unsigned long long c0 = __hip_atomic_load(table + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        while ((uint32_t)(c0 >> 33) != epoch) {  // a word of an older epoch is free: claim it
+            const unsigned long long old = atomicCAS(table + s, c0, mine);
+            if (old == c0) return;
+            c0 = old;  // somebody else took it in the meantime: look at what is there now
         }
-        if ((uint32_t)cur == fp) {  // this key is here already: a pair
+        if ((uint32_t)c0 == fp) {  // this key is here already: a pair
             atomicOr(table + s, 1ull << 32);
             return;
         }
     }
 }
 
-__global__ void hash_flag_kernel(const uint64_t* __restrict__ key_lo, const uint64_t* __restrict__ key_hi, int64_t n,
-                                 uint32_t epoch, uint32_t slot_mask, const unsigned long long* __restrict__ table,
-                                 uint8_t* __restrict__ flags) {
+// flags[i] = the node is kept; the kept nodes' positions in `cur` are also appended (in any order: what sorts them
+// breaks ties by position) to `kept` while they number at most `list_cap` -- the short list of small_subset_kernel.
+__global__ void hash_flag_kernel(const uint32_t* __restrict__ cur, int64_t n, const uint8_t* __restrict__ merged,
+                                 const uint64_t* __restrict__ key_lo, const uint64_t* __restrict__ key_hi, uint32_t epoch,
+                                 uint32_t slot_mask, const unsigned long long* __restrict__ table,
+                                 uint8_t* __restrict__ flags, uint32_t* __restrict__ kept, uint32_t* __restrict__ n_kept,
+                                 uint32_t list_cap) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const uint64_t h = key_hash(key_lo[i], key_hi ? key_hi[i] : 0);
-    const uint32_t fp = (uint32_t)(h >> 32);
-    uint32_t s = (uint32_t)h & slot_mask;
-    uint8_t keep = 1;  // no word within kProbes steps: kept (and so is every node with this key)
-    for (int p = 0; p < kProbes; ++p, s = (s + 1) & slot_mask) {
-        const unsigned long long cur = table[s];
-        if ((uint32_t)(cur >> 33) != epoch) break;  // (cannot happen before the node's own word; kept)
-        if ((uint32_t)cur == fp) {
-            keep = (uint8_t)((cur >> 32) & 1ull);
-            break;
+    uint8_t keep = 0;
+    if (!merged[cur[i]]) {
+        const uint64_t h = key_hash(key_lo[i], key_hi ? key_hi[i] : 0);
+        const uint32_t fp = (uint32_t)(h >> 32);
+        uint32_t s = (uint32_t)h & slot_mask;
+        keep = 1;  // no word within kProbes steps: kept (and so is every node with this key)
+        for (int p = 0; p < kProbes; ++p, s = (s + 1) & slot_mask) {
+            const unsigned long long c0 = table[s];
+            if ((uint32_t)(c0 >> 33) != epoch) break;  // (cannot happen before the node's own word; kept)
+            if ((uint32_t)c0 == fp) {
+                keep = (uint8_t)((c0 >> 32) & 1ull);
+                break;
+            }
+        }
+        if (keep) {
+            const uint32_t slot = atomicAdd(n_kept, 1u);
+            if (slot < list_cap) kept[slot] = (uint32_t)i;
         }
     }
     flags[i] = keep;
@@ -198,8 +225,8 @@ __global__ void hash_flag_kernel(const uint64_t* __restrict__ key_lo, const uint
 
 // A position subset whose pre-filter kept at most kSmallMax nodes, in ONE launch of one block: what the radix sorts, the
 // gathers, group_kernel, the two scans, emit_kernel and bump_kernel do for a long list (about forty launches).  The kept
-// nodes (pos[i] indexes the active list, in its order) are sorted by (key_hi, key_lo, i) -- the order of the two stable
-// radix passes -- by a bitonic network in LDS; a thread per group head walks its group exactly as group_kernel does; the
+// nodes (pos[] = their positions in the diff's list `act`, in any order) are sorted by (key_hi, key_lo, position) -- the
+// order of the two stable radix passes over the list -- by a bitonic network in LDS; a thread per group head walks its group exactly as group_kernel does; the
 // children / finalists are appended in sorted order through block-wide prefix sums.
 constexpr int kSmallMax = 2048;
 constexpr int kSmallThreads = 1024;
@@ -209,7 +236,7 @@ __global__ __launch_bounds__(kSmallThreads) void small_subset_kernel(
     uint32_t* __restrict__ edges, uint32_t* __restrict__ finalists, uint32_t* __restrict__ counters) {
     __shared__ uint64_t s_lo[kSmallMax], s_hi[kSmallMax];
     __shared__ uint32_t s_id[kSmallMax], s_par[kSmallMax];
-    __shared__ uint16_t s_ix[kSmallMax];
+    __shared__ uint32_t s_ix[kSmallMax];  // position in the diff's list: the ties' order (the list arrives in any order)
     __shared__ uint8_t s_child[kSmallMax], s_final[kSmallMax];
     __shared__ uint32_t s_wave[2][kSmallThreads / 64];
     const int tid = threadIdx.x;
@@ -227,7 +254,7 @@ __global__ __launch_bounds__(kSmallThreads) void small_subset_kernel(
             s_hi[i] = ~0ull;
             s_id[i] = 0xffffffffu;
         }
-        s_ix[i] = (uint16_t)i;
+        s_ix[i] = i < n ? pos[i] : 0xffffffffu;
         s_child[i] = 0;
         s_final[i] = 0;
         s_par[i] = 0xffffffffu;
@@ -240,8 +267,9 @@ __global__ __launch_bounds__(kSmallThreads) void small_subset_kernel(
                 const int ixj = i | j;
                 const bool up = (i & k) == 0;
                 const uint64_t ah = s_hi[i], bh = s_hi[ixj], al = s_lo[i], bl = s_lo[ixj];
-                const uint16_t ai = s_ix[i], bi = s_ix[ixj];
-                const bool a_gt_b = ah != bh ? ah > bh : al != bl ? al > bl : ai > bi;  // entries are distinct: the index decides
+                const uint32_t ai = s_ix[i], bi = s_ix[ixj];
+                // (real entries are distinct by position; padding entries compare equal among themselves: either order)
+                const bool a_gt_b = ah != bh ? ah > bh : al != bl ? al > bl : ai > bi;
                 if (a_gt_b == up) {
                     s_hi[i] = bh, s_hi[ixj] = ah;
                     s_lo[i] = bl, s_lo[ixj] = al;
@@ -357,7 +385,7 @@ int find_edges_gpu(const uint8_t* codes, int64_t n, int M, int max_height_folds,
              *d_cslot = nullptr, *d_fslot = nullptr, *d_edges = nullptr, *d_finalists = nullptr, *d_counters = nullptr,
              *d_num = nullptr, *d_perm_a = nullptr, *d_perm_b = nullptr;
     uint64_t *d_klo_a = nullptr, *d_klo_b = nullptr, *d_khi_a = nullptr, *d_khi_b = nullptr;
-    unsigned long long* d_table = nullptr;  // the subsets' pre-filter (hash_mark_kernel)
+    unsigned long long* d_table = nullptr;  // the subsets' pre-filter (keys_mark_kernel)
     uint32_t *d_iota = nullptr, *d_pos = nullptr;
     uint32_t slot_mask = 0, epoch = 0;
     void* d_temp = nullptr;
@@ -420,62 +448,54 @@ int find_edges_gpu(const uint8_t* codes, int64_t n, int M, int max_height_folds,
 
     for (int diff = 0; diff <= M; ++diff) {
         position_subsets(M, M - diff, &combos);
-        bool act_fresh = false;  // d_act / n_act_list are the active list of d_cur as it stands (nothing merged since)
-        uint32_t n_act_list = 0;
         for (const auto& kept : combos) {
-            // act = unmerged ids of cur, order kept
             size_t tb = temp_bytes;
-            if (!act_fresh) {
-                hipLaunchKernelGGL(unmerged_flags_kernel, dim3(blocks_for(n_cur)), dim3(256), 0, 0, d_cur, d_merged, n_cur,
-                                   d_flags);
-                GB_HIP(hipcub::DeviceSelect::Flagged(d_temp, tb, d_cur, d_flags, d_act, d_num, (int)n_cur));
-                GB_HIP(hipMemcpy(&n_act_list, d_num, 4, hipMemcpyDeviceToHost));
-            }
-            act_fresh = false;
-            uint32_t n_act = n_act_list;
-            if (n_act < 2) break;
             uint64_t mlo = 0, mhi = 0;
             for (int pos : kept) {
                 if (pos < 8) mlo |= 0xffull << (8 * pos);
                 else mhi |= 0xffull << (8 * (pos - 8));
             }
-            hipLaunchKernelGGL(make_keys_kernel, dim3(blocks_for(n_act)), dim3(256), 0, 0, d_codes, M, d_act,
-                               (int64_t)n_act, mlo, mhi, d_klo_a, wide ? d_khi_a : nullptr);
+            uint32_t n_act = 0;
             if (prefilter) {
+                // keys of the unmerged nodes of the diff's list + the pair table; then who is kept (a count and a short list)
                 ++epoch;  // < 2^31: at most 2^16 subsets per diff, M + 1 diffs
-                hipLaunchKernelGGL(hash_mark_kernel, dim3(blocks_for(n_act)), dim3(256), 0, 0, d_klo_a,
-                                   wide ? d_khi_a : nullptr, (int64_t)n_act, epoch, slot_mask, d_table);
-                hipLaunchKernelGGL(hash_flag_kernel, dim3(blocks_for(n_act)), dim3(256), 0, 0, d_klo_a,
-                                   wide ? d_khi_a : nullptr, (int64_t)n_act, epoch, slot_mask, d_table, d_flags);
-                tb = temp_bytes;
-                GB_HIP(hipcub::DeviceSelect::Flagged(d_temp, tb, d_iota, d_flags, d_pos, d_num, (int)n_act));
+                hipLaunchKernelGGL(keys_mark_kernel, dim3(blocks_for(n_cur)), dim3(256), 0, 0, d_codes, M, d_cur, n_cur,
+                                   d_merged, mlo, mhi, d_klo_a, wide ? d_khi_a : nullptr, epoch, slot_mask, d_table, d_num);
+                hipLaunchKernelGGL(hash_flag_kernel, dim3(blocks_for(n_cur)), dim3(256), 0, 0, d_cur, n_cur, d_merged,
+                                   d_klo_a, wide ? d_khi_a : nullptr, epoch, slot_mask, d_table, d_flags, d_pos, d_num,
+                                   (uint32_t)kSmallMax);
                 uint32_t n_keep = 0;
                 GB_HIP(hipMemcpy(&n_keep, d_num, 4, hipMemcpyDeviceToHost));
-                if (n_keep < 2) {  // no two active nodes agree on the kept positions: nothing to merge,
-                    act_fresh = true;  // and the active list stays what it is for the next subset
-                    continue;
-                }
+                // (h:1288 stops a diff's subsets once fewer than two nodes are unmerged: such subsets keep nothing here)
+                if (n_keep < 2) continue;  // no two unmerged nodes agree on the kept positions: nothing to merge
                 if (n_keep <= (uint32_t)kSmallMax) {  // a short list: sort, group and emit in one launch
                     hipLaunchKernelGGL(small_subset_kernel, dim3(1), dim3(kSmallThreads), 0, 0, d_klo_a,
-                                       wide ? d_khi_a : nullptr, d_act, d_pos, (int)n_keep, MAXH - 2, d_heights, d_merged,
+                                       wide ? d_khi_a : nullptr, d_cur, d_pos, (int)n_keep, MAXH - 2, d_heights, d_merged,
                                        d_edges, d_finalists, d_counters);
                     continue;
                 }
-                if (n_keep < n_act) {
-                    // the kept nodes, in their order, take the place of the active list for the rest of this subset
-                    hipLaunchKernelGGL(gather_u32_kernel, dim3(blocks_for(n_keep)), dim3(256), 0, 0, d_act, d_pos,
-                                       (int64_t)n_keep, d_ids_b);
-                    hipLaunchKernelGGL(gather_u64_kernel, dim3(blocks_for(n_keep)), dim3(256), 0, 0, d_klo_a, d_pos,
-                                       (int64_t)n_keep, d_klo_b);
-                    GB_HIP(hipMemcpyAsync(d_act, d_ids_b, (size_t)n_keep * 4, hipMemcpyDeviceToDevice, 0));
-                    GB_HIP(hipMemcpyAsync(d_klo_a, d_klo_b, (size_t)n_keep * 8, hipMemcpyDeviceToDevice, 0));
-                    if (wide) {
-                        hipLaunchKernelGGL(gather_u64_kernel, dim3(blocks_for(n_keep)), dim3(256), 0, 0, d_khi_a, d_pos,
-                                           (int64_t)n_keep, d_khi_b);
-                        GB_HIP(hipMemcpyAsync(d_khi_a, d_khi_b, (size_t)n_keep * 8, hipMemcpyDeviceToDevice, 0));
-                    }
-                    n_act = n_keep;
+                // a long list: the kept nodes, in the list's order, are what the passes below sort
+                GB_HIP(hipcub::DeviceSelect::Flagged(d_temp, tb, d_iota, d_flags, d_pos, d_num, (int)n_cur));
+                hipLaunchKernelGGL(gather_u32_kernel, dim3(blocks_for(n_keep)), dim3(256), 0, 0, d_cur, d_pos,
+                                   (int64_t)n_keep, d_act);
+                hipLaunchKernelGGL(gather_u64_kernel, dim3(blocks_for(n_keep)), dim3(256), 0, 0, d_klo_a, d_pos,
+                                   (int64_t)n_keep, d_klo_b);
+                GB_HIP(hipMemcpyAsync(d_klo_a, d_klo_b, (size_t)n_keep * 8, hipMemcpyDeviceToDevice, 0));
+                if (wide) {
+                    hipLaunchKernelGGL(gather_u64_kernel, dim3(blocks_for(n_keep)), dim3(256), 0, 0, d_khi_a, d_pos,
+                                       (int64_t)n_keep, d_khi_b);
+                    GB_HIP(hipMemcpyAsync(d_khi_a, d_khi_b, (size_t)n_keep * 8, hipMemcpyDeviceToDevice, 0));
                 }
+                n_act = n_keep;
+            } else {
+                // act = unmerged ids of cur, order kept
+                hipLaunchKernelGGL(unmerged_flags_kernel, dim3(blocks_for(n_cur)), dim3(256), 0, 0, d_cur, d_merged, n_cur,
+                                   d_flags);
+                GB_HIP(hipcub::DeviceSelect::Flagged(d_temp, tb, d_cur, d_flags, d_act, d_num, (int)n_cur));
+                GB_HIP(hipMemcpy(&n_act, d_num, 4, hipMemcpyDeviceToHost));
+                if (n_act < 2) break;
+                hipLaunchKernelGGL(make_keys_kernel, dim3(blocks_for(n_act)), dim3(256), 0, 0, d_codes, M, d_act,
+                                   (int64_t)n_act, mlo, mhi, d_klo_a, wide ? d_khi_a : nullptr);
             }
             const uint64_t *s_lo = nullptr, *s_hi = nullptr;
             const uint32_t* s_ids = nullptr;
