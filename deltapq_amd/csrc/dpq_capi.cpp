@@ -94,7 +94,7 @@ struct Tuning {
     int boot_cap = 0, boot_target = 0;
     int boot_variant = 1;  // bootstrap_kernel's V (dpq_kernels.hip); 0 = the kernel of rounds 2 - 3  [DPQ_BOOT_VARIANT]
     int select_threads = 0;  // select_kernel block size, 0 = by top_k  [DPQ_SELECT_THREADS]
-    int select_fast = 1;     // the last level of a small top_k from one histogram pass (select_kernel)  [DPQ_SELECT_FAST=0: radix select]
+    int select_fast = 1;     // the last level as a bucket sort from one histogram pass (select_kernel)  [DPQ_SELECT_FAST=0: radix select + rank count / bitonic network]
     int64_t batch_tile_nodes = (int64_t)16 << 20;
     bool relabel = true, fuse_quantise = true, async_overlap = true, boot_fullsort = false, tighten = true, strands = true,
          force_strands = false, strand1 = true;

@@ -108,7 +108,7 @@ struct SelectArgs {
     int32_t keep_thr;              // 1: thr_key = min(thr_key, this level's k-th key) (levels after a bootstrap)
     unsigned long long* stamps;    // developer diagnostics (NULL in product calls): [slots][8] s_memtime marks
     int32_t threads;               // block size (256 / 512 / 1024); 0 = by top_k (launch_select)
-    int32_t fast_final;            // 1: the last level of a top_k <= 256 ranks what one histogram pass leaves (select_kernel)
+    int32_t fast_final;            // 1: the last level is a bucket sort from one histogram pass (select_kernel); 0: the exact way
 };
 
 // Threshold bootstrap from the inverted multi-index (see bootstrap_kernel).
